@@ -1,0 +1,81 @@
+"""ctypes binding of libgsr_hip.so (the C ABI of include/gsr.h).
+
+There is NO fallback: if the library is missing or fails to load, importing the
+rasterizer raises.  ctypes releases the GIL for the duration of every native call
+(the reference's pybind functions hold it, ext.cpp:16-19).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+GSR_ABI_VERSION = 1
+
+#: every symbol include/gsr.h declares, with (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    "gsr_abi_version": (c_int, []),
+    "gsr_status_string": (ctypes.c_char_p, [c_int]),
+    "gsr_last_hip_error": (c_int, []),
+    "gsr_scratch_sizes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
+    "gsr_sort_key_bits": (c_int, [c_int, c_int]),
+    "gsr_preprocess": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
+                               c_float, c_float, c_int, c_int, _P, _P, POINTER(c_int64)]),
+    "gsr_bin": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
+                             _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
+    "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_debug_export_binning": (c_int, [_P, c_int64, c_int, c_int, _P, _P, _P]),
+    "gsr_debug_export_image": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class GsrError(RuntimeError):
+    """A native call returned a non-zero gsr_status."""
+
+    def __init__(self, fn: str, status: int, message: str, hip_error: int = 0):
+        self.status = status
+        self.hip_error = hip_error
+        extra = f" (hipError_t {hip_error})" if hip_error else ""
+        super().__init__(f"{fn} failed: {message} [status {status}]{extra}")
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and type the native library.  Raises if it is absent: build it with
+    `python -c 'import __graft_entry__ as g; g.build()'` or `make -C gaussianeditor_amd/csrc`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU or PyTorch fallback; "
+                "run `make -C gaussianeditor_amd/csrc` (hipcc --offload-arch=gfx950).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        if L.gsr_abi_version() != GSR_ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {L.gsr_abi_version()} != expected {GSR_ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(fn: str, status: int) -> None:
+    if status != 0:
+        L = lib()
+        msg = L.gsr_status_string(status).decode()
+        raise GsrError(fn, status, msg, L.gsr_last_hip_error() if status == -4 else 0)
+
+
+def scratch_sizes(P: int, R: int, W: int, H: int):
+    sizes = (c_size_t * 3)()
+    check("gsr_scratch_sizes", lib().gsr_scratch_sizes(P, R, W, H, sizes))
+    return int(sizes[0]), int(sizes[1]), int(sizes[2])

@@ -1,0 +1,248 @@
+// gsr_capi.hip -- the C ABI declared in include/gsr.h: argument checking, scratch carving and
+// kernel sequencing.  No device memory is allocated here and no global state is kept.
+#include <math.h>
+#include <string.h>
+
+
+#include "gsr_kernels.h"
+
+using namespace gsr;
+
+namespace {
+thread_local int g_last_hip_error = 0;
+inline int hip_fail(hipError_t e) {
+  g_last_hip_error = (int)e;
+  return GSR_ERR_HIP;
+}
+#define GSR_HIP(expr)                          \
+  do {                                         \
+    hipError_t _e = (expr);                    \
+    if (_e != hipSuccess) return hip_fail(_e); \
+  } while (0)
+
+inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg) {
+  BlendArgs a;
+  memset(&a, 0, sizeof(a));
+  a.W = W;
+  a.H = H;
+  a.gx = (W + TILE - 1) / TILE;
+  a.gy = (H + TILE - 1) / TILE;
+  a.ranges = im.ranges;
+  a.point_list = b.vals[b.final_buf];
+  a.rec0 = g.rec0;
+  a.rec1 = g.rec1;
+  a.rec2 = g.rec2;
+  a.bg = bg;
+  a.final_T = im.final_T;
+  a.n_contrib = im.n_contrib;
+  return a;
+}
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+const char* gsr_status_string(int status) {
+  switch (status) {
+    case GSR_OK: return "ok";
+    case GSR_ERR_BAD_ARGUMENT: return "bad argument";
+    case GSR_ERR_BAD_CHANNELS: return "unsupported number of channels (apply_weights supports 1, 2 or 3)";
+    case GSR_ERR_TOO_MANY: return "number of rendered instances exceeds the 31-bit index space";
+    case GSR_ERR_HIP: return "HIP runtime error";
+    case GSR_ERR_PREFILTERED: return "point culled although prefiltered is set";
+    default: return "unknown status";
+  }
+}
+
+int gsr_last_hip_error(void) { return g_last_hip_error; }
+
+int gsr_sort_key_bits(int W, int H) { return sort_key_bits(W, H); }
+
+int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
+  sizes[0] = carve_geom(nullptr, P).bytes;
+  sizes[1] = carve_binning(nullptr, R, W, H).bytes;
+  sizes[2] = carve_image(nullptr, W, H).bytes;
+  return GSR_OK;
+}
+
+int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                   const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                   const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                   int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, int32_t* radii,
+                   void* geom, int64_t* num_rendered_host) {
+  (void)prefiltered;  // the reference only uses it to trap on an impossible condition (auxiliary.h:156-160)
+  if (num_rendered_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
+  *num_rendered_host = 0;
+  if (P == 0) return GSR_OK;
+  if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
+  if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
+  if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr)) return GSR_ERR_BAD_ARGUMENT;
+  if (!skip_color) {
+    // the reference throws std::runtime_error for "non-RGB without precomputed colours"
+    // (rasterizer_impl.cu:210-213); with NUM_CHANNELS == 3 the only failure left is "no colour source".
+    if (colors_precomp == nullptr && (shs == nullptr || campos == nullptr)) return GSR_ERR_BAD_ARGUMENT;
+    if (colors_precomp == nullptr && M < (D + 1) * (D + 1)) return GSR_ERR_BAD_ARGUMENT;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  PreArgs a;
+  a.P = P; a.D = D; a.M = M;
+  a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
+  a.opacities = opacities; a.shs = shs; a.cov3D_precomp = cov3D_precomp; a.colors_precomp = colors_precomp;
+  a.viewmatrix = viewmatrix; a.projmatrix = projmatrix; a.campos = campos;
+  a.W = W; a.H = H; a.tan_fovx = tan_fovx; a.tan_fovy = tan_fovy;
+  a.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:190-191
+  a.focal_x = W / (2.0f * tan_fovx);
+  a.gx = (W + TILE - 1) / TILE; a.gy = (H + TILE - 1) / TILE;
+  a.skip_color = skip_color;
+  a.radii = radii;
+  a.g = carve_geom(geom, P);
+  GSR_HIP(launch_preprocess(s, a));
+  // the one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239)
+  uint64_t total = 0;
+  GSR_HIP(hipMemcpyAsync(&total, a.g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
+  *num_rendered_host = (int64_t)total;
+  return GSR_OK;
+}
+
+int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, const void* geom, void* binning,
+            void* image) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !image) return GSR_ERR_BAD_ARGUMENT;
+  if (R >= (1ll << 31)) return GSR_ERR_TOO_MANY;
+  if (R > 0 && (!radii || !geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(binning, R, W, H);
+  const Image im = carve_image(image, W, H);
+  GSR_HIP(launch_binning((hipStream_t)stream, P, R, W, H, radii, g, b, im));
+  return GSR_OK;
+}
+
+int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                      const void* binning, void* image, float* out_color, float* out_depth) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth) return GSR_ERR_BAD_ARGUMENT;
+  if (R > 0 && (!geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Image im = carve_image(image, W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg);
+  a.out_color = out_color;
+  a.out_depth = out_depth;
+  GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
+int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii, const void* geom,
+                 const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drots) {
+  (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
+  if (P == 0) return GSR_OK;
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
+  if (!bg || !means3D || !viewmatrix || !projmatrix || !radii || !geom || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
+  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
+  if (shs && (!dL_dsh || !campos)) return GSR_ERR_BAD_ARGUMENT;
+  if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
+  if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Image im = carve_image(const_cast<void*>(image), W, H);
+  if (R > 0) {
+    const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+    BlendArgs a = make_blend_args(W, H, g, b, im, bg);
+    a.dL_dpix = dL_dpix;
+    a.dL_dmean2D = dL_dmeans2D;
+    a.dL_dconic = dL_dconic;
+    a.dL_dopacity = dL_dopacity;
+    a.dL_dcolors = dL_dcolors;
+    GSR_HIP(launch_blend_backward(s, a));
+  }
+  PreBwdArgs pa;
+  pa.P = P; pa.D = D; pa.M = shs ? M : 0;
+  pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.scales = scales; pa.rotations = rotations;
+  pa.scale_modifier = scale_modifier;
+  pa.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
+  pa.clamped = g.clamped;
+  pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
+  pa.h_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:308-309
+  pa.h_x = W / (2.0f * tan_fovx);
+  pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
+  pa.dL_dmean2D = dL_dmeans2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolors;
+  pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dcov3D = dL_dcov3D;
+  pa.dL_dsh = shs ? dL_dsh : nullptr;
+  pa.dL_dscale = scales ? dL_dscales : nullptr;
+  pa.dL_drot = scales ? dL_drots : nullptr;
+  GSR_HIP(launch_preprocess_backward(s, pa));
+  return GSR_OK;
+}
+
+int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present) {
+  (void)projmatrix;  // computed but unused by the reference as well (auxiliary.h:149-154)
+  if (P == 0) return GSR_OK;
+  if (P < 0 || !means3D || !viewmatrix || !present) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_mark_visible((hipStream_t)stream, P, means3D, viewmatrix, present));
+  return GSR_OK;
+}
+
+int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const void* geom, const void* binning,
+                      const void* image, const float* image_weights, float* weights, int32_t* cnt) {
+  if (C < 1 || C > 3) return GSR_ERR_BAD_CHANNELS;
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !image || !image_weights || !weights || !cnt) return GSR_ERR_BAD_ARGUMENT;
+  if (R == 0) return GSR_OK;
+  if (!geom || !binning) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Image im = carve_image(const_cast<void*>(image), W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, nullptr);
+  a.C = C;
+  a.image_weights = image_weights;
+  a.weights = weights;
+  a.cnt = cnt;
+  GSR_HIP(launch_trace_weights((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
+int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
+                          float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
+  if (P <= 0) return GSR_OK;
+  if (!geom) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  GSR_HIP(launch_export_geom((hipStream_t)stream, P, g, means2D, depths, rgb, conic_opacity, clamped));
+  hipStream_t s = (hipStream_t)stream;
+  if (cov3D) GSR_HIP(hipMemcpyAsync(cov3D, g.cov3D, sizeof(float) * 6 * (size_t)P, hipMemcpyDeviceToDevice, s));
+  if (tiles_touched)
+    GSR_HIP(hipMemcpyAsync(tiles_touched, g.tiles, sizeof(uint32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
+  return GSR_OK;
+}
+
+int gsr_debug_export_binning(void* stream, int64_t R, int W, int H, const void* binning, uint64_t* keys,
+                             uint32_t* point_list) {
+  if (R <= 0) return GSR_OK;
+  if (!binning) return GSR_ERR_BAD_ARGUMENT;
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  hipStream_t s = (hipStream_t)stream;
+  if (keys) GSR_HIP(hipMemcpyAsync(keys, b.keys[b.final_buf], sizeof(uint64_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+  if (point_list)
+    GSR_HIP(hipMemcpyAsync(point_list, b.vals[b.final_buf], sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+  return GSR_OK;
+}
+
+int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32_t* ranges, float* final_T,
+                           uint32_t* n_contrib) {
+  if (!image || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
+  const Image im = carve_image(const_cast<void*>(image), W, H);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE), N = (size_t)W * H;
+  if (ranges) GSR_HIP(hipMemcpyAsync(ranges, im.ranges, sizeof(uint2) * T, hipMemcpyDeviceToDevice, s));
+  if (final_T) GSR_HIP(hipMemcpyAsync(final_T, im.final_T, sizeof(float) * N, hipMemcpyDeviceToDevice, s));
+  if (n_contrib) GSR_HIP(hipMemcpyAsync(n_contrib, im.n_contrib, sizeof(uint32_t) * N, hipMemcpyDeviceToDevice, s));
+  return GSR_OK;
+}
+
+}  // extern "C"

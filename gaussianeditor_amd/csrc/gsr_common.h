@@ -1,0 +1,216 @@
+// gsr_common.h -- shared definitions for the gfx950 Gaussian-splatting rasterizer kernels.
+//
+// Target: AMD Instinct MI355X (CDNA4, gfx950) only.  wave = 64 lanes; one
+// rasterizer "pixel wave" covers an 8x8 pixel quadrant of a 16x16 tile.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/gsr.h"
+
+namespace gsr {
+
+constexpr int TILE = 16;        // tile edge in pixels (reference: BLOCK_X/BLOCK_Y, config.h:16-17)
+constexpr int QUAD = 8;         // one wave = 8x8 pixels
+constexpr int WAVE = 64;
+constexpr int GAUSS_BLOCK = 256;  // Gaussians per block in the per-Gaussian kernels
+
+// ----------------------------------------------------------------------------------
+// Opaque scratch layouts.  Every section is 256-byte aligned.
+// ----------------------------------------------------------------------------------
+__host__ __device__ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Per-Gaussian state ("geomBuffer").  The three float4 records are what the blend
+// kernels gather per instance (48 B, 16-byte aligned vector loads):
+//   rec0 = conic.x, conic.y, conic.z, opacity     (reference: conic_opacity, forward.cu:254)
+//   rec1 = mean2D.x, mean2D.y, depth, radius(float) (reference: points_xy_image, depths, radii)
+//   rec2 = r, g, b, 0                              (reference: rgb, or a copy of colors_precomp)
+struct Geom {
+  float4* rec0;
+  float4* rec1;
+  float4* rec2;
+  float* cov3D;          // (P,6)   computed or copied from cov3D_precomp
+  uint32_t* tiles;       // (P)     tiles_touched
+  uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
+  uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block
+  uint32_t* block_offs;  // (nb)    exclusive prefix of block_sums
+  uint64_t* total;       // (1)     num_rendered
+  size_t bytes;
+};
+
+__host__ __device__ inline Geom carve_geom(void* base, int P) {
+  char* p = (char*)base;
+  const size_t nb = ((size_t)P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  Geom g;
+  size_t off = 0;
+  g.total = (uint64_t*)(p + off);      off += 256;
+  g.rec0 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
+  g.rec1 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
+  g.rec2 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
+  g.cov3D = (float*)(p + off);         off += align_up(sizeof(float) * 6 * (size_t)P);
+  g.tiles = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * (size_t)P);
+  g.clamped = (uint8_t*)(p + off);     off += align_up((size_t)P);
+  g.block_sums = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
+  g.block_offs = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
+  g.bytes = off;
+  return g;
+}
+
+// Per-pixel / per-tile state ("imgBuffer").
+struct Image {
+  uint2* ranges;        // (T)  [begin,end) into point_list
+  float* final_T;       // (N)
+  uint32_t* n_contrib;  // (N)
+  size_t bytes;
+};
+__host__ __device__ inline Image carve_image(void* base, int W, int H) {
+  char* p = (char*)base;
+  const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  const size_t N = (size_t)W * H;
+  Image im;
+  size_t off = 0;
+  im.ranges = (uint2*)(p + off);        off += align_up(sizeof(uint2) * T);
+  im.final_T = (float*)(p + off);       off += align_up(sizeof(float) * N);
+  im.n_contrib = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * N);
+  im.bytes = off;
+  return im;
+}
+
+// Radix sort geometry.
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ITEMS = 16;                          // keys per thread
+constexpr int SORT_KPB = SORT_THREADS * SORT_ITEMS;     // keys per block (4096)
+constexpr int SORT_RADIX_BITS = 8;
+constexpr int SORT_BINS = 1 << SORT_RADIX_BITS;
+
+// Per-instance state ("binningBuffer"): ping-pong key/value arrays + histograms.
+struct Binning {
+  uint64_t* keys[2];
+  uint32_t* vals[2];
+  uint32_t* hist;       // (SORT_BINS * nblocks)
+  uint32_t* bin_total;  // (SORT_BINS)
+  uint32_t nblocks;
+  int passes;           // ceil(key_bits / 8)
+  int final_buf;        // which ping-pong side holds the sorted result (= passes & 1)
+  size_t bytes;
+};
+__host__ __device__ inline uint32_t higher_msb(uint32_t n) {  // rasterizer_impl.cu:36-49
+  uint32_t msb = sizeof(n) * 4, step = msb;
+  while (step > 1) {
+    step /= 2;
+    if (n >> msb) msb += step; else msb -= step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+__host__ __device__ inline int sort_key_bits(int W, int H) {
+  const uint32_t T = (uint32_t)((W + TILE - 1) / TILE) * (uint32_t)((H + TILE - 1) / TILE);
+  return 32 + (int)higher_msb(T);
+}
+__host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, int H) {
+  char* p = (char*)base;
+  Binning b;
+  b.nblocks = (uint32_t)((R + SORT_KPB - 1) / SORT_KPB);
+  b.passes = (sort_key_bits(W, H) + SORT_RADIX_BITS - 1) / SORT_RADIX_BITS;
+  b.final_buf = b.passes & 1;
+  size_t off = 0;
+  for (int i = 0; i < 2; ++i) { b.keys[i] = (uint64_t*)(p + off); off += align_up(sizeof(uint64_t) * (size_t)R); }
+  for (int i = 0; i < 2; ++i) { b.vals[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)R); }
+  b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_BINS * (size_t)b.nblocks);
+  b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_BINS);
+  b.bytes = R > 0 ? off : 0;
+  return b;
+}
+
+#if defined(__HIPCC__)
+// ----------------------------------------------------------------------------------
+// Device maths.  This translation unit set is compiled with -ffp-contract=off:
+// every float op below is one IEEE binary32 operation unless fmaf is spelled out.
+// ----------------------------------------------------------------------------------
+
+// The exactly specified exponential (see oracle/gsr_oracle.cpp and DESIGN.md section 4):
+// exp(x) = 2^n p(f), t = max(x log2 e, -125), n = rint(t), f = t - n, p = degree-6
+// Horner polynomial in fmaf.  9 full-rate VALU ops + v_rndne + v_cvt + v_ldexp; no
+// transcendental unit, bit-reproducible on any IEEE machine.
+__device__ __forceinline__ float gsr_expf(float x) {
+  float t = x * 0x1.715476p+0f;
+  t = fmaxf(t, -125.0f);
+  const float n = __builtin_rintf(t);
+  const float f = t - n;
+  float p = 0x1.44138ap-13f;
+  p = __builtin_fmaf(p, f, 0x1.5f0890p-10f);
+  p = __builtin_fmaf(p, f, 0x1.3b2a54p-7f);
+  p = __builtin_fmaf(p, f, 0x1.c6af6cp-5f);
+  p = __builtin_fmaf(p, f, 0x1.ebfbe0p-3f);
+  p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+  p = __builtin_fmaf(p, f, 1.0f);
+  return __builtin_amdgcn_ldexpf(p, (int)n);
+}
+
+// Gaussian footprint exponent, forward.cu:335-338 with the fma placement of the spec.
+__device__ __forceinline__ float blend_power(float cx, float cy, float cz, float dx, float dy) {
+  const float a = (cx * dx) * dx;
+  const float s = __builtin_fmaf(cz * dy, dy, a);
+  const float h = -0.5f * s;
+  return __builtin_fmaf(-(cy * dx), dy, h);
+}
+
+// float -> int with v_cvt_i32_f32 semantics (saturating, NaN -> 0).
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+
+// --- wave64 primitives -------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v) {
+  // v + (v moved by DPP control CTRL); lanes without a source add 0.
+  const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false);
+  return v + __builtin_bit_cast(float, moved);
+}
+// Sum over the 64 lanes of a wave; the total is valid in lane 63 only.
+// 6 v_add_f32_dpp: row_shr 1,2,4,8 then row_bcast15 (rows 1,3) and row_bcast31 (rows 2,3).
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v = dpp_add<0x111>(v);
+  v = dpp_add<0x112>(v);
+  v = dpp_add<0x114>(v);
+  v = dpp_add<0x118>(v);
+  v = dpp_add<0x142, 0xa>(v);
+  v = dpp_add<0x143, 0xc>(v);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d, 64);
+    if (l >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread across a block of NT threads (NT multiple of 64, <= 1024).
+// Returns the exclusive prefix; *block_total receives the block sum (valid in all threads).
+template <int NT>
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* block_total, uint32_t* smem /* NT/64 + 1 */) {
+  constexpr int NW = NT / 64;
+  const int w = (int)(threadIdx.x >> 6), l = lane_id();
+  const uint32_t incl = wave_incl_scan_u32(v);
+  __syncthreads();  // protect smem reuse across calls
+  if (l == 63) smem[w] = incl;
+  __syncthreads();
+  if (w == 0) {
+    uint32_t t = (l < NW) ? smem[l] : 0u;
+    const uint32_t ti = wave_incl_scan_u32(t);
+    if (l < NW) smem[l] = ti - t;
+    if (l == NW - 1) smem[NW] = ti;
+  }
+  __syncthreads();
+  *block_total = smem[NW];
+  return smem[w] + incl - v;
+}
+#endif  // __HIPCC__
+
+}  // namespace gsr

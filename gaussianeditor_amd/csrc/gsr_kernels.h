@@ -1,0 +1,92 @@
+// gsr_kernels.h -- kernel argument blocks and host-side launchers shared by the translation units.
+#pragma once
+#include "gsr_common.h"
+
+namespace gsr {
+
+// K1 arguments (preprocess_kernel, gsr_preprocess.hip)
+struct PreArgs {
+  int P, D, M;
+  const float* means3D;
+  const float* scales;
+  float scale_modifier;
+  const float* rotations;
+  const float* opacities;
+  const float* shs;
+  const float* cov3D_precomp;
+  const float* colors_precomp;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  int W, H;
+  float tan_fovx, tan_fovy, focal_x, focal_y;
+  int gx, gy;
+  int skip_color;
+  int32_t* radii;
+  Geom g;
+};
+
+// K8+K9 arguments (preprocess_backward_kernel, gsr_preprocess.hip)
+struct PreBwdArgs {
+  int P, D, M;
+  const float* means3D;
+  const int32_t* radii;
+  const float* shs;
+  const float* scales;
+  const float* rotations;
+  float scale_modifier;
+  const float* cov3D;  // computed (geom) or precomputed
+  const uint8_t* clamped;
+  const float* viewmatrix;
+  const float* projmatrix;
+  const float* campos;
+  float h_x, h_y, tan_fovx, tan_fovy;
+  const float* dL_dmean2D;  // (P,3)
+  const float* dL_dconic;   // (P,4)
+  const float* dL_dcolor;   // (P,3)
+  float* dL_dmeans3D;       // (P,3)
+  float* dL_dcov3D;         // (P,6)
+  float* dL_dsh;            // (P,M,3) | null
+  float* dL_dscale;         // (P,3)   | null
+  float* dL_drot;           // (P,4)   | null
+};
+
+// K6 / K7 / K12 arguments (gsr_blend.hip)
+struct BlendArgs {
+  int W, H, gx, gy, SX, NS;
+  const uint2* ranges;
+  const uint32_t* point_list;
+  const float4* rec0;
+  const float4* rec1;
+  const float4* rec2;
+  const float* bg;
+  float* final_T;
+  uint32_t* n_contrib;
+  // forward outputs
+  float* out_color;
+  float* out_depth;
+  // backward
+  const float* dL_dpix;
+  float* dL_dmean2D;
+  float* dL_dconic;
+  float* dL_dopacity;
+  float* dL_dcolors;
+  // tracing
+  int C;
+  const float* image_weights;
+  float* weights;
+  int32_t* cnt;
+};
+
+hipError_t launch_preprocess(hipStream_t s, const PreArgs& a);
+hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
+hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a);
+hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
+                              float* conic_opacity, uint8_t* clamped);
+hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
+                          const Binning& b, const Image& im);
+hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
+hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);
+hipError_t launch_trace_weights(hipStream_t s, BlendArgs a);
+
+}  // namespace gsr

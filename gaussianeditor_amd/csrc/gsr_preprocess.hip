@@ -1,0 +1,598 @@
+// gsr_preprocess.hip -- per-Gaussian kernels: K1 (forward preprocess), K2 (scan of the
+// per-block tile counts), K8+K9 fused (backward preprocess), K10 (frustum mark).
+//
+// All of them are HBM-streaming kernels: one thread per Gaussian, 256 Gaussians per
+// block, every input byte read once and every output byte written once.  Arithmetic
+// follows the reference's statement order with no FMA contraction so that the
+// integer outputs (radii, tiles_touched) are bit-identical to the CPU oracle.
+#include "gsr_kernels.h"
+
+namespace gsr {
+
+// glm::mat3 semantics (column-major m[col][row]; product evaluated left to right),
+// DGR/third_party/glm/glm/detail/type_mat3x3.inl:486-519.
+struct M3 {
+  float m[3][3];
+};
+__device__ __forceinline__ M3 mk(float a, float b, float c, float d, float e, float f, float g, float h, float i) {
+  M3 r;
+  r.m[0][0] = a; r.m[0][1] = b; r.m[0][2] = c;
+  r.m[1][0] = d; r.m[1][1] = e; r.m[1][2] = f;
+  r.m[2][0] = g; r.m[2][1] = h; r.m[2][2] = i;
+  return r;
+}
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) R.m[c][r] = A.m[0][r] * B.m[c][0] + A.m[1][r] * B.m[c][1] + A.m[2][r] * B.m[c][2];
+  return R;
+}
+__device__ __forceinline__ M3 tr(const M3& A) {
+  M3 R;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) R.m[c][r] = A.m[r][c];
+  return R;
+}
+
+__device__ __forceinline__ int f2i_sat(float v) {
+  if (!(v == v)) return 0;
+  if (v >= 2147483648.0f) return 2147483647;
+  if (v <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)v;
+}
+
+struct Cam {
+  float view[16];
+  float proj[16];
+  float campos[3];
+};
+
+__device__ __forceinline__ void load_cam(Cam& c, const float* view, const float* proj, const float* campos) {
+  // 35 uniform floats: the compiler turns these into scalar (s_load) loads.
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.view[i] = view[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) c.proj[i] = proj[i];
+  if (campos) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.campos[i] = campos[i];
+  }
+}
+
+__device__ __forceinline__ void get_rect(float px, float py, int max_radius, int gx, int gy, uint32_t& minx,
+                                         uint32_t& miny, uint32_t& maxx, uint32_t& maxy) {
+  // DGR/cuda_rasterizer/auxiliary.h:46-56
+  const float r = (float)max_radius;
+  minx = (uint32_t)min(gx, max(0, f2i_sat((px - r) / (float)TILE)));
+  miny = (uint32_t)min(gy, max(0, f2i_sat((py - r) / (float)TILE)));
+  maxx = (uint32_t)min(gx, max(0, f2i_sat((px + r + (float)TILE - 1.0f) / (float)TILE)));
+  maxy = (uint32_t)min(gy, max(0, f2i_sat((py + r + (float)TILE - 1.0f) / (float)TILE)));
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                       -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float SH_C3[7] = {-0.5900435899266435f, 2.890611442640554f,  -0.4570457994644658f,
+                                       0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                       -0.5900435899266435f};
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Loads the SH coefficients of one Gaussian into registers.  M == 16 (the standard
+// 3DGS ply) is a 192-byte, 16-byte-aligned record: 12 dwordx4 loads.
+template <int MAXC>
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int ncoef, V3 (&sh)[MAXC]) {
+  const float* p = shs + idx * (size_t)M * 3;
+  if (M == 16 && MAXC == 16) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    float f[48];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      // coefficients beyond the active degree are never read (uniform branch)
+      if (i * 4 < ncoef * 3) {
+        const float4 v = q[i];
+        f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+      } else {
+        f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sh[k] = {f[3 * k], f[3 * k + 1], f[3 * k + 2]};
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+      if (k < ncoef)
+        sh[k] = {p[3 * k], p[3 * k + 1], p[3 * k + 2]};
+      else
+        sh[k] = {0.f, 0.f, 0.f};
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// K1: preprocessCUDA, DGR/cuda_rasterizer/forward.cu:155-256 (+ apply_weights.cu:148-234).
+// Additionally produces the per-block sum of tiles_touched (first level of K2).
+// ----------------------------------------------------------------------------------
+
+__global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a) {
+  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  uint32_t my_tiles = 0;
+  if (idx < a.P) {
+    Cam cam;
+    load_cam(cam, a.viewmatrix, a.projmatrix, a.skip_color || a.colors_precomp ? nullptr : a.campos);
+    const float* view = cam.view;
+    const float* proj = cam.proj;
+    int my_radius_i = 0;
+    do {
+      const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      // in_frustum, auxiliary.h:139-164: only the near test survives
+      const V3 p_view = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
+                         view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
+                         view[2] * p.x + view[6] * p.y + view[10] * p.z + view[14]};
+      if (p_view.z <= 0.2f) break;
+      const float hx = proj[0] * p.x + proj[4] * p.y + proj[8] * p.z + proj[12];
+      const float hy = proj[1] * p.x + proj[5] * p.y + proj[9] * p.z + proj[13];
+      const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
+      const float p_w = 1.0f / (hw + 0.0000001f);
+      const float projx = hx * p_w, projy = hy * p_w;
+
+      // cov3D: forward.cu:118-152, or the precomputed one
+      float c3[6];
+      if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+      } else {
+        M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
+        S.m[0][0] = a.scale_modifier * a.scales[3 * idx + 0];
+        S.m[1][1] = a.scale_modifier * a.scales[3 * idx + 1];
+        S.m[2][2] = a.scale_modifier * a.scales[3 * idx + 2];
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float r = q.x, x = q.y, y = q.z, z = q.w;
+        const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+        const M3 Mm = mul(S, R);
+        const M3 Sigma = mul(tr(Mm), Mm);
+        c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+        c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) a.g.cov3D[6 * (size_t)idx + i] = c3[i];
+
+      // cov2D: forward.cu:74-113
+      V3 t = p_view;
+      const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+      const float txtz = t.x / t.z, tytz = t.y / t.z;
+      t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+      t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+      const M3 J = mk(a.focal_x / t.z, 0.0f, -(a.focal_x * t.x) / (t.z * t.z), 0.0f, a.focal_y / t.z,
+                      -(a.focal_y * t.y) / (t.z * t.z), 0, 0, 0);
+      const M3 Wm = mk(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+      const M3 T = mul(Wm, J);
+      const M3 Vrk = mk(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+      M3 cov = mul(mul(tr(T), tr(Vrk)), T);
+      const float cx = cov.m[0][0] + 0.3f, cy = cov.m[0][1], cz = cov.m[1][1] + 0.3f;
+
+      // forward.cu:219-237
+      const float det = (cx * cz - cy * cy);
+      if (det == 0.0f) break;
+      const float det_inv = 1.f / det;
+      const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+      const float mid = 0.5f * (cx + cz);
+      const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+      const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      // ndc2Pix in double, auxiliary.h:41-44
+      const float pix = (float)((((double)projx + 1.0) * (double)a.W - 1.0) * 0.5);
+      const float piy = (float)((((double)projy + 1.0) * (double)a.H - 1.0) * 0.5);
+      uint32_t minx, miny, maxx, maxy;
+      const int radius_i = f2i_sat(my_radius);
+      get_rect(pix, piy, radius_i, a.gx, a.gy, minx, miny, maxx, maxy);
+      const uint32_t area = (maxx - minx) * (maxy - miny);
+      if (area == 0) break;
+
+      // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
+      float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!a.skip_color) {
+        if (a.colors_precomp != nullptr) {
+          col.x = a.colors_precomp[3 * (size_t)idx];
+          col.y = a.colors_precomp[3 * (size_t)idx + 1];
+          col.z = a.colors_precomp[3 * (size_t)idx + 2];
+        } else {
+          V3 dir = {p.x - cam.campos[0], p.y - cam.campos[1], p.z - cam.campos[2]};
+          const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+          dir = {dir.x / len, dir.y / len, dir.z / len};
+          V3 sh[16];
+          const int ncoef = (a.D + 1) * (a.D + 1);
+          load_sh<16>(a.shs, (size_t)idx, a.M, ncoef, sh);
+          V3 result = SH_C0 * sh[0];
+          if (a.D > 0) {
+            const float x = dir.x, y = dir.y, z = dir.z;
+            result = result - (SH_C1 * y) * sh[1] + (SH_C1 * z) * sh[2] - (SH_C1 * x) * sh[3];
+            if (a.D > 1) {
+              const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+              result = result + (SH_C2[0] * xy) * sh[4] + (SH_C2[1] * yz) * sh[5] +
+                       (SH_C2[2] * (2.0f * zz - xx - yy)) * sh[6] + (SH_C2[3] * xz) * sh[7] +
+                       (SH_C2[4] * (xx - yy)) * sh[8];
+              if (a.D > 2) {
+                result = result + (SH_C3[0] * y * (3.0f * xx - yy)) * sh[9] + (SH_C3[1] * xy * z) * sh[10] +
+                         (SH_C3[2] * y * (4.0f * zz - xx - yy)) * sh[11] +
+                         (SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[12] +
+                         (SH_C3[4] * x * (4.0f * zz - xx - yy)) * sh[13] + (SH_C3[5] * z * (xx - yy)) * sh[14] +
+                         (SH_C3[6] * x * (xx - 3.0f * yy)) * sh[15];
+              }
+            }
+          }
+          result = {result.x + 0.5f, result.y + 0.5f, result.z + 0.5f};
+          a.g.clamped[idx] = (uint8_t)((result.x < 0 ? 1 : 0) | (result.y < 0 ? 2 : 0) | (result.z < 0 ? 4 : 0));
+          col.x = fmaxf(result.x, 0.0f);
+          col.y = fmaxf(result.y, 0.0f);
+          col.z = fmaxf(result.z, 0.0f);
+        }
+      }
+      // forward.cu:250-255
+      a.g.rec0[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
+      a.g.rec1[idx] = make_float4(pix, piy, p_view.z, my_radius);
+      a.g.rec2[idx] = col;
+      my_radius_i = radius_i;
+      my_tiles = area;
+    } while (false);
+    a.radii[idx] = my_radius_i;
+    a.g.tiles[idx] = my_tiles;
+  }
+  uint32_t total;
+  (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);
+  if (threadIdx.x == 0) a.g.block_sums[blockIdx.x] = total;
+}
+
+// ----------------------------------------------------------------------------------
+// K2 (second level): exclusive scan of the per-block sums by one 1024-thread block;
+// writes num_rendered.  Replaces cub::DeviceScan::InclusiveSum, rasterizer_impl.cu:229-232
+// (the per-Gaussian offsets themselves are rebuilt inside the emit kernel from
+// block_offs + an in-block scan, so no P-sized offsets array ever touches HBM).
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) scan_blocks_kernel(const uint32_t* __restrict__ sums, uint32_t* __restrict__ offs,
+                                                          uint64_t* __restrict__ total, int nb) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  uint64_t carry = 0;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const uint32_t v = i < nb ? sums[i] : 0u;
+    uint32_t chunk_total;
+    const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk_total, smem);
+    if (i < nb) offs[i] = (uint32_t)(carry + ex);
+    carry += chunk_total;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+// ----------------------------------------------------------------------------------
+// K10: checkFrustum, rasterizer_impl.cu:53-63.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GAUSS_BLOCK) mark_visible_kernel(int P, const float* __restrict__ means3D,
+                                                                  const float* __restrict__ view,
+                                                                  uint8_t* __restrict__ present) {
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  if (idx >= P) return;
+  const float x = means3D[3 * idx], y = means3D[3 * idx + 1], z = means3D[3 * idx + 2];
+  const float vz = view[2] * x + view[6] * y + view[10] * z + view[14];
+  present[idx] = vz > 0.2f ? 1 : 0;
+}
+
+// ----------------------------------------------------------------------------------
+// K8 + K9 fused: computeCov2DCUDA (backward.cu:144-274) and the backward preprocessCUDA
+// (backward.cu:346-396) with the SH backward (backward.cu:20-139) and the cov3D backward
+// (backward.cu:278-341).  One thread per Gaussian; dL_dcov3D stays in registers between
+// the two reference kernels.  Every element of every output is written (zeros for
+// Gaussians with radii <= 0), so the caller does not have to zero-fill them.
+// ----------------------------------------------------------------------------------
+
+__device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, const V3* g, int ncoef) {
+  // dst -> (M,3) row of this Gaussian; coefficients >= ncoef are zero.
+  if (M == 16) {
+    float f[48];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const bool on = k < ncoef;
+      f[3 * k] = on ? g[k].x : 0.f;
+      f[3 * k + 1] = on ? g[k].y : 0.f;
+      f[3 * k + 2] = on ? g[k].z : 0.f;
+    }
+    float4* q = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) q[i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+  } else {
+    for (int k = 0; k < M; ++k) {
+      const bool on = k < ncoef && k < 16;
+      V3 v = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk)
+        if (kk == k && on) v = g[kk];
+      dst[3 * k] = v.x; dst[3 * k + 1] = v.y; dst[3 * k + 2] = v.z;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_backward_kernel(const PreBwdArgs a) {
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  if (idx >= a.P) return;
+  const int ncoef = (a.D + 1) * (a.D + 1);
+  V3 dmean = {0.f, 0.f, 0.f};
+  float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  V3 dsh[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
+  V3 dscale = {0.f, 0.f, 0.f};
+  float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  if (a.radii[idx] > 0) {
+    Cam cam;
+    load_cam(cam, a.viewmatrix, a.projmatrix, a.shs ? a.campos : nullptr);
+    const float* view = cam.view;
+    const float* proj = cam.proj;
+    const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float c3[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) c3[i] = a.cov3D[6 * (size_t)idx + i];
+    const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
+    const V3 dL_dcon = {gc.x, gc.y, gc.w};
+
+    // ---- computeCov2DCUDA, backward.cu:159-273 ----
+    V3 t = {view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12],
+            view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13],
+            view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14]};
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    const float x_grad_mul = txtz < -limx || txtz > limx ? 0.f : 1.f;
+    const float y_grad_mul = tytz < -limy || tytz > limy ? 0.f : 1.f;
+    const float h_x = a.h_x, h_y = a.h_y;
+    const M3 J = mk(h_x / t.z, 0.0f, -(h_x * t.x) / (t.z * t.z), 0.0f, h_y / t.z, -(h_y * t.y) / (t.z * t.z), 0, 0, 0);
+    const M3 Wm = mk(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    const M3 Vrk = mk(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+    const M3 T = mul(Wm, J);
+    const M3 cov2D = mul(mul(tr(T), tr(Vrk)), T);
+    const float ca = cov2D.m[0][0] + 0.3f, cb = cov2D.m[0][1], cc = cov2D.m[1][1] + 0.3f;
+    const float denom = ca * cc - cb * cb;
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    const auto& Tm = T.m;
+    if (denom2inv != 0) {
+      dL_da = denom2inv * (-cc * cc * dL_dcon.x + 2 * cb * cc * dL_dcon.y + (denom - ca * cc) * dL_dcon.z);
+      dL_dc = denom2inv * (-ca * ca * dL_dcon.z + 2 * ca * cb * dL_dcon.y + (denom - ca * cc) * dL_dcon.x);
+      dL_db = denom2inv * 2 * (cb * cc * dL_dcon.x - (denom + 2 * cb * cb) * dL_dcon.y + ca * cb * dL_dcon.z);
+      dcov[0] = (Tm[0][0] * Tm[0][0] * dL_da + Tm[0][0] * Tm[1][0] * dL_db + Tm[1][0] * Tm[1][0] * dL_dc);
+      dcov[3] = (Tm[0][1] * Tm[0][1] * dL_da + Tm[0][1] * Tm[1][1] * dL_db + Tm[1][1] * Tm[1][1] * dL_dc);
+      dcov[5] = (Tm[0][2] * Tm[0][2] * dL_da + Tm[0][2] * Tm[1][2] * dL_db + Tm[1][2] * Tm[1][2] * dL_dc);
+      dcov[1] = 2 * Tm[0][0] * Tm[0][1] * dL_da + (Tm[0][0] * Tm[1][1] + Tm[0][1] * Tm[1][0]) * dL_db +
+                2 * Tm[1][0] * Tm[1][1] * dL_dc;
+      dcov[2] = 2 * Tm[0][0] * Tm[0][2] * dL_da + (Tm[0][0] * Tm[1][2] + Tm[0][2] * Tm[1][0]) * dL_db +
+                2 * Tm[1][0] * Tm[1][2] * dL_dc;
+      dcov[4] = 2 * Tm[0][2] * Tm[0][1] * dL_da + (Tm[0][1] * Tm[1][2] + Tm[0][2] * Tm[1][1]) * dL_db +
+                2 * Tm[1][1] * Tm[1][2] * dL_dc;
+    }
+    const auto& V = Vrk.m;
+    const float dL_dT00 = 2 * (Tm[0][0] * V[0][0] + Tm[0][1] * V[0][1] + Tm[0][2] * V[0][2]) * dL_da +
+                          (Tm[1][0] * V[0][0] + Tm[1][1] * V[0][1] + Tm[1][2] * V[0][2]) * dL_db;
+    const float dL_dT01 = 2 * (Tm[0][0] * V[1][0] + Tm[0][1] * V[1][1] + Tm[0][2] * V[1][2]) * dL_da +
+                          (Tm[1][0] * V[1][0] + Tm[1][1] * V[1][1] + Tm[1][2] * V[1][2]) * dL_db;
+    const float dL_dT02 = 2 * (Tm[0][0] * V[2][0] + Tm[0][1] * V[2][1] + Tm[0][2] * V[2][2]) * dL_da +
+                          (Tm[1][0] * V[2][0] + Tm[1][1] * V[2][1] + Tm[1][2] * V[2][2]) * dL_db;
+    const float dL_dT10 = 2 * (Tm[1][0] * V[0][0] + Tm[1][1] * V[0][1] + Tm[1][2] * V[0][2]) * dL_dc +
+                          (Tm[0][0] * V[0][0] + Tm[0][1] * V[0][1] + Tm[0][2] * V[0][2]) * dL_db;
+    const float dL_dT11 = 2 * (Tm[1][0] * V[1][0] + Tm[1][1] * V[1][1] + Tm[1][2] * V[1][2]) * dL_dc +
+                          (Tm[0][0] * V[1][0] + Tm[0][1] * V[1][1] + Tm[0][2] * V[1][2]) * dL_db;
+    const float dL_dT12 = 2 * (Tm[1][0] * V[2][0] + Tm[1][1] * V[2][1] + Tm[1][2] * V[2][2]) * dL_dc +
+                          (Tm[0][0] * V[2][0] + Tm[0][1] * V[2][1] + Tm[0][2] * V[2][2]) * dL_db;
+    const auto& Wx = Wm.m;
+    const float dL_dJ00 = Wx[0][0] * dL_dT00 + Wx[0][1] * dL_dT01 + Wx[0][2] * dL_dT02;
+    const float dL_dJ02 = Wx[2][0] * dL_dT00 + Wx[2][1] * dL_dT01 + Wx[2][2] * dL_dT02;
+    const float dL_dJ11 = Wx[1][0] * dL_dT10 + Wx[1][1] * dL_dT11 + Wx[1][2] * dL_dT12;
+    const float dL_dJ12 = Wx[2][0] * dL_dT10 + Wx[2][1] * dL_dT11 + Wx[2][2] * dL_dT12;
+    const float tz = 1.f / t.z, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+    const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+    const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * t.x) * tz3 * dL_dJ02 +
+                         (2 * h_y * t.y) * tz3 * dL_dJ12;
+    // transformVec4x3Transpose, auxiliary.h:89-97 (assignment, backward.cu:273)
+    dmean = {view[0] * dL_dtx + view[1] * dL_dty + view[2] * dL_dtz,
+             view[4] * dL_dtx + view[5] * dL_dty + view[6] * dL_dtz,
+             view[8] * dL_dtx + view[9] * dL_dty + view[10] * dL_dtz};
+
+    // ---- preprocessCUDA (backward), backward.cu:370-395 ----
+    const V3 m = mean;
+    const float m_hw = proj[3] * m.x + proj[7] * m.y + proj[11] * m.z + proj[15];
+    const float m_w = 1.0f / (m_hw + 0.0000001f);
+    const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
+    const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+    V3 dL_dmean;
+    dL_dmean.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+    dL_dmean.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+    dL_dmean.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+    dmean = dmean + dL_dmean;
+
+    if (a.shs != nullptr) {
+      // computeColorFromSH (backward), backward.cu:20-139
+      const V3 dir_orig = {m.x - cam.campos[0], m.y - cam.campos[1], m.z - cam.campos[2]};
+      const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+      const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
+      V3 sh[16];
+      load_sh<16>(a.shs, (size_t)idx, a.M, ncoef, sh);
+      const uint8_t cl = a.clamped[idx];
+      V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
+      dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
+      dL_dRGB.y *= (cl & 2) ? 0.f : 1.f;
+      dL_dRGB.z *= (cl & 4) ? 0.f : 1.f;
+      V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
+      const float x = dir.x, y = dir.y, z = dir.z;
+      dsh[0] = SH_C0 * dL_dRGB;
+      if (a.D > 0) {
+        dsh[1] = (-SH_C1 * y) * dL_dRGB;
+        dsh[2] = (SH_C1 * z) * dL_dRGB;
+        dsh[3] = (-SH_C1 * x) * dL_dRGB;
+        dRGBdx = (-SH_C1) * sh[3];
+        dRGBdy = (-SH_C1) * sh[1];
+        dRGBdz = SH_C1 * sh[2];
+        if (a.D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          dsh[4] = (SH_C2[0] * xy) * dL_dRGB;
+          dsh[5] = (SH_C2[1] * yz) * dL_dRGB;
+          dsh[6] = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB;
+          dsh[7] = (SH_C2[3] * xz) * dL_dRGB;
+          dsh[8] = (SH_C2[4] * (xx - yy)) * dL_dRGB;
+          dRGBdx = dRGBdx + ((SH_C2[0] * y) * sh[4] + (SH_C2[2] * 2.f * -x) * sh[6] + (SH_C2[3] * z) * sh[7] +
+                             (SH_C2[4] * 2.f * x) * sh[8]);
+          dRGBdy = dRGBdy + ((SH_C2[0] * x) * sh[4] + (SH_C2[1] * z) * sh[5] + (SH_C2[2] * 2.f * -y) * sh[6] +
+                             (SH_C2[4] * 2.f * -y) * sh[8]);
+          dRGBdz = dRGBdz + ((SH_C2[1] * y) * sh[5] + (SH_C2[2] * 2.f * 2.f * z) * sh[6] + (SH_C2[3] * x) * sh[7]);
+          if (a.D > 2) {
+            dsh[9] = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB;
+            dsh[10] = (SH_C3[1] * xy * z) * dL_dRGB;
+            dsh[11] = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
+            dsh[12] = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
+            dsh[13] = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
+            dsh[14] = (SH_C3[5] * z * (xx - yy)) * dL_dRGB;
+            dsh[15] = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
+            // `SH_C3[k] * sh[n] * s1 * s2` parses as (((SH_C3[k]*sh[n])*s1)*s2)
+            dRGBdx = dRGBdx + ((SH_C3[0] * sh[9]) * 3.f * 2.f * xy + (SH_C3[1] * sh[10]) * yz +
+                               (SH_C3[2] * sh[11]) * -2.f * xy + (SH_C3[3] * sh[12]) * -3.f * 2.f * xz +
+                               (SH_C3[4] * sh[13]) * (-3.f * xx + 4.f * zz - yy) + (SH_C3[5] * sh[14]) * 2.f * xz +
+                               (SH_C3[6] * sh[15]) * 3.f * (xx - yy));
+            dRGBdy = dRGBdy + ((SH_C3[0] * sh[9]) * 3.f * (xx - yy) + (SH_C3[1] * sh[10]) * xz +
+                               (SH_C3[2] * sh[11]) * (-3.f * yy + 4.f * zz - xx) +
+                               (SH_C3[3] * sh[12]) * -3.f * 2.f * yz + (SH_C3[4] * sh[13]) * -2.f * xy +
+                               (SH_C3[5] * sh[14]) * -2.f * yz + (SH_C3[6] * sh[15]) * -3.f * 2.f * xy);
+            dRGBdz = dRGBdz + ((SH_C3[1] * sh[10]) * xy + (SH_C3[2] * sh[11]) * 4.f * 2.f * yz +
+                               (SH_C3[3] * sh[12]) * 3.f * (2.f * zz - xx - yy) +
+                               (SH_C3[4] * sh[13]) * 4.f * 2.f * xz + (SH_C3[5] * sh[14]) * (xx - yy));
+          }
+        }
+      }
+      const V3 dL_ddir = {dot3(dRGBdx, dL_dRGB), dot3(dRGBdy, dL_dRGB), dot3(dRGBdz, dL_dRGB)};
+      // dnormvdv, auxiliary.h:107-117
+      const V3 v = dir_orig, dv = dL_ddir;
+      const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      V3 dm;
+      dm.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+      dm.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+      dm.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+      dmean = dmean + dm;
+    }
+
+    if (a.scales != nullptr) {
+      // computeCov3D (backward), backward.cu:278-341
+      const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+      const float r = q.x, x = q.y, y = q.z, z = q.w;
+      const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                      2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                      2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+      M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
+      const V3 s = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
+                    a.scale_modifier * a.scales[3 * idx + 2]};
+      S.m[0][0] = s.x; S.m[1][1] = s.y; S.m[2][2] = s.z;
+      const M3 Mm = mul(S, R);
+      const M3 dL_dSigma = mk(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
+                              0.5f * dcov[2], 0.5f * dcov[4], dcov[5]);
+      M3 M2;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) M2.m[c][rr] = Mm.m[c][rr] * 2.0f;
+      const M3 dL_dM = mul(M2, dL_dSigma);
+      const M3 Rt = tr(R);
+      M3 Q = tr(dL_dM);  // dL_dMt
+      dscale.x = Rt.m[0][0] * Q.m[0][0] + Rt.m[0][1] * Q.m[0][1] + Rt.m[0][2] * Q.m[0][2];
+      dscale.y = Rt.m[1][0] * Q.m[1][0] + Rt.m[1][1] * Q.m[1][1] + Rt.m[1][2] * Q.m[1][2];
+      dscale.z = Rt.m[2][0] * Q.m[2][0] + Rt.m[2][1] * Q.m[2][1] + Rt.m[2][2] * Q.m[2][2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        Q.m[0][k] *= s.x;
+        Q.m[1][k] *= s.y;
+        Q.m[2][k] *= s.z;
+      }
+      const auto& D_ = Q.m;
+      drot.x = 2 * z * (D_[0][1] - D_[1][0]) + 2 * y * (D_[2][0] - D_[0][2]) + 2 * x * (D_[1][2] - D_[2][1]);
+      drot.y = 2 * y * (D_[1][0] + D_[0][1]) + 2 * z * (D_[2][0] + D_[0][2]) + 2 * r * (D_[1][2] - D_[2][1]) -
+               4 * x * (D_[2][2] + D_[1][1]);
+      drot.z = 2 * x * (D_[1][0] + D_[0][1]) + 2 * r * (D_[2][0] - D_[0][2]) + 2 * z * (D_[1][2] + D_[2][1]) -
+               4 * y * (D_[2][2] + D_[0][0]);
+      drot.w = 2 * r * (D_[0][1] - D_[1][0]) + 2 * x * (D_[2][0] + D_[0][2]) + 2 * y * (D_[1][2] + D_[2][1]) -
+               4 * z * (D_[1][1] + D_[0][0]);
+    }
+  }
+
+  a.dL_dmeans3D[3 * (size_t)idx] = dmean.x;
+  a.dL_dmeans3D[3 * (size_t)idx + 1] = dmean.y;
+  a.dL_dmeans3D[3 * (size_t)idx + 2] = dmean.z;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+  if (a.dL_dsh != nullptr) store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
+  if (a.dL_dscale != nullptr) {
+    a.dL_dscale[3 * (size_t)idx] = dscale.x;
+    a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
+    a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+  }
+  if (a.dL_drot != nullptr) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+}
+
+// ----------------------------------------------------------------------------------
+// Host-side launchers (called from gsr_capi.hip).
+// ----------------------------------------------------------------------------------
+hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
+  const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, a.g.block_sums, a.g.block_offs, a.g.total, nb);
+  return hipGetLastError();
+}
+// Test-only introspection: unpack the gather records into the reference's separate arrays.
+__global__ void __launch_bounds__(GAUSS_BLOCK) export_geom_kernel(int P, const Geom g, float* means2D, float* depths,
+                                                                 float* rgb, float* conic_opacity, uint8_t* clamped) {
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  if (idx >= P) return;
+  const bool live = g.tiles[idx] != 0;  // records of culled Gaussians are uninitialised
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 r0 = live ? g.rec0[idx] : z, r1 = live ? g.rec1[idx] : z, r2 = live ? g.rec2[idx] : z;
+  if (means2D) { means2D[2 * idx] = r1.x; means2D[2 * idx + 1] = r1.y; }
+  if (depths) depths[idx] = r1.z;
+  if (rgb) { rgb[3 * idx] = r2.x; rgb[3 * idx + 1] = r2.y; rgb[3 * idx + 2] = r2.z; }
+  if (conic_opacity) reinterpret_cast<float4*>(conic_opacity)[idx] = r0;
+  if (clamped) {
+    const uint8_t c = live ? g.clamped[idx] : 0;
+    clamped[3 * idx] = c & 1; clamped[3 * idx + 1] = (c >> 1) & 1; clamped[3 * idx + 2] = (c >> 2) & 1;
+  }
+}
+hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
+                              float* conic_opacity, uint8_t* clamped) {
+  const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(export_geom_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g, means2D, depths, rgb, conic_opacity,
+                     clamped);
+  return hipGetLastError();
+}
+hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present) {
+  const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(mark_visible_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, means3D, view, present);
+  return hipGetLastError();
+}
+hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a) {
+  const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace gsr

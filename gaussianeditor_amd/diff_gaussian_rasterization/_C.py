@@ -1,0 +1,230 @@
+"""`_C`: the four entry points the reference binds with pybind11
+(diff-gaussian-rasterization/ext.cpp:15-20), re-implemented as thin torch glue over the
+C ABI of libgsr_hip.so.  Argument order, return arity and error behaviour follow
+rasterize_points.cu:35-234; torch owns every allocation (the native library never allocates).
+
+There is no CPU path: tensors must live on a ROCm device ("cuda"), and the import
+fails if the HIP library is not built.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Optional, Tuple
+
+import torch
+
+from .. import _native
+
+_native.lib()  # fail loudly at import time if the extension is missing
+
+NUM_CHANNELS = 3  # config.h:15
+
+#: optional allocator for the backward's gradient outputs: fn(name, shape, zero) -> tensor.
+#: Used by gaussianeditor_amd.multiview to make the gradients views of one flat all-reduce bucket.
+_grad_allocator: Optional[Callable[[str, Tuple[int, ...], bool], torch.Tensor]] = None
+
+
+def set_grad_allocator(fn) -> None:
+    global _grad_allocator
+    _grad_allocator = fn
+
+
+def _require_cuda(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"diff_gaussian_rasterization: `{name}` is on {t.device}; this build only runs on a ROCm GPU "
+            "(device 'cuda') through the HIP extension -- there is no CPU fallback.")
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    """contiguous float32, 16-byte aligned (the kernels use dwordx4 loads on (P,4)/(P,16,3) rows)."""
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 for `{name}`, got {t.dtype}")
+    t = t.contiguous()
+    if t.data_ptr() % 16 != 0:
+        t = t.clone(memory_format=torch.contiguous_format)
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """empty tensor <=> NULL <=> feature absent (rasterize_points.cu:80-91 / forward.cu:205,241)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _check_means(means3D: torch.Tensor) -> None:
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:46-48
+
+
+def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations, opacity, sh, cov3D_precomp, colors,
+                        viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, skip_color, radii):
+    L = _native.lib()
+    s = _stream(dev)
+    gbytes, _, ibytes = _native.scratch_sizes(P, 0, W, H)
+    geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+    img = torch.empty(ibytes, dtype=torch.uint8, device=dev)
+    R = ctypes.c_int64(0)
+    _native.check("gsr_preprocess", L.gsr_preprocess(
+        s, P, D, M, _ptr(means3D), _ptr(scales), scale_modifier, _ptr(rotations), _ptr(opacity), _ptr(sh),
+        _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H, tan_fovx, tan_fovy,
+        int(bool(prefiltered)), int(skip_color), radii.data_ptr(), geom.data_ptr(), ctypes.byref(R)))
+    R = int(R.value)
+    _, bbytes, _ = _native.scratch_sizes(P, R, W, H)
+    binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
+    _native.check("gsr_bin", L.gsr_bin(s, P, R, W, H, radii.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr()))
+    return R, geom, binning, img
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    """RasterizeGaussiansCUDA, rasterize_points.cu:35-95 ->
+    (num_rendered, color(3,H,W), depth(1,H,W), radii(P) i32, geomBuffer, binningBuffer, imgBuffer)."""
+    _check_means(means3D)
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    if P == 0:  # rasterize_points.cu:72: everything stays zero / empty
+        return (0, torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev),
+                torch.zeros((1, H, W), dtype=torch.float32, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev),
+                torch.empty(0, **u8), torch.empty(0, **u8), torch.empty(0, **u8))
+    M = int(sh.size(1)) if sh.size(0) != 0 else 0
+    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity")
+    background, viewmatrix, projmatrix, campos = (_f32(background, "bg"), _f32(viewmatrix, "viewmatrix"),
+                                                  _f32(projmatrix, "projmatrix"), _f32(campos, "campos"))
+    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp"), _f32(scales, "scales"),
+                                                    _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
+                                                    _f32(sh, "sh"))
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        R, geom, binning, img = _preprocess_and_bin(dev, P, int(degree), M, means3D, scales, float(scale_modifier),
+                                                    rotations, opacity, sh, cov3D_precomp, colors, viewmatrix,
+                                                    projmatrix, campos, W, H, float(tan_fovx), float(tan_fovy),
+                                                    prefiltered, 0, radii)
+        _native.check("gsr_blend_forward", _native.lib().gsr_blend_forward(
+            _stream(dev), P, R, W, H, background.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr(),
+            out_color.data_ptr(), out_depth.data_ptr()))
+        if debug:
+            torch.cuda.synchronize(dev)  # CHECK_CUDA, auxiliary.h:166-173
+    return R, out_color, out_depth, radii, geom, binning, img
+
+
+def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
+    if _grad_allocator is not None:
+        t = _grad_allocator(name, tuple(shape), zero)
+        if t is not None:
+            return t
+    return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:97-157 ->
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.size(0) != 0 else 0
+    if P == 0:
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)  # noqa: E731
+        return z(0, 3), z(0, NUM_CHANNELS), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
+    _require_cuda(means3D, "means3D")
+    means3D = _f32(means3D, "means3D")
+    background, viewmatrix, projmatrix, campos = (_f32(background, "bg"), _f32(viewmatrix, "viewmatrix"),
+                                                  _f32(projmatrix, "projmatrix"), _f32(campos, "campos"))
+    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp"), _f32(scales, "scales"),
+                                                    _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
+                                                    _f32(sh, "sh"))
+    dL_dpix = _f32(dL_dout_color, "dL_dout_color")
+    radii = radii.contiguous()
+    has_scales = scales.numel() != 0
+    # accumulated with atomics -> zero-filled; the rest is fully written by the kernels
+    dL_dmeans2D = _alloc("means2D", (P, 3), True, dev)
+    dL_dcolors = _alloc("colors_precomp", (P, NUM_CHANNELS), True, dev)
+    dL_dopacity = _alloc("opacities", (P, 1), True, dev)
+    dL_dconic = torch.zeros((P, 4), dtype=torch.float32, device=dev)
+    dL_dmeans3D = _alloc("means3D", (P, 3), False, dev)
+    dL_dcov3D = _alloc("cov3Ds_precomp", (P, 6), False, dev)
+    dL_dsh = _alloc("sh", (P, M, 3), M == 0, dev)
+    dL_dscales = _alloc("scales", (P, 3), not has_scales, dev)
+    dL_drotations = _alloc("rotations", (P, 4), not has_scales, dev)
+    with torch.cuda.device(dev):
+        _native.check("gsr_backward", _native.lib().gsr_backward(
+            _stream(dev), P, int(degree), M, int(R), W, H, background.data_ptr(), means3D.data_ptr(), _ptr(sh),
+            _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+            viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy),
+            radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
+            dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+            dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
+            dL_drotations.data_ptr() if has_scales else None))
+        if debug:
+            torch.cuda.synchronize(dev)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """markVisible, rasterize_points.cu:159-175 -> bool (P)."""
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P != 0:
+        _require_cuda(means3D, "means3D")
+        dev = means3D.device
+        means3D, viewmatrix, projmatrix = _f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
+        with torch.cuda.device(dev):
+            _native.check("gsr_mark_visible", _native.lib().gsr_mark_visible(
+                _stream(dev), P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(), present.data_ptr()))
+    return present
+
+
+def apply_weights(background, means3D, weights, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                  projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                  image_weights, cnt, debug):
+    """applyWeightsGaussiansCUDA, rasterize_points.cu:177-234.  `weights` (P,C) float32 and
+    `cnt` (P[,1]) int32 are updated in place; returns None."""
+    _check_means(means3D)
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    C = int(image_weights.size(0))
+    if C not in (1, 2, 3):
+        # the reference printf()s and exit(-1)s the process (apply_weights.cu:377-380)
+        raise _native.GsrError("gsr_trace_weights", -2, f"Unsupported number of channels: {C}")
+    if P == 0:
+        return None
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    if weights.dtype != torch.float32 or cnt.dtype != torch.int32:
+        raise RuntimeError("apply_weights: weights must be float32 and cnt int32")
+    if weights.numel() != P * C or cnt.numel() != P:
+        raise RuntimeError("apply_weights: weights must hold P*C and cnt P elements")
+    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity")
+    viewmatrix, projmatrix = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
+    scales, rotations, cov3D_precomp = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
+    image_weights = _f32(image_weights, "image_weights")
+    w_work = weights if weights.is_contiguous() else weights.contiguous()
+    c_work = cnt if cnt.is_contiguous() else cnt.contiguous()
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        # the reference passes `weights` in the colour slot only to skip the SH evaluation
+        # (rasterizer_impl.cu:384, apply_weights.cu:219): no colour is needed at all here.
+        R, geom, binning, img = _preprocess_and_bin(dev, P, 0, 0, means3D, scales, float(scale_modifier), rotations,
+                                                    opacity, None, cov3D_precomp, None, viewmatrix, projmatrix, None,
+                                                    W, H, float(tan_fovx), float(tan_fovy), prefiltered, 1, radii)
+        _native.check("gsr_trace_weights", _native.lib().gsr_trace_weights(
+            _stream(dev), P, R, W, H, C, geom.data_ptr(), _ptr(binning), img.data_ptr(), image_weights.data_ptr(),
+            w_work.data_ptr(), c_work.data_ptr()))
+        if debug:
+            torch.cuda.synchronize(dev)
+    if w_work is not weights:
+        weights.copy_(w_work)
+    if c_work is not cnt:
+        cnt.copy_(c_work)
+    return None

@@ -1,0 +1,154 @@
+"""Drop-in replacement for the reference's `diff_gaussian_rasterization` Python package
+(DGR/diff_gaussian_rasterization/__init__.py, 364 lines): same public names, same call
+signatures, same return arities, same exceptions -- backed by the gfx950 HIP library
+instead of the CUDA extension.
+
+Public surface (reference line numbers):
+    GaussianRasterizationSettings   :228-240   NamedTuple of 12 fields
+    GaussianRasterizer              :243-364   nn.Module with forward / markVisible / apply_weights
+    rasterize_gaussians             :26-47
+    _RasterizeGaussians             :50-225    autograd.Function
+
+To let unmodified GaussianEditor code `import diff_gaussian_rasterization`, call
+`gaussianeditor_amd.install()` once.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_RasterizeGaussians"]
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args):
+    """CPU deep copy of a native call's arguments (reference: cpu_deep_copy_tuple, :18-23)."""
+    return tuple(a.cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+
+
+def _call_native(fn, args, debug: bool, dump_path: str, message: str):
+    """Invoke a `_C` entry point; in debug mode dump the inputs on failure, as the
+    reference does (:88-107 forward, :180-200 backward)."""
+    if not debug:
+        return fn(*args)
+    saved = _snapshot(args)  # before anything can corrupt them
+    try:
+        return fn(*args)
+    except Exception:
+        torch.save(saved, dump_path)
+        print(message)
+        raise
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        # argument order of _C.rasterize_gaussians (rasterize_points.h:17-36)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_native(
+            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump",
+            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
+                              binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        # grad_radii / grad_depth are ignored exactly as in the reference (:137, :155-177):
+        # depth is a forward-only output.
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
+         imgBuffer) = ctx.saved_tensors
+        # argument order of _C.rasterize_gaussians_backward (rasterize_points.h:38-60)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,
+                geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _call_native(
+             _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump",
+             "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+        # one slot per forward() input (:213-225)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+def _absent(like: torch.Tensor) -> torch.Tensor:
+    """The reference encodes "not provided" as an empty float32 tensor on "cuda" (:285-295);
+    we put it on the device of `means3D`, which is the same thing for every valid call."""
+    return torch.empty(0, dtype=torch.float32, device=like.device)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points in front of the camera's near plane (:248-256)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None) == (colors_precomp is None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")  # sic, :271-276
+        has_sr = scales is not None or rotations is not None
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (has_sr and cov3D_precomp is not None):
+            raise Exception(
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")  # :278-283
+        shs = _absent(means3D) if shs is None else shs
+        colors_precomp = _absent(means3D) if colors_precomp is None else colors_precomp
+        scales = _absent(means3D) if scales is None else scales
+        rotations = _absent(means3D) if rotations is None else rotations
+        cov3D_precomp = _absent(means3D) if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
+
+    def apply_weights(self, means3D, means2D, opacities, shs=None, weights=None, scales=None, rotations=None,
+                      cov3Ds_precomp=None, cnt=None, image_weights=None):
+        """Semantic tracing (:311-364): every pixel adds its `image_weights` value(s) to
+        `weights[i]` and C to `cnt[i]` for every Gaussian i it would blend.  In place; returns None."""
+        assert weights is not None
+        assert cnt is not None
+        assert image_weights is not None
+        rs = self.raster_settings
+        shs = _absent(means3D) if shs is None else shs
+        scales = _absent(means3D) if scales is None else scales
+        rotations = _absent(means3D) if rotations is None else rotations
+        cov3Ds_precomp = _absent(means3D) if cov3Ds_precomp is None else cov3Ds_precomp
+        # argument order of _C.apply_weights (rasterize_points.h:66-77)
+        _C.apply_weights(rs.bg, means3D, weights, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                         rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, shs,
+                         rs.sh_degree, rs.campos, rs.prefiltered, image_weights, cnt, rs.debug)

@@ -1,0 +1,146 @@
+/* gsr.h -- C ABI of libgsr_hip.so, the MI355X (gfx950) Gaussian-splatting rasterizer.
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `diff_gaussian_rasterization._C` (reference paths relative to
+ * /root/reference/gaussiansplatting/submodules/diff-gaussian-rasterization):
+ *
+ *   _C.rasterize_gaussians           ext.cpp:16, rasterize_points.cu:35-95
+ *       -> gsr_preprocess + gsr_bin + gsr_blend_forward
+ *   _C.rasterize_gaussians_backward  ext.cpp:17, rasterize_points.cu:97-157
+ *       -> gsr_backward
+ *   _C.mark_visible                  ext.cpp:18, rasterize_points.cu:159-175
+ *       -> gsr_mark_visible
+ *   _C.apply_weights                 ext.cpp:19, rasterize_points.cu:177-234
+ *       -> gsr_preprocess + gsr_bin + gsr_trace_weights
+ *
+ * Rules of the boundary
+ *   - plain C: pointers, sizes, scalars; no torch / pybind types.
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`.
+ *   - the library never allocates device memory: the caller (torch) owns every
+ *     output and scratch buffer; sizes come from gsr_scratch_sizes().  Scratch
+ *     buffers are opaque bytes that the caller keeps alive between forward and
+ *     backward (the reference's geomBuffer / binningBuffer / imgBuffer,
+ *     rasterize_points.cu:64-69, diff_gaussian_rasterization/__init__.py:122-133).
+ *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it.
+ *     The library keeps no global state and is re-entrant.
+ *   - an absent optional input is a NULL pointer (the reference uses empty
+ *     tensors for the same purpose, diff_gaussian_rasterization/__init__.py:285-295).
+ *   - return value: GSR_OK (0) or a negative gsr_status; never exit()/abort().
+ *   - all floating point is IEEE binary32; images are CHW; matrices are the
+ *     16-float row-major tensors holding the TRANSPOSED 4x4 matrices exactly as
+ *     the reference passes them.
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+typedef enum gsr_status {
+  GSR_OK = 0,
+  GSR_ERR_BAD_ARGUMENT = -1,   /* NULL where a pointer is required, negative sizes, ... */
+  GSR_ERR_BAD_CHANNELS = -2,   /* apply_weights with C outside {1,2,3} (reference: exit(-1), apply_weights.cu:377-380) */
+  GSR_ERR_TOO_MANY = -3,       /* num_rendered does not fit the 31-bit index space */
+  GSR_ERR_HIP = -4,            /* a HIP runtime call failed; see gsr_last_hip_error() */
+  GSR_ERR_PREFILTERED = -5     /* reserved: prefiltered point culled (reference traps, auxiliary.h:156-160) */
+} gsr_status;
+
+/* Version of this ABI (== GSR_ABI_VERSION of the header the library was built from). */
+int gsr_abi_version(void);
+/* Static description of a status code. */
+const char* gsr_status_string(int status);
+/* hipError_t of the most recent failing HIP call on the calling thread (0 if none). */
+int gsr_last_hip_error(void);
+
+/* Byte sizes of the three opaque scratch buffers for P Gaussians, R rendered
+ * instances and a W x H image.  Pass R = 0 before R is known (sizes[1] is then 0).
+ * sizes[0] = geometry (per Gaussian), sizes[1] = binning (per instance),
+ * sizes[2] = image (per pixel / tile).
+ * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
+int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]);
+
+/* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
+int gsr_sort_key_bits(int W, int H);
+
+/* K1 + K2: per-Gaussian preprocessing (SH -> RGB, 3D -> 2D covariance, conic,
+ * radius, tile rectangle) and the prefix sum over tiles_touched; then the ONE
+ * blocking device->host readback of the path: *num_rendered_host = total number
+ * of (Gaussian, tile) instances.  Reference: FORWARD::preprocess + InclusiveSum +
+ * cudaMemcpy, rasterizer_impl.cu:217-239 (and :381-403 for apply_weights).
+ *
+ *   P, D, M          #Gaussians, active SH degree (0..3), SH coefficients per Gaussian (0 if shs == NULL)
+ *   means3D (P,3); scales (P,3)|NULL; rotations (P,4)|NULL; opacities (P); shs (P,M,3)|NULL;
+ *   cov3D_precomp (P,6)|NULL; colors_precomp (P,3)|NULL  (exactly one of shs/colors, one of scales+rot/cov3D,
+ *   unless skip_color != 0, in which case neither colour source is read: the apply_weights path)
+ *   viewmatrix, projmatrix (16 floats each); campos (3)
+ *   radii (P) int32 out; geom: scratch, sizes[0] bytes. */
+int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, const float* scales,
+                   float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                   const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                   const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                   int prefiltered, int skip_color, int32_t* radii, void* geom, int64_t* num_rendered_host);
+
+/* K3 + K4 + K5: emit one (tile|depth, Gaussian) pair per touched tile, stable radix
+ * sort on the low gsr_sort_key_bits() bits, and per-tile [begin,end) ranges.
+ * Reference: duplicateWithKeys + cub::DeviceRadixSort::SortPairs + identifyTileRanges,
+ * rasterizer_impl.cu:248-271.  `binning` holds sizes[1] bytes for this R. */
+int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, const void* geom, void* binning,
+            void* image);
+
+/* K6: per-tile front-to-back alpha compositing.  Reference: FORWARD::render,
+ * forward.cu:261-409.  out_color (3,H,W), out_depth (1,H,W) are fully written
+ * (background where nothing is blended); final_T / n_contrib go to `image`. */
+int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                      const void* binning, void* image, float* out_color, float* out_depth);
+
+/* K7 + K8 + K9: the whole backward.  Reference: Rasterizer::backward,
+ * rasterizer_impl.cu:289-341 (BACKWARD::render then BACKWARD::preprocess).
+ *   dL_dpix (3,H,W) in.
+ *   Accumulated with atomics, MUST be zero-filled by the caller:
+ *       dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P), dL_dconic (P,4) [workspace].
+ *   Fully written by the library (no need to zero): dL_dmeans3D (P,3), dL_dcov3D (P,6),
+ *       dL_dsh (P,M,3) [NULL if shs == NULL], dL_dscales (P,3) and dL_drots (P,4) [NULL if scales == NULL].
+ *   (The reference zero-fills all nine, rasterize_points.cu:120-128.) */
+int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                 const void* geom, const void* binning, const void* image, const float* dL_dpix,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots);
+
+/* K10: present[i] = (view-space z of point i) > 0.2.  Reference: checkFrustum,
+ * rasterizer_impl.cu:53-63, 128-133.  `present` is one byte per Gaussian (torch.bool). */
+int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present);
+
+/* K12: semantic tracing -- every pixel scatters its C mask values to every Gaussian
+ * it would blend.  weights (P,C) float and cnt (P) int32 are accumulated IN PLACE.
+ * Reference: APPLY_WEIGHTS::render, apply_weights.cu:239-381.  Unlike the reference,
+ * image_weights is only read for pixels inside the image (hazard a). */
+int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const void* geom, const void* binning,
+                      const void* image, const float* image_weights, float* weights, int32_t* cnt);
+
+/* ---- introspection used by the parity tests (not needed by the drop-in) ----
+ * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
+ * scratch buffers into caller-provided DEVICE arrays (any may be NULL):
+ *   means2D (P,2) f32, depths (P) f32, cov3D (P,6) f32, rgb (P,3) f32, conic_opacity (P,4) f32,
+ *   tiles_touched (P) u32, clamped (P,3) u8;
+ *   keys (R) u64 sorted, point_list (R) u32 sorted; ranges (T,2) u32; final_T (N) f32; n_contrib (N) u32. */
+int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
+                          float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped);
+int gsr_debug_export_binning(void* stream, int64_t R, int W, int H, const void* binning, uint64_t* keys,
+                             uint32_t* point_list);
+int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32_t* ranges, float* final_T,
+                           uint32_t* n_contrib);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */

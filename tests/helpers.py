@@ -1,0 +1,90 @@
+"""Shared test plumbing: scene setup, oracle runs, and extraction of the HIP path's
+intermediate state through the debug-export entry points of the C ABI."""
+import math
+
+import numpy as np
+import torch
+
+from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
+
+
+def make_case(P, W, H, seed=1, s0=0.03, view=0, nviews=4, sh_degree=3, scale_xyz=1.0, bg=(0.1, 0.2, 0.3)):
+    sc = synth_scene(P, seed=seed, s0=s0, sh_degree=sh_degree)
+    sc["xyz"] = (sc["xyz"] * scale_xyz).contiguous()
+    cam = ring_cameras(nviews, W, H)[view]
+    case = dict(sc=sc, cam=cam, W=W, H=H, tfx=math.tan(cam.FoVx / 2), tfy=math.tan(cam.FoVy / 2),
+                bg=torch.tensor(bg, dtype=torch.float32), D=sh_degree)
+    return case
+
+
+def oracle_forward(O, case, colors_precomp=None, cov3D_precomp=None, D=None, shs=None, scale_modifier=1.0):
+    sc, cam = case["sc"], case["cam"]
+    shs = sc["features"] if (shs is None and colors_precomp is None) else shs
+    return O.forward(sc["xyz"], None if cov3D_precomp is not None else sc["scaling"],
+                     None if cov3D_precomp is not None else sc["rotation"], sc["opacity"],
+                     None if colors_precomp is not None else shs, colors_precomp, cov3D_precomp,
+                     cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], case["W"],
+                     case["H"], case["tfx"], case["tfy"], scale_modifier, case["D"] if D is None else D)
+
+
+def oracle_backward(O, case, fwd, G, colors_precomp=None, cov3D_precomp=None, D=None, shs=None, scale_modifier=1.0):
+    sc, cam = case["sc"], case["cam"]
+    shs = sc["features"] if (shs is None and colors_precomp is None) else shs
+    return O.backward(fwd, G, sc["xyz"], None if cov3D_precomp is not None else sc["scaling"],
+                      None if cov3D_precomp is not None else sc["rotation"],
+                      None if colors_precomp is not None else shs, colors_precomp, cov3D_precomp,
+                      cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], case["W"],
+                      case["H"], case["tfx"], case["tfy"], scale_modifier, case["D"] if D is None else D)
+
+
+def settings(case, dev, D=None, scale_modifier=1.0, debug=False):
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings
+
+    cam = case["cam"]
+    return GaussianRasterizationSettings(case["H"], case["W"], case["tfx"], case["tfy"], case["bg"].to(dev),
+                                         scale_modifier, cam.world_view_transform.to(dev),
+                                         cam.full_proj_transform.to(dev), case["D"] if D is None else D,
+                                         cam.camera_center.to(dev), False, debug)
+
+
+def hip_state(P, R, W, H, geom, binning, img):
+    """Pull every intermediate out of the opaque scratch buffers (device -> numpy)."""
+    from gaussianeditor_amd import _native
+
+    L = _native.lib()
+    dev = geom.device
+    s = torch.cuda.current_stream(dev).cuda_stream
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)  # noqa: E731
+    out = dict(means2D=f(P, 2), depths=f(P), cov3D=f(P, 6), rgb=f(P, 3), conic_opacity=f(P, 4),
+               tiles_touched=torch.zeros(P, dtype=torch.int32, device=dev),
+               clamped=torch.zeros((P, 3), dtype=torch.uint8, device=dev),
+               keys=torch.zeros(R, dtype=torch.int64, device=dev),
+               point_list=torch.zeros(R, dtype=torch.int32, device=dev),
+               ranges=torch.zeros((T, 2), dtype=torch.int32, device=dev), final_T=f(H * W),
+               n_contrib=torch.zeros(H * W, dtype=torch.int32, device=dev))
+    p = lambda k: out[k].data_ptr()  # noqa: E731
+    _native.check("export_geom", L.gsr_debug_export_geom(s, P, geom.data_ptr(), p("means2D"), p("depths"), p("cov3D"),
+                                                         p("rgb"), p("conic_opacity"), p("tiles_touched"), p("clamped")))
+    if R > 0:
+        _native.check("export_binning", L.gsr_debug_export_binning(s, R, W, H, binning.data_ptr(), p("keys"),
+                                                                   p("point_list")))
+    _native.check("export_image", L.gsr_debug_export_image(s, W, H, img.data_ptr(), p("ranges"), p("final_T"),
+                                                           p("n_contrib")))
+    torch.cuda.synchronize(dev)
+    res = {k: v.cpu().numpy() for k, v in out.items()}
+    res["tiles_touched"] = res["tiles_touched"].view(np.uint32)
+    res["keys"] = res["keys"].view(np.uint64)
+    res["point_list"] = res["point_list"].view(np.uint32)
+    res["ranges"] = res["ranges"].view(np.uint32)
+    res["n_contrib"] = res["n_contrib"].view(np.uint32)
+    return res
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max())) if a.size else 0.0
+
+
+__all__ = ["make_case", "oracle_forward", "oracle_backward", "settings", "hip_state", "rel_err", "seed_gradient"]

@@ -1,0 +1,248 @@
+"""-m gpu: the parity tests proper.  The HIP path (through the C ABI, via the drop-in L1 API)
+is compared stage by stage with the CPU oracle on identical seeded inputs.
+
+Bars: integers / indices bit-exact; forward floats bit-exact in practice (asserted <= 1e-6
+relative, exactness reported); gradients within 1e-5 of the oracle's (relative to the
+tensor's max magnitude -- float atomics re-associate the sums)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_state, make_case, oracle_backward, oracle_forward, rel_err, seed_gradient, settings
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _c():
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+
+    return _C
+
+
+def _run_hip_forward(case, colors_precomp=None, cov3D_precomp=None, D=None, scale_modifier=1.0, shs=None):
+    sc, cam = case["sc"], case["cam"]
+    e = torch.empty(0, device=DEV)
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    shs_t = sc["features"] if shs is None else shs
+    args = (dev(case["bg"]), dev(sc["xyz"]), e if colors_precomp is None else dev(colors_precomp), dev(sc["opacity"]),
+            e if cov3D_precomp is not None else dev(sc["scaling"]), e if cov3D_precomp is not None else dev(sc["rotation"]),
+            scale_modifier, e if cov3D_precomp is None else dev(cov3D_precomp), dev(cam.world_view_transform),
+            dev(cam.full_proj_transform), case["tfx"], case["tfy"], case["H"], case["W"],
+            e if colors_precomp is not None else dev(shs_t), case["D"] if D is None else D, dev(cam.camera_center),
+            False, False)
+    return _c().rasterize_gaussians(*args)
+
+
+def _compare_forward(O, case, **kw):
+    f = oracle_forward(O, case, **kw)
+    R, color, depth, radii, geom, binning, img = _run_hip_forward(case, **kw)
+    P, W, H = case["sc"]["xyz"].shape[0], case["W"], case["H"]
+    st = hip_state(P, R, W, H, geom, binning, img)
+    vis = f["radii"] > 0
+    # --- integers / indices: bit exact
+    assert R == f["num_rendered"]
+    assert np.array_equal(radii.cpu().numpy(), f["radii"])
+    assert np.array_equal(st["tiles_touched"], f["tiles_touched"])
+    assert np.array_equal(st["keys"], f["keys"])
+    assert np.array_equal(st["point_list"], f["point_list"])
+    assert np.array_equal(st["ranges"], f["ranges"])
+    assert np.array_equal(st["n_contrib"], f["n_contrib"])
+    if kw.get("colors_precomp") is None:
+        assert np.array_equal(st["clamped"][vis], f["clamped"][vis])
+    # --- per-Gaussian floats
+    exact = {}
+    for k in ("means2D", "depths", "conic_opacity", "cov3D"):
+        a, b = st[k][vis], f[k][vis]
+        exact[k] = bool(np.array_equal(a, b))
+        assert rel_err(a, b) <= 1e-6, k
+    a, b = st["rgb"][vis], f["colors_used"][vis]
+    exact["rgb"] = bool(np.array_equal(a, b))
+    assert rel_err(a, b) <= 1e-6
+    # --- images
+    col, dep = color.cpu().numpy(), depth.cpu().numpy()
+    exact["final_T"] = bool(np.array_equal(st["final_T"], f["final_T"]))
+    exact["color"] = bool(np.array_equal(col, f["color"]))
+    exact["depth"] = bool(np.array_equal(dep, f["depth"]))
+    assert np.abs(st["final_T"] - f["final_T"]).max() <= 1e-6
+    assert np.abs(col - f["color"]).max() <= 1e-5
+    assert rel_err(dep, f["depth"]) <= 1e-5
+    print("bit-exact:", exact)
+    return f, (R, color, depth, radii, geom, binning, img)
+
+
+@pytest.mark.parametrize("P,W,H,s0,seed", [(10000, 256, 256, 0.03, 1), (3000, 250, 131, 0.05, 2), (500, 64, 64, 0.1, 3),
+                                           (20000, 512, 512, 0.02, 4)])
+def test_forward_all_stages(oracle, P, W, H, s0, seed):
+    case = make_case(P, W, H, seed=seed, s0=s0)
+    _compare_forward(oracle, case)
+
+
+@pytest.mark.parametrize("D,M", [(0, 16), (1, 16), (2, 16), (0, 1), (1, 4), (2, 9)])
+def test_forward_sh_degrees(oracle, D, M):
+    case = make_case(4000, 200, 120, seed=5, s0=0.04)
+    shs = case["sc"]["features"][:, :M, :].contiguous()
+    _compare_forward(oracle, case, D=D, shs=shs)
+
+
+def test_forward_colors_precomp_and_cov3d_precomp(oracle):
+    case = make_case(5000, 256, 192, seed=6, s0=0.04)
+    g = torch.Generator().manual_seed(7)
+    cols = torch.rand(5000, 3, generator=g)
+    f0 = oracle_forward(oracle, case)
+    cov = torch.from_numpy(f0["cov3D"].copy())
+    _compare_forward(oracle, case, colors_precomp=cols)
+    _compare_forward(oracle, case, cov3D_precomp=cov)
+    _compare_forward(oracle, case, colors_precomp=cols, cov3D_precomp=cov)
+
+
+def test_forward_scale_modifier_and_culling(oracle):
+    # camera inside the cloud: many Gaussians behind the near plane, huge splats near the eye
+    case = make_case(3000, 160, 160, seed=8, s0=0.05, scale_xyz=4.0)
+    f, _ = _compare_forward(oracle, case, scale_modifier=0.7)
+    assert (f["radii"] == 0).any() and (f["radii"] > 0).any()
+
+
+def _grads_hip(case, G, colors_precomp=None, cov3D_precomp=None, D=None):
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    sc = case["sc"]
+    rs = settings(case, DEV, D=D)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+    xyz, op = leaf(sc["xyz"]), leaf(sc["opacity"])
+    m2d = torch.zeros_like(xyz, requires_grad=True)
+    kw, leaves = {}, dict(dL_dmeans3D=xyz, dL_dopacity=op, dL_dmeans2D=m2d)
+    if colors_precomp is None:
+        kw["shs"] = leaves["dL_dsh"] = leaf(sc["features"])
+    else:
+        kw["colors_precomp"] = leaves["dL_dcolors"] = leaf(colors_precomp)
+    if cov3D_precomp is None:
+        kw["scales"] = leaves["dL_dscales"] = leaf(sc["scaling"])
+        kw["rotations"] = leaves["dL_drotations"] = leaf(sc["rotation"])
+    else:
+        kw["cov3D_precomp"] = leaves["dL_dcov3D"] = leaf(cov3D_precomp)
+    color, radii, depth = GaussianRasterizer(rs)(xyz, m2d, op, **kw)
+    (color * G.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    return {k: v.grad.cpu().numpy() for k, v in leaves.items()}
+
+
+@pytest.mark.parametrize("P,W,H,s0,seed", [(10000, 256, 256, 0.03, 1), (3000, 250, 131, 0.05, 2), (20000, 512, 512, 0.02, 4)])
+def test_backward_vs_oracle(oracle, P, W, H, s0, seed):
+    case = make_case(P, W, H, seed=seed, s0=s0)
+    G = seed_gradient(H, W, seed) * (H * W)  # O(1) pixel gradients
+    f = oracle_forward(oracle, case)
+    g = oracle_backward(oracle, case, f, G)
+    h = _grads_hip(case, G)
+    for k, v in h.items():
+        e = rel_err(v, g[k].reshape(v.shape))
+        print(k, "rel err", e)
+        assert e <= 1e-5, k
+
+
+def test_backward_precomp_paths(oracle):
+    case = make_case(4000, 192, 128, seed=9, s0=0.05)
+    G = seed_gradient(128, 192, 9) * (128 * 192)
+    cols = torch.rand(4000, 3, generator=torch.Generator().manual_seed(3))
+    f0 = oracle_forward(oracle, case)
+    cov = torch.from_numpy(f0["cov3D"].copy())
+    f = oracle_forward(oracle, case, colors_precomp=cols, cov3D_precomp=cov)
+    g = oracle_backward(oracle, case, f, G, colors_precomp=cols, cov3D_precomp=cov)
+    h = _grads_hip(case, G, colors_precomp=cols, cov3D_precomp=cov)
+    for k, v in h.items():
+        assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+def test_backward_run_to_run_spread():
+    """Float atomics make the backward order-dependent; the spread must stay far below the parity bar."""
+    case = make_case(10000, 256, 256, seed=1, s0=0.03)
+    G = seed_gradient(256, 256, 1) * (256 * 256)
+    a, b = _grads_hip(case, G), _grads_hip(case, G)
+    for k in a:
+        assert rel_err(a[k], b[k]) <= 2e-6, k
+
+
+def test_mark_visible(oracle):
+    case = make_case(5000, 64, 64, seed=10, scale_xyz=4.0)
+    cam = case["cam"]
+    ref = oracle.mark_visible(case["sc"]["xyz"], cam.world_view_transform, cam.full_proj_transform)
+    got = _c().mark_visible(case["sc"]["xyz"].to(DEV), cam.world_view_transform.to(DEV), cam.full_proj_transform.to(DEV))
+    assert got.dtype == torch.bool and np.array_equal(got.cpu().numpy(), ref)
+    assert ref.any() and not ref.all()
+
+
+@pytest.mark.parametrize("C,W,H", [(1, 256, 256), (1, 250, 131), (2, 128, 96), (3, 100, 100)])
+def test_apply_weights(oracle, C, W, H):
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    P = 6000
+    case = make_case(P, W, H, seed=11, s0=0.04)
+    sc, cam = case["sc"], case["cam"]
+    gen = torch.Generator().manual_seed(12)
+    mask = (torch.rand(C, H, W, generator=gen) > 0.5).float()  # 0/1 masks: sums are exact in any order
+    w_ref = np.zeros((P, C), np.float32)
+    c_ref = np.zeros((P,), np.int32)
+    oracle.apply_weights(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], None, cam.world_view_transform,
+                         cam.full_proj_transform, cam.camera_center, W, H, case["tfx"], case["tfy"], mask, w_ref, c_ref)
+    w = torch.zeros((P, C), device=DEV)
+    cnt = torch.zeros((P, 1), dtype=torch.int32, device=DEV)
+    rast = GaussianRasterizer(settings(case, DEV, D=0))
+    for _ in range(2):  # in-place accumulation over two calls
+        rast.apply_weights(sc["xyz"].to(DEV), None, sc["opacity"].to(DEV), None, w, sc["scaling"].to(DEV),
+                           sc["rotation"].to(DEV), None, cnt, mask.to(DEV))
+    torch.cuda.synchronize()
+    assert np.array_equal(cnt.cpu().numpy().reshape(-1), 2 * c_ref)
+    assert np.array_equal(w.cpu().numpy(), 2 * w_ref)
+    assert c_ref.sum() > 0
+
+
+def test_apply_weights_bad_channels():
+    from gaussianeditor_amd import _native
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(100, 32, 32, seed=1)
+    sc = case["sc"]
+    rast = GaussianRasterizer(settings(case, DEV, D=0))
+    with pytest.raises(_native.GsrError):
+        rast.apply_weights(sc["xyz"].to(DEV), None, sc["opacity"].to(DEV), None, torch.zeros(100, 4, device=DEV),
+                           sc["scaling"].to(DEV), sc["rotation"].to(DEV), None,
+                           torch.zeros(100, dtype=torch.int32, device=DEV), torch.zeros(4, 32, 32, device=DEV))
+
+
+def test_empty_and_fully_culled():
+    e = torch.empty(0, device=DEV)
+    case = make_case(10, 48, 40, seed=1)
+    cam = case["cam"]
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    # P == 0: zeros everywhere (rasterize_points.cu:72)
+    out = _c().rasterize_gaussians(dev(case["bg"]), torch.zeros(0, 3, device=DEV), e, torch.zeros(0, 1, device=DEV),
+                                   torch.zeros(0, 3, device=DEV), torch.zeros(0, 4, device=DEV), 1.0, e,
+                                   dev(cam.world_view_transform), dev(cam.full_proj_transform), case["tfx"], case["tfy"],
+                                   40, 48, torch.zeros(0, 16, 3, device=DEV), 3, dev(cam.camera_center), False, False)
+    assert out[0] == 0 and float(out[1].abs().max()) == 0.0 and out[1].shape == (3, 40, 48)
+    # all Gaussians behind the camera: R == 0, image == background
+    sc = case["sc"]
+    behind = sc["xyz"] * 0.1 + cam.camera_center * 2.0  # further out along the eye ray: behind the camera
+    R, color, depth, radii, *_ = _c().rasterize_gaussians(
+        dev(case["bg"]), dev(behind.contiguous()), e, dev(sc["opacity"]), dev(sc["scaling"]), dev(sc["rotation"]), 1.0,
+        e, dev(cam.world_view_transform), dev(cam.full_proj_transform), case["tfx"], case["tfy"], 40, 48,
+        dev(sc["features"]), 3, dev(cam.camera_center), False, False)
+    assert R == 0 and int(radii.abs().max()) == 0
+    assert torch.allclose(color, dev(case["bg"])[:, None, None].expand(3, 40, 48))
+    assert float(depth.abs().max()) == 0.0
+
+
+def test_validation_errors():
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(10, 32, 32, seed=1)
+    sc = case["sc"]
+    rast = GaussianRasterizer(settings(case, DEV))
+    x, o = sc["xyz"].to(DEV), sc["opacity"].to(DEV)
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        rast(x, x, o, scales=sc["scaling"].to(DEV), rotations=sc["rotation"].to(DEV))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation"):
+        rast(x, x, o, shs=sc["features"].to(DEV))
+    with pytest.raises(RuntimeError, match="means3D must have dimensions"):
+        rast(x.reshape(-1), x, o, shs=sc["features"].to(DEV), scales=sc["scaling"].to(DEV), rotations=sc["rotation"].to(DEV))
