@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the rasterizer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Workload (BASELINE.json metric, config C4): synth-v1 scene, 1,000,000 Gaussians, SH degree 3
+(M = 16), 1920x1080, ring-v1 cameras; rank r renders view r (one view per GPU, weak scaling).
+A step = forward + backward of this rank's view through the drop-in L1 API + the gradient
+all-reduce (SUM over the flat bucket, MAX over radii); inputs are resident in HBM.
+
+One JSON line is printed by rank 0: the train rate is `value`; the forward-only rate
+(renders/s, Mpixels/s), the per-stage GPU times, the roofline of the dominant stage and
+the CPU-oracle baseline ride along in the same object.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(P, V, R, N, T, M):
+    """compulsory HBM bytes per stage for one view."""
+    return {
+        "preprocess": (48 + 12 * M) * P + 67 * V,            # K1+K2: params in, radii + survivor state out
+        "bin": 36 * R + 16 * T,                              # K3 emit 12 + K4 sort 24 per instance, K5 ranges
+        "blend_forward": 44 * R + 24 * N,                    # K6: list 4 + gather 40 per instance; 24 B per pixel out
+        "blend_backward": 20 * N + 76 * R,                   # K7: pixel inputs 20; per instance 4 + 36 + 36
+        "preprocess_backward": (103 + 12 * M) * V + (56 + 12 * M) * P,  # K8+K9
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=6, help="oracle train iterations timed for cpu_baseline")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the rasterizer has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from gaussianeditor_amd import _native
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+    from gaussianeditor_amd.multiview import GradBucket, allreduce_view_grads, render_view_grads
+    from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
+
+    P, W, H = args.gaussians, args.width, args.height
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    sc = synth_scene(P, seed=0, s0=0.01, sh_degree=3)
+    M = sc["features"].shape[1]
+    cam = ring_cameras(8, W, H)[rank % 8]
+    tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    params = {k: sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+    G = seed_gradient(H, W, 0).to(dev)
+    rs = GaussianRasterizationSettings(H, W, tfx, tfy, sc["bg"].to(dev), 1.0, cam.world_view_transform.to(dev),
+                                       cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
+    bucket = GradBucket(P, M, dev)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(seconds: float) -> float:
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---------------- train step: fwd + bwd + all-reduce ----------------
+    def train_step():
+        color, radii, depth, grads = render_view_grads(rs, params["xyz"], params["opacity"], params["features"],
+                                                       params["scaling"], params["rotation"], G, bucket)
+        allreduce_view_grads(bucket, radii)
+        return radii
+
+    for _ in range(args.warmup):
+        train_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        radii = train_step()
+    sync_all()
+    train_s = max_over_ranks(time.perf_counter() - t0)
+
+    # ---------------- forward only ----------------
+    rast = GaussianRasterizer(rs)
+    m2d = torch.zeros_like(params["xyz"])
+
+    def fwd_step():
+        with torch.no_grad():
+            return rast(params["xyz"], m2d, params["opacity"], shs=params["features"], scales=params["scaling"],
+                        rotations=params["rotation"])
+
+    for _ in range(max(2, args.warmup // 2)):
+        fwd_step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd_step()
+    sync_all()
+    fwd_s = max_over_ranks(time.perf_counter() - t0)
+
+    # ---------------- per-stage GPU time (HIP events on the launch stream), rank-local ----------------
+    L = _native.lib()
+    s = torch.cuda.current_stream(dev)
+    sp = s.cuda_stream
+    import ctypes
+    e = torch.empty(0, device=dev)
+    names = ("preprocess", "bin", "blend_forward", "blend_backward", "preprocess_backward")
+    acc = {k: 0.0 for k in names}
+    p = lambda t: t.data_ptr()  # noqa: E731
+    op_flat = params["opacity"].contiguous()
+    R = V = 0
+    stage_iters = max(5, min(args.steps, 20))
+    for it in range(stage_iters + 2):
+        gb, _, ib = _native.scratch_sizes(P, 0, W, H)
+        geom = torch.empty(gb, dtype=torch.uint8, device=dev)
+        img = torch.empty(ib, dtype=torch.uint8, device=dev)
+        radii_t = torch.empty(P, dtype=torch.int32, device=dev)
+        color = torch.empty((3, H, W), device=dev)
+        depth = torch.empty((1, H, W), device=dev)
+        z = torch.zeros(P * 11, device=dev)
+        d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
+        d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
+        d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        Rc = ctypes.c_int64(0)
+        ev[0].record(s)
+        _native.check("pre", L.gsr_preprocess(sp, P, 3, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
+                                              p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
+                                              p(rs.campos), W, H, tfx, tfy, 0, 0, p(radii_t), p(geom), ctypes.byref(Rc)))
+        ev[1].record(s)
+        R = int(Rc.value)
+        _, bb, _ = _native.scratch_sizes(P, R, W, H)
+        binning = torch.empty(bb, dtype=torch.uint8, device=dev)
+        _native.check("bin", L.gsr_bin(sp, P, R, W, H, p(radii_t), p(geom), p(binning), p(img)))
+        ev[2].record(s)
+        _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth)))
+        ev[3].record(s)
+        _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
+                                                  p(d_con), p(d_op), p(d_col)))
+        ev[4].record(s)
+        _native.check("pbw", L.gsr_preprocess_backward(sp, P, 3, M, W, H, p(params["xyz"]), p(params["features"]),
+                                                       p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
+                                                       p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom), p(d_m2),
+                                                       p(d_con), p(d_col), p(d_m3), p(d_cov), p(d_sh), p(d_sc), p(d_rot)))
+        ev[5].record(s)
+        torch.cuda.synchronize(dev)
+        if it >= 2:
+            for i, k in enumerate(names):
+                acc[k] += ev[i].elapsed_time(ev[i + 1])
+        V = int((radii_t > 0).sum().item())
+    stage_ms = {k: acc[k] / stage_iters for k in names}
+    ab = algorithmic_bytes(P, V, R, N, T, M)
+    dominant = max(stage_ms, key=stage_ms.get)
+    ach = ab[dominant] / (stage_ms[dominant] * 1e-3) / 1e9  # GB/s
+
+    # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N == 1) ----------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu as O
+
+        cam0 = cam
+        G_cpu = seed_gradient(H, W, 0)
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_iters):
+            f = O.forward(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], None, None,
+                          cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"], W, H, tfx, tfy,
+                          1.0, 3)
+            O.backward(f, G_cpu, sc["xyz"], sc["scaling"], sc["rotation"], sc["features"], None, None,
+                       cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"], W, H, tfx, tfy,
+                       1.0, 3)
+        cpu_s = time.perf_counter() - t0
+        cpu = {"value": args.cpu_iters / cpu_s, "unit": "train iters/s", "cores": O.num_threads(), "kind": "port",
+               "sample": f"{args.cpu_iters} train iterations (fwd+bwd, one 1920x1080 view of the same 1M-Gaussian scene) "
+                         f"in {cpu_s:.1f} s with OpenMP over {O.num_threads()} threads; host has {os.cpu_count()} logical cores",
+               "pixel_instances_per_view": int(f["pixel_instances"])}
+
+    if rank == 0:
+        iters_per_s = world * args.steps / train_s
+        renders_per_s = world * args.steps / fwd_s
+        out = {
+            "metric": "train iters/sec (fwd+bwd of one 1080p view per GPU + grad all-reduce), 1M Gaussians @1080p",
+            "value": iters_per_s,
+            "unit": "view-iters/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * train_s / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16), {W}x{H}, ring-v1 8 views, one view per GPU "
+                                   "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
+                       "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
+                       "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
+            "forward_renders_per_s": renders_per_s,
+            "forward_mpixels_per_s": renders_per_s * N / 1e6,
+            "forward_ms": 1e3 * fwd_s / args.steps,
+            "stage_ms": stage_ms,
+            "stage_algorithmic_bytes": ab,
+            "hbm_fraction_train_iter": (sum(ab.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

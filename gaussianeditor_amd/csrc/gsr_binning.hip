@@ -178,12 +178,52 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint6
   if (idx == L - 1) ranges[currtile].y = (uint32_t)L;
 }
 
+// ----------------------------------------------------------------------------------
+// Work list for the blend kernels: tile ids ordered longest-list-first (bucketed by
+// ceil(len/64)), empty tiles last.  One 1024-thread block; T is a few thousand.
+// The order inside a bucket depends on LDS-atomic timing: it only affects scheduling,
+// never results.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
+                                                            uint32_t* __restrict__ order, uint32_t* __restrict__ meta) {
+  __shared__ uint32_t hist[WORK_BUCKETS + 1], cursor[WORK_BUCKETS + 1];
+  for (int i = threadIdx.x; i <= WORK_BUCKETS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  auto bucket_of = [](uint32_t len) -> uint32_t {
+    if (len == 0) return WORK_BUCKETS;  // empty tiles: last
+    const uint32_t c = (len + 63u) / 64u;
+    return (uint32_t)(WORK_BUCKETS - 1) - min(c - 1u, (uint32_t)(WORK_BUCKETS - 1));
+  };
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint2 r = ranges[t];
+    atomicAdd(&hist[bucket_of(r.y - r.x)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i <= WORK_BUCKETS; ++i) {
+      cursor[i] = run;
+      run += hist[i];
+    }
+    meta[0] = cursor[WORK_BUCKETS];  // number of non-empty tiles
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint2 r = ranges[t];
+    const uint32_t pos = atomicAdd(&cursor[bucket_of(r.y - r.x)], 1u);
+    order[pos] = (uint32_t)t;
+  }
+}
+
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
                           const Binning& b, const Image& im) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
   if (e != hipSuccess) return e;
-  if (R <= 0) return hipSuccess;
+  if (R <= 0) {
+    hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta);
+    return hipGetLastError();
+  }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   hipLaunchKernelGGL(emit_keys_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, b.keys[0], b.vals[0]);
   int cur = 0;
@@ -198,6 +238,7 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
   }
   const int64_t nbr = (R + 255) / 256;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.keys[cur], im.ranges);
+  hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta);
   return hipGetLastError();
 }
 

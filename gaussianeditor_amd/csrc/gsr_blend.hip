@@ -11,13 +11,19 @@
 //     "no lane contributes" early-outs (scalar branches on a 64-bit ballot) fire often;
 //   * each wave stages 64 sorted instances at a time in LDS (3 x float4 per instance, read
 //     back as uniform-address ds_read_b128 broadcasts);
-//   * workgroup ids are remapped so that the 64 waves of a 4x4-tile super-tile are
-//     consecutive on ONE XCD (blockIdx % 8): the 4 quadrants of a tile and its neighbours
-//     gather the same Gaussians from the same 4 MiB L2, while super-tiles are dealt
-//     round-robin to the 8 XCDs for load balance;
+//   * the kernels are PERSISTENT: a fixed number of single-wave workgroups (a few per SIMD)
+//     pull (tile, quadrant) items from eight per-XCD queues (one relaxed agent-scope atomic
+//     per item).  Tiles are queued longest-list-first (gsr_binning.hip: tile_worklist_kernel)
+//     and dealt round-robin to the XCD queues, so every XCD gets the same amount of work, the
+//     heavy quadrants start first and the light ones fill the gaps (the instance lists are
+//     heavy-tailed: with one workgroup per quadrant most SIMDs idle through a long tail);
+//     the four quadrants of a tile are consecutive items of ONE queue, so they gather the same
+//     Gaussians through the same 4 MiB L2.  Which wave runs an item never affects results;
 //   * the backward reduces the 9 per-Gaussian gradient terms across the 64 lanes with DPP
 //     row shifts / row broadcasts (6 v_add_f32_dpp per value) and issues ONE vectorised
 //     atomic per (quadrant, instance, term) instead of the reference's one per pixel.
+#include <stdlib.h>
+
 #include "gsr_kernels.h"
 
 namespace gsr {
@@ -28,78 +34,225 @@ struct PixelWave {
   bool inside;
 };
 
-// XCD-aware workgroup -> (tile, quadrant) map.  Returns false if this wave has no pixels.
-__device__ __forceinline__ bool map_wave(const BlendArgs& a, PixelWave& pw) {
-  const uint32_t b = blockIdx.x;
-  const uint32_t xcd = b & 7u, k = b >> 3;
-  const uint32_t s = xcd + 8u * (k >> 6), w = k & 63u;
-  if (s >= (uint32_t)a.NS) return false;
-  const uint32_t sx = s % (uint32_t)a.SX, sy = s / (uint32_t)a.SX;
-  const uint32_t t = w >> 2, quad = w & 3u;
-  const int tx = (int)(sx * 4 + (t & 3u)), ty = (int)(sy * 4 + (t >> 2));
-  if (tx >= a.gx || ty >= a.gy) return false;
+// (tile, quadrant) -> this lane's pixel.  Returns false if the quadrant lies outside the image.
+__device__ __forceinline__ bool setup_wave(const BlendArgs& a, uint32_t tile, uint32_t quad, PixelWave& pw) {
+  const int tx = (int)(tile % (uint32_t)a.gx), ty = (int)(tile / (uint32_t)a.gx);
   const int lane = lane_id();
-  pw.tile = ty * a.gx + tx;
+  pw.tile = (int)tile;
   pw.px = tx * TILE + (int)(quad & 1u) * QUAD + (lane & 7);
   pw.py = ty * TILE + (int)(quad >> 1) * QUAD + (lane >> 3);
   pw.inside = pw.px < a.W && pw.py < a.H;
   return __any(pw.inside) != 0;
 }
 
-__host__ inline unsigned blend_grid(int gx, int gy, int* SX, int* NS) {
-  *SX = (gx + 3) / 4;
-  const int SY = (gy + 3) / 4;
-  *NS = *SX * SY;
-  return 8u * 64u * (unsigned)((*NS + 7) / 8);
+// Persistent work loop.  Queue x (one per XCD) owns entries x, x+8, x+16, ... of work_order;
+// its cursor counts quadrant items (4 per non-empty tile) and then, if `with_empty`, one item
+// per empty tile.  A wave serves the queue of the XCD it happens to run on (HW_REG_XCC_ID, a
+// placement hint only: any wave may run any item).
+template <class F>
+__device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
+  const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID
+  const uint32_t nwork = a.work_meta[0];
+  const uint32_t T = (uint32_t)(a.gx * a.gy);
+  const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
+  const uint32_t nempty = with_empty ? T - nwork : 0u;
+  const uint32_t e_x = nempty > x ? (nempty - x + 7u) / 8u : 0u;
+  const uint32_t total = 4u * n_x + e_x;
+  uint32_t* head = a.queue + x * QUEUE_STRIDE;
+  for (;;) {
+    uint32_t q = 0;
+    if (lane_id() == 0) q = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (q >= total) break;
+    if (q < 4u * n_x)
+      item(a.work_order[x + 8u * (q >> 2)], q & 3u, false);
+    else
+      item(a.work_order[nwork + x + 8u * (q - 4u * n_x)], 0u, true);
+  }
 }
+
+constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
+
+// Sums each of four per-lane values over the 64 lanes of the wave, 10 instructions for all four
+// instead of 4 x 6: two v_permlane32_swap + adds fold the half-waves (a,c | b,d), one
+// v_permlane16_swap + add folds row pairs so that row r of the wave holds 16 partial sums of
+// value r, then 4 row_shr DPP adds finish each row.  The total of value r ends up in lane 16 r + 15.
+__device__ __forceinline__ float wave_sum4_to_rows(float a, float b, float c, float d) {
+  unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+  unsigned uc = __builtin_bit_cast(unsigned, c), ud = __builtin_bit_cast(unsigned, d);
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(ua, uc, false, false);  // ua = [a_lo|c_lo], uc = [a_hi|c_hi]
+    ua = r[0];
+    uc = r[1];
+  }
+  {
+    auto r = __builtin_amdgcn_permlane32_swap(ub, ud, false, false);
+    ub = r[0];
+    ud = r[1];
+  }
+  const float x = __builtin_bit_cast(float, ua) + __builtin_bit_cast(float, uc);  // lanes 0-31: a, 32-63: c
+  const float y = __builtin_bit_cast(float, ub) + __builtin_bit_cast(float, ud);  // lanes 0-31: b, 32-63: d
+  unsigned ux = __builtin_bit_cast(unsigned, x), uy = __builtin_bit_cast(unsigned, y);
+  {
+    auto r = __builtin_amdgcn_permlane16_swap(ux, uy, false, false);  // ux rows [x0,y0,x2,y2], uy rows [x1,y1,x3,y3]
+    ux = r[0];
+    uy = r[1];
+  }
+  float z = __builtin_bit_cast(float, ux) + __builtin_bit_cast(float, uy);  // rows: a, b, c, d
+  z = dpp_add<0x111>(z);
+  z = dpp_add<0x112>(z);
+  z = dpp_add<0x114>(z);
+  z = dpp_add<0x118>(z);
+  return z;
+}
+
+struct Entry {
+  uint32_t id;
+  float4 r0, r1, r2;
+};
+
+__device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r1, float qx0, float qy0) {
+  // r0 = conic.x, conic.y, conic.z, opacity; r1 = mean.x, mean.y, depth, radius
+  const float o = r0.w;
+  if (!(o >= 1.0f / 255.0f)) return !(o == o) ? true : false;  // o < 1/255: alpha < 1/255 everywhere (NaN: keep)
+  const float det = r0.x * r0.z - r0.y * r0.y;
+  if (!(det > 0.0f)) return true;  // degenerate / NaN conic: never cull
+  const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f);
+  const float inv = __builtin_amdgcn_rcpf(det) * 1.0001f;
+  const float hx = __builtin_sqrtf(tau2 * r0.z * inv) + 0.01f;
+  const float hy = __builtin_sqrtf(tau2 * r0.x * inv) + 0.01f;
+  if (!(hx == hx) || !(hy == hy)) return true;
+  const bool out = (r1.x + hx < qx0) || (r1.x - hx > qx0 + (float)(QUAD - 1)) || (r1.y + hy < qy0) ||
+                   (r1.y - hy > qy0 + (float)(QUAD - 1));
+  return !out;
+}
+
+// Walks list positions in chunks.  FORWARD: positions [0,len) ascending, lane l of chunk c holds
+// position 64c + l.  Otherwise descending from `top`: lane l of chunk c holds top-1-(64c+l).
+template <bool FORWARD>
+struct ChunkWalker {
+  const BlendArgs& a;
+  uint32_t list_base;  // range.x
+  uint32_t count;      // number of positions to walk
+  uint32_t id_next, id_next2;
+  Entry cur, nxt;
+  uint32_t chunk;  // index of the chunk held in `cur`
+
+  __device__ __forceinline__ uint32_t pos_of(uint32_t k) const {  // k = 64*chunk + lane
+    return FORWARD ? k : (count - 1 - k);
+  }
+  // All loads are UNCONDITIONAL (out-of-range lanes re-read the last entry): a predicated load would
+  // make hipcc merge old and new register values right after the issue and wait for the data there,
+  // which defeats the prefetch.
+  __device__ __forceinline__ uint32_t load_id(uint32_t k) const {
+    return a.point_list[list_base + pos_of(min(k, count - 1u))];
+  }
+  __device__ __forceinline__ void gather(Entry& e, uint32_t id) const {
+    e.id = id;
+    e.r0 = a.rec0[id];
+    e.r1 = a.rec1[id];
+    e.r2 = a.rec2[id];
+  }
+  __device__ __forceinline__ ChunkWalker(const BlendArgs& a_, uint32_t base, uint32_t n) : a(a_), list_base(base), count(n) {
+    const uint32_t l = (uint32_t)lane_id();
+    const uint32_t id0 = load_id(l);
+    id_next = load_id(WAVE + l);
+    id_next2 = load_id(2 * WAVE + l);
+    gather(cur, id0);
+    gather(nxt, id_next);
+    chunk = 0;
+  }
+  // number of list positions covered by the current chunk
+  __device__ __forceinline__ uint32_t chunk_size() const { return min((uint32_t)WAVE, count - chunk * WAVE); }
+  __device__ __forceinline__ bool valid() const { return chunk * WAVE < count; }
+  // list position (0-based, in tile order) held by this lane in the current chunk
+  __device__ __forceinline__ uint32_t lane_pos() const { return pos_of(chunk * WAVE + (uint32_t)lane_id()); }
+  // advance: cur <- nxt, start the loads for the chunk after next
+  __device__ __forceinline__ void advance() {
+    const uint32_t l = (uint32_t)lane_id();
+    cur = nxt;
+    chunk++;
+    gather(nxt, id_next2);
+    id_next = id_next2;
+    id_next2 = load_id((chunk + 2) * WAVE + l);
+  }
+};
 
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
+template <bool PROFILE>
+__device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited) {
   PixelWave pw;
-  if (!map_wave(a, pw)) return;
+  if (!setup_wave(a, tile, quad, pw)) return;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
+  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
   bool done = !pw.inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last_contributor = 0;
 
   __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
-  for (uint32_t base = range.x; base < range.y; base += WAVE) {
-    if (__all(done)) break;
-    const uint32_t n = min((uint32_t)WAVE, range.y - base);
-    __syncthreads();
-    if ((uint32_t)lane < n) {
-      const uint32_t id = a.point_list[base + lane];
-      s0[lane] = a.rec0[id];
-      s1[lane] = a.rec1[id];
-      s2[lane] = a.rec2[id];
-    }
-    __syncthreads();
-    const uint32_t cbase = base - range.x;
-    for (uint32_t j = 0; !done && j < n; ++j) {
-      const float4 g = s1[j];
-      const float4 co = s0[j];
-      const float dx = g.x - pfx, dy = g.y - pfy;
-      const float power = blend_power(co.x, co.y, co.z, dx, dy);
-      if (power > 0.0f) continue;
-      const float alpha = fminf(0.99f, co.w * gsr_expf(power));
-      if (alpha < 1.0f / 255.0f) continue;
-      const float test_T = T * (1.0f - alpha);
-      if (test_T < 0.0001f) {
-        done = true;
-        continue;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  if (range.y > range.x) {
+    ChunkWalker<true> walk(a, range.x, range.y - range.x);
+    for (; walk.valid(); walk.advance()) {
+      if (__all(done)) break;
+      const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+      const uint64_t m = __ballot(keep);
+      if (m == 0) continue;
+      const uint32_t cnt = (uint32_t)__popcll(m);
+      const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
+      __syncthreads();
+      if (keep) {
+        const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
+        s0[slot] = walk.cur.r0;
+        s1[slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(walk.lane_pos() + 1u));
+        s2[slot] = walk.cur.r2;
       }
-      const float4 col = s2[j];
-      const float w = alpha * T;
-      C0 = __builtin_fmaf(col.x, w, C0);
-      C1 = __builtin_fmaf(col.y, w, C1);
-      C2 = __builtin_fmaf(col.z, w, C2);
-      D = __builtin_fmaf(g.z, w, D);
-      T = test_T;
-      last_contributor = cbase + j + 1;
+      if ((uint32_t)lane >= cnt && (uint32_t)lane < cnt4) {
+        // null entries pad the survivors to a multiple of GROUP: opacity 0 => alpha 0 => never a hit
+        s0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s1[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+        s2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      __syncthreads();
+      // GROUP entries per iteration: the footprint / exp evaluations of a group are independent
+      // straight-line code (ILP for a wave that is alone on its SIMD); only the short
+      // transmittance chain below is serial.
+      for (uint32_t j = 0; j < cnt4; j += GROUP) {
+        if (__all(done)) break;
+        if (PROFILE) prof_visited += GROUP;
+        float al[GROUP];
+        bool ok[GROUP];
+        float4 gg[GROUP], cc[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+          gg[u] = s1[j + u];
+          const float4 co = s0[j + u];
+          cc[u] = s2[j + u];
+          const float dx = gg[u].x - pfx, dy = gg[u].y - pfy;
+          const float power = blend_power(co.x, co.y, co.z, dx, dy);
+          al[u] = fminf(0.99f, co.w * gsr_expf(power));
+          ok[u] = !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
+        }
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+          const bool hit = ok[u] && !done;
+          const float test_T = T * (1.0f - al[u]);
+          const bool term = hit && (test_T < 0.0001f);
+          done = done || term;
+          const bool b = hit && !term;
+          const float w = al[u] * T;
+          C0 = b ? __builtin_fmaf(cc[u].x, w, C0) : C0;
+          C1 = b ? __builtin_fmaf(cc[u].y, w, C1) : C1;
+          C2 = b ? __builtin_fmaf(cc[u].z, w, C2) : C2;
+          D = b ? __builtin_fmaf(gg[u].z, w, D) : D;
+          T = b ? test_T : T;
+          last_contributor = b ? __float_as_uint(gg[u].w) : last_contributor;
+        }
+      }
     }
   }
   if (pw.inside) {
@@ -113,6 +266,46 @@ __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) 
   }
 }
 
+template <bool PROFILE>
+__global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
+  uint64_t t_start = 0;
+  uint32_t prof_visited = 0, prof_items = 0;
+  if (PROFILE) t_start = __builtin_amdgcn_s_memtime();
+  run_work_queue(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
+    if (PROFILE) prof_items++;
+    if (!empty) {
+      forward_item<PROFILE>(a, tile, quad, prof_visited);
+    } else {
+      // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
+      for (uint32_t q = 0; q < 4; ++q) {
+        PixelWave pw;
+        if (!setup_wave(a, tile, q, pw)) continue;
+        if (pw.inside) {
+          const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
+          a.final_T[pix] = 1.0f;
+          a.n_contrib[pix] = 0u;
+          a.out_color[pix] = __builtin_fmaf(1.0f, a.bg[0], 0.f);
+          a.out_color[HW + pix] = __builtin_fmaf(1.0f, a.bg[1], 0.f);
+          a.out_color[2 * HW + pix] = __builtin_fmaf(1.0f, a.bg[2], 0.f);
+          a.out_depth[pix] = 0.f;
+        }
+      }
+    }
+  });
+  if (PROFILE) {
+    // debug record per persistent wave: start, end (s_memtime ticks), XCC_ID<<32 | HW_ID, items<<32 | visited entries
+    const uint64_t t_end = __builtin_amdgcn_s_memtime();
+    if (lane_id() == 0) {
+      uint64_t* rec = a.profile + (size_t)blockIdx.x * 4;
+      rec[0] = t_start;
+      rec[1] = t_end;
+      rec[2] = ((uint64_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |  // HW_REG_XCC_ID[3:0]
+               (uint64_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);              // HW_REG_HW_ID
+      rec[3] = ((uint64_t)prof_items << 32) | (uint64_t)prof_visited;
+    }
+  }
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
@@ -122,13 +315,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ----------------------------------------------------------------------------------
 // K7: renderCUDA (backward), DGR/cuda_rasterizer/backward.cu:399-557.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a) {
+__device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
-  if (!map_wave(a, pw)) return;
+  if (!setup_wave(a, tile, quad, pw)) return;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
+  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
 
   const float T_final = pw.inside ? a.final_T[pix] : 0.f;
@@ -154,77 +348,98 @@ __global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a)
   __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
   __shared__ uint32_t sid[WAVE];
   __shared__ float sacc[9][WAVE];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  // back to front over positions [0, maxc) of the tile's list, 64 at a time
-  for (uint32_t end = maxc; end > 0; end -= min(end, (uint32_t)WAVE)) {
-    const uint32_t n = min((uint32_t)WAVE, end);
+  // back to front over positions [0, maxc) of the tile's list
+  ChunkWalker<false> walk(a, range.x, maxc);
+  for (; walk.valid(); walk.advance()) {
+    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+    const uint64_t m = __ballot(keep);
+    if (m == 0) continue;
+    const uint32_t cnt = (uint32_t)__popcll(m);
+    const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
     __syncthreads();
-    if ((uint32_t)lane < n) {
-      const uint32_t id = a.point_list[range.x + end - 1 - lane];
-      sid[lane] = id;
-      s0[lane] = a.rec0[id];
-      s1[lane] = a.rec1[id];
-      s2[lane] = a.rec2[id];
+    if (keep) {
+      const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
+      sid[slot] = walk.cur.id;
+      s0[slot] = walk.cur.r0;
+      s1[slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(walk.lane_pos()));
+      s2[slot] = walk.cur.r2;
+    }
+    if ((uint32_t)lane >= cnt && (uint32_t)lane < cnt4) {
+      s0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: alpha 0 => never contributes
+      s1[lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+      s2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) sacc[k][lane] = 0.f;
     __syncthreads();
 
-    for (uint32_t j = 0; j < n; ++j) {
-      const uint32_t c = end - 1 - j;  // 0-based position of this instance in the tile list
-      const float4 g = s1[j];
-      const float4 co = s0[j];
-      const float dx = g.x - pfx, dy = g.y - pfy;
-      const float power = blend_power(co.x, co.y, co.z, dx, dy);
-      bool contrib = (c < last_contributor) && !(power > 0.0f);
-      float G = 0.f, alpha = 0.f;
-      if (contrib) {
-        G = gsr_expf(power);
-        alpha = fminf(0.99f, co.w * G);
-        contrib = !(alpha < 1.0f / 255.0f);
+    for (uint32_t j = 0; j < cnt4; j += GROUP) {
+      float G[GROUP], al[GROUP], dxs[GROUP], dys[GROUP];
+      bool contrib[GROUP];
+      float4 cos_[GROUP], cols[GROUP];
+      bool any = false;
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) {
+        const float4 g = s1[j + u];
+        cos_[u] = s0[j + u];
+        cols[u] = s2[j + u];
+        const uint32_t c = __float_as_uint(g.w);  // 0-based position of this instance in the tile list
+        dxs[u] = g.x - pfx;
+        dys[u] = g.y - pfy;
+        const float power = blend_power(cos_[u].x, cos_[u].y, cos_[u].z, dxs[u], dys[u]);
+        G[u] = gsr_expf(power);
+        al[u] = fminf(0.99f, cos_[u].w * G[u]);
+        contrib[u] = (c < last_contributor) && !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
+        any = any || contrib[u];
       }
-      if (!__any(contrib)) continue;  // wave-uniform
+      if (!__any(any)) continue;  // wave-uniform
 
-      float v[9];
+      float v[9][GROUP];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) v[k] = 0.f;
-      if (contrib) {
-        const float4 col = s2[j];
-        const float one_m = 1.f - alpha;
-        T = T * __builtin_amdgcn_rcpf(one_m);  // T / (1 - alpha), backward.cu:503
-        const float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.0f;
-        const float cc[3] = {col.x, col.y, col.z};
+      for (int u = 0; u < GROUP; ++u) {
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) {
-          accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-          last_color[ch] = cc[ch];
-          dL_dalpha += (cc[ch] - accum_rec[ch]) * dpx[ch];
-          v[6 + ch] = dchannel_dcolor * dpx[ch];
+        for (int k = 0; k < 9; ++k) v[k][u] = 0.f;
+        if (contrib[u]) {
+          const float4 co = cos_[u];
+          const float alpha = al[u], dx = dxs[u], dy = dys[u];
+          const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
+          T = T * inv_one_m;  // T / (1 - alpha), backward.cu:503
+          const float dchannel_dcolor = alpha * T;
+          float dL_dalpha = 0.0f;
+          const float cc[3] = {cols[u].x, cols[u].y, cols[u].z};
+#pragma unroll
+          for (int ch = 0; ch < 3; ch++) {
+            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+            last_color[ch] = cc[ch];
+            dL_dalpha += (cc[ch] - accum_rec[ch]) * dpx[ch];
+            v[6 + ch][u] = dchannel_dcolor * dpx[ch];
+          }
+          dL_dalpha *= T;
+          last_alpha = alpha;
+          dL_dalpha += (-T_final * inv_one_m) * bg_dot_dpixel;
+          const float dL_dG = co.w * dL_dalpha;
+          const float gdx = G[u] * dx, gdy = G[u] * dy;
+          const float dG_ddelx = -gdx * co.x - gdy * co.y;
+          const float dG_ddely = -gdy * co.z - gdx * co.y;
+          v[0][u] = dL_dG * dG_ddelx * ddelx_dx;
+          v[1][u] = dL_dG * dG_ddely * ddely_dy;
+          v[2][u] = -0.5f * gdx * dx * dL_dG;
+          v[3][u] = -0.5f * gdx * dy * dL_dG;
+          v[4][u] = -0.5f * gdy * dy * dL_dG;
+          v[5][u] = G[u] * dL_dalpha;
         }
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final * __builtin_amdgcn_rcpf(one_m)) * bg_dot_dpixel;
-        const float dL_dG = co.w * dL_dalpha;
-        const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-        const float dG_ddely = -gdy * co.z - gdx * co.y;
-        v[0] = dL_dG * dG_ddelx * ddelx_dx;
-        v[1] = dL_dG * dG_ddely * ddely_dy;
-        v[2] = -0.5f * gdx * dx * dL_dG;
-        v[3] = -0.5f * gdx * dy * dL_dG;
-        v[4] = -0.5f * gdy * dy * dL_dG;
-        v[5] = G * dL_dalpha;
       }
+      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave total of entry j + r
 #pragma unroll
-      for (int k = 0; k < 9; ++k) v[k] = wave_sum_to_lane63(v[k]);
-      if (lane == 63) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) sacc[k][j] = v[k];
+      for (int k = 0; k < 9; ++k) {
+        const float tot = wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
+        if ((lane & 15) == 15) sacc[k][j + (uint32_t)(lane >> 4)] = tot;
       }
     }
     __syncthreads();
-    if ((uint32_t)lane < n) {
+    if ((uint32_t)lane < cnt) {
       float r[9];
       bool any = false;
 #pragma unroll
@@ -248,6 +463,10 @@ __global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a)
   }
 }
 
+__global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a) {
+  run_work_queue(a, false, [&](uint32_t tile, uint32_t quad, bool) { backward_item(a, tile, quad); });
+}
+
 // ----------------------------------------------------------------------------------
 // K12: renderCUDA_apply_weights, DGR/cuda_rasterizer/apply_weights.cu:239-356.
 // Same traversal / termination as K6; every blended (pixel, instance) adds the pixel's
@@ -255,13 +474,14 @@ __global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a)
 // channel loop, apply_weights.cu:331-339).
 // ----------------------------------------------------------------------------------
 template <int C>
-__global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
+__device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
-  if (!map_wave(a, pw)) return;
+  if (!setup_wave(a, tile, quad, pw)) return;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
+  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   float Cw[C];
 #pragma unroll
@@ -273,15 +493,20 @@ __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) 
   __shared__ uint32_t sid[WAVE];
   __shared__ float sacc[C][WAVE];
   __shared__ int scnt[WAVE];
-  for (uint32_t base = range.x; base < range.y; base += WAVE) {
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  ChunkWalker<true> walk(a, range.x, range.y - range.x);
+  for (; walk.valid(); walk.advance()) {
     if (__all(done)) break;
-    const uint32_t n = min((uint32_t)WAVE, range.y - base);
+    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+    const uint64_t km = __ballot(keep);
+    if (km == 0) continue;
+    const uint32_t n = (uint32_t)__popcll(km);
     __syncthreads();
-    if ((uint32_t)lane < n) {
-      const uint32_t id = a.point_list[base + lane];
-      sid[lane] = id;
-      s0[lane] = a.rec0[id];
-      s1[lane] = a.rec1[id];
+    if (keep) {
+      const uint32_t slot = (uint32_t)__popcll(km & lt_mask);
+      sid[slot] = walk.cur.id;
+      s0[slot] = walk.cur.r0;
+      s1[slot] = walk.cur.r1;
     }
 #pragma unroll
     for (int ch = 0; ch < C; ++ch) sacc[ch][lane] = 0.f;
@@ -293,19 +518,12 @@ __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) 
       const float4 co = s0[j];
       const float dx = g.x - pfx, dy = g.y - pfy;
       const float power = blend_power(co.x, co.y, co.z, dx, dy);
-      bool hit = !done && !(power > 0.0f);
-      float test_T = T;
-      if (hit) {
-        const float alpha = fminf(0.99f, co.w * gsr_expf(power));
-        hit = !(alpha < 1.0f / 255.0f);
-        if (hit) {
-          test_T = T * (1.0f - alpha);
-          if (test_T < 0.0001f) {
-            done = true;
-            hit = false;
-          }
-        }
-      }
+      const float alpha = fminf(0.99f, co.w * gsr_expf(power));
+      bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const float test_T = T * (1.0f - alpha);
+      const bool term = hit && (test_T < 0.0001f);
+      done = done || term;
+      hit = hit && !term;
       const uint64_t m = __ballot(hit);
       if (m == 0) continue;
       if (hit) T = test_T;
@@ -331,18 +549,48 @@ __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) 
   }
 }
 
+template <int C>
+__global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
+  run_work_queue(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C>(a, tile, quad); });
+}
+
+// Number of persistent single-wave workgroups: (SIMDs on the device) x (waves per SIMD).
+// GSR_BLEND_WAVES_PER_SIMD overrides the default (tuning knob; read once).
+unsigned blend_grid_size() {
+  static const unsigned n = [] {
+    int cus = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (cus <= 0) cus = 256;
+    int per_simd = 4;
+    if (const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD")) per_simd = atoi(e);
+    if (per_simd < 1) per_simd = 1;
+    if (per_simd > 8) per_simd = 8;
+    return (unsigned)cus * 4u * (unsigned)per_simd;
+  }();
+  return n;
+}
+static hipError_t reset_queue(hipStream_t s, const BlendArgs& a) {
+  return hipMemsetAsync(a.queue, 0, sizeof(uint32_t) * QUEUE_STRIDE * 8, s);
+}
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
-  const unsigned grid = blend_grid(a.gx, a.gy, &a.SX, &a.NS);
-  hipLaunchKernelGGL(blend_forward_kernel, dim3(grid), dim3(WAVE), 0, s, a);
+  hipError_t e = reset_queue(s, a);
+  if (e != hipSuccess) return e;
+  if (a.profile)
+    hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+  else
+    hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
-  const unsigned grid = blend_grid(a.gx, a.gy, &a.SX, &a.NS);
-  hipLaunchKernelGGL(blend_backward_kernel, dim3(grid), dim3(WAVE), 0, s, a);
+  hipError_t e = reset_queue(s, a);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(blend_backward_kernel, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
-  const unsigned grid = blend_grid(a.gx, a.gy, &a.SX, &a.NS);
+  hipError_t e = reset_queue(s, a);
+  if (e != hipSuccess) return e;
+  const unsigned grid = blend_grid_size();
   switch (a.C) {
     case 1: hipLaunchKernelGGL(trace_weights_kernel<1>, dim3(grid), dim3(WAVE), 0, s, a); break;
     case 2: hipLaunchKernelGGL(trace_weights_kernel<2>, dim3(grid), dim3(WAVE), 0, s, a); break;

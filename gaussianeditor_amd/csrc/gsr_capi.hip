@@ -20,13 +20,16 @@ inline int hip_fail(hipError_t e) {
     if (_e != hipSuccess) return hip_fail(_e); \
   } while (0)
 
-inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg) {
+inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
+                                 int queue_kind) {
   BlendArgs a;
   memset(&a, 0, sizeof(a));
   a.W = W;
   a.H = H;
   a.gx = (W + TILE - 1) / TILE;
   a.gy = (H + TILE - 1) / TILE;
+  a.work_order = im.work_order;
+  a.work_meta = im.work_meta;
   a.ranges = im.ranges;
   a.point_list = b.vals[b.final_buf];
   a.rec0 = g.rec0;
@@ -35,6 +38,7 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.bg = bg;
   a.final_T = im.final_T;
   a.n_contrib = im.n_contrib;
+  a.queue = im.queue_heads + (size_t)queue_kind * 8 * QUEUE_STRIDE;
   return a;
 }
 }  // namespace
@@ -127,41 +131,68 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
   const Image im = carve_image(image, W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
   a.out_color = out_color;
   a.out_depth = out_depth;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }
 
-int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
-                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii, const void* geom,
-                 const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
-                 float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscales, float* dL_drots) {
-  (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
-  if (P == 0) return GSR_OK;
-  if (P < 0 || R < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
-  if (!bg || !means3D || !viewmatrix || !projmatrix || !radii || !geom || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
-  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
-  if (shs && (!dL_dsh || !campos)) return GSR_ERR_BAD_ARGUMENT;
-  if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
-  if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
-  hipStream_t s = (hipStream_t)stream;
+int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                                    const void* binning, void* image, float* out_color, float* out_depth,
+                                    uint64_t* records, int64_t max_records, int64_t* n_records_host) {
+  if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
+  const int64_t n = (int64_t)blend_grid_size();
+  *n_records_host = n;
+  if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth) return GSR_ERR_BAD_ARGUMENT;
+  if (R > 0 && (!geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Image im = carve_image(image, W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
+  a.out_color = out_color;
+  a.out_depth = out_depth;
+  a.profile = records;
+  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 4 * (size_t)n, (hipStream_t)stream));
+  GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
+int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                       const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors) {
+  if (P == 0 || R == 0) return GSR_OK;
+  if (P < 0 || R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
+  if (!bg || !geom || !binning || !image || !dL_dpix || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors)
+    return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Image im = carve_image(const_cast<void*>(image), W, H);
-  if (R > 0) {
-    const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
-    BlendArgs a = make_blend_args(W, H, g, b, im, bg);
-    a.dL_dpix = dL_dpix;
-    a.dL_dmean2D = dL_dmeans2D;
-    a.dL_dconic = dL_dconic;
-    a.dL_dopacity = dL_dopacity;
-    a.dL_dcolors = dL_dcolors;
-    GSR_HIP(launch_blend_backward(s, a));
-  }
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
+  a.dL_dpix = dL_dpix;
+  a.dL_dmean2D = dL_dmeans2D;
+  a.dL_dconic = dL_dconic;
+  a.dL_dopacity = dL_dopacity;
+  a.dL_dcolors = dL_dcolors;
+  GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
+int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            float* dL_dscales, float* dL_drots) {
+  if (P == 0) return GSR_OK;
+  if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
+  if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
+  if (!dL_dmeans2D || !dL_dconic || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
+  if (shs && (!dL_dsh || !campos)) return GSR_ERR_BAD_ARGUMENT;
+  if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
   PreBwdArgs pa;
   pa.P = P; pa.D = D; pa.M = shs ? M : 0;
   pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.scales = scales; pa.rotations = rotations;
@@ -177,8 +208,26 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
   pa.dL_dsh = shs ? dL_dsh : nullptr;
   pa.dL_dscale = scales ? dL_dscales : nullptr;
   pa.dL_drot = scales ? dL_drots : nullptr;
-  GSR_HIP(launch_preprocess_backward(s, pa));
+  GSR_HIP(launch_preprocess_backward((hipStream_t)stream, pa));
   return GSR_OK;
+}
+
+int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii, const void* geom,
+                 const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
+                 float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                 float* dL_dscales, float* dL_drots) {
+  (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
+  if (P == 0) return GSR_OK;
+  if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
+  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, dL_dmeans2D, dL_dconic,
+                              dL_dopacity, dL_dcolors);
+  if (st != GSR_OK) return st;
+  return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
+                                 viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                 dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
 }
 
 int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -199,7 +248,7 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, nullptr);
+  BlendArgs a = make_blend_args(W, H, g, b, im, nullptr, 2);
   a.C = C;
   a.image_weights = image_weights;
   a.weights = weights;

@@ -53,7 +53,10 @@ struct PreBwdArgs {
 
 // K6 / K7 / K12 arguments (gsr_blend.hip)
 struct BlendArgs {
-  int W, H, gx, gy, SX, NS;
+  int W, H, gx, gy;
+  const uint32_t* work_order;  // tile ids, longest first, empty tiles last
+  const uint32_t* work_meta;   // [0] = number of non-empty tiles
+  uint32_t* queue;             // 8 per-XCD cursors of this launch, QUEUE_STRIDE words apart (zeroed before launch)
   const uint2* ranges;
   const uint32_t* point_list;
   const float4* rec0;
@@ -76,6 +79,8 @@ struct BlendArgs {
   const float* image_weights;
   float* weights;
   int32_t* cnt;
+  // debug: per-workgroup timing records (4 x u64 each), or null
+  uint64_t* profile;
 };
 
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a);
@@ -86,6 +91,7 @@ hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
                           const Binning& b, const Image& im);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
+unsigned blend_grid_size();
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a);
 

@@ -1,0 +1,107 @@
+"""Multi-view data parallelism for the rasterizer path (SURVEY.md section 8(e) -- new design;
+the reference is single-GPU and renders the views of a batch sequentially,
+threestudio/systems/GassuianEditor.py:165-207).
+
+One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI).  The Gaussian
+parameters are replicated; a batch of K views is sharded one view per rank; after the local
+backward the rasterizer-input gradients of all ranks are summed with ONE all-reduce over a
+single flat fp32 bucket, and the per-Gaussian screen radii are combined with one MAX
+all-reduce (the reference takes `torch.max` over the views, GassuianEditor.py:175-178).
+
+The bucket is filled without copies: the backward's gradient tensors are *allocated as views
+into the bucket* (see `_C.set_grad_allocator`), so the kernels write straight into the
+buffer RCCL reduces.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
+
+__all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step"]
+
+#: bucket layout per Gaussian: name -> number of floats (3M for the SH block is filled in at construction)
+_SLOTS = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
+
+
+class GradBucket:
+    """Flat fp32 buffer `[means3D 3P | sh 3MP | opacities P | scales 3P | rotations 4P | means2D 3P]`
+    = (14 + 3M) * P floats (248 MB at P = 1M, M = 16)."""
+
+    def __init__(self, P: int, M: int, device):
+        self.P, self.M = int(P), int(M)
+        shapes = {"means3D": (P, 3), "sh": (P, M, 3), "opacities": (P, 1), "scales": (P, 3), "rotations": (P, 4),
+                  "means2D": (P, 3)}
+        n = sum(int(torch.Size(s).numel()) for s in shapes.values())
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views: Dict[str, torch.Tensor] = {}
+        off = 0
+        for name in _SLOTS:
+            cnt = int(torch.Size(shapes[name]).numel())
+            # every segment starts on a 16-byte boundary as long as P % 4 == 0; otherwise the kernels'
+            # dwordx4 stores on (P,4) rows would be misaligned -> fall back to private tensors for those.
+            self.views[name] = self.flat[off:off + cnt].view(shapes[name])
+            off += cnt
+
+    def allocator(self, name: str, shape: Tuple[int, ...], zero: bool) -> Optional[torch.Tensor]:
+        v = self.views.get(name)
+        if v is None or tuple(v.shape) != tuple(shape) or v.data_ptr() % 16 != 0:
+            return None
+        if zero:
+            v.zero_()
+        return v
+
+    @contextlib.contextmanager
+    def capture(self):
+        """While active, the rasterizer backward writes its gradients into this bucket."""
+        _C.set_grad_allocator(self.allocator)
+        try:
+            yield self
+        finally:
+            _C.set_grad_allocator(None)
+
+    def grads(self) -> Dict[str, torch.Tensor]:
+        return dict(self.views)
+
+
+def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
+                      dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None):
+    """Forward + backward of ONE view through the drop-in L1 API with `dL_dcolor` as the
+    pixel gradient.  Returns (color, radii, depth, grads) where grads has the six
+    rasterizer-input gradients (views of `bucket` when one is given)."""
+    leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
+    m3, sh, op, sc, rot = leaves
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
+    ctx = bucket.capture() if bucket is not None else contextlib.nullcontext()
+    with ctx:
+        g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor])
+    names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
+    return color.detach(), radii, depth.detach(), dict(zip(names, g))
+
+
+def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = None, group=None, async_op: bool = False):
+    """The exchange step of an iteration: SUM over ranks of the flat gradient bucket, MAX over
+    ranks of the screen radii.  No-op in a single-process run."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return []
+    works = [dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)]
+    if radii is not None:
+        works.append(dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group, async_op=async_op))
+    return [w for w in works if w is not None]
+
+
+def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, torch.Tensor], dL_dcolor: torch.Tensor,
+                   bucket: GradBucket, group=None):
+    """One data-parallel iteration for this rank's view: forward, backward, gradient all-reduce.
+    `params`: xyz, opacity, features, scaling, rotation (activated, as the rasterizer consumes them).
+    After the call `bucket.views[...]` hold the batch-summed gradients on every rank and
+    `radii` the batch-max radii."""
+    color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
+                                                   params["scaling"], params["rotation"], dL_dcolor, bucket)
+    allreduce_view_grads(bucket, radii, group)
+    return color, radii, depth, grads

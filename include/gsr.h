@@ -115,6 +115,20 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots);
 
+/* The two halves of gsr_backward as separate entry points (same argument meaning), so a caller
+ * can time or overlap them: K7 = BACKWARD::render (backward.cu:399-557), K8+K9 = BACKWARD::preprocess
+ * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward. */
+int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                       const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors);
+int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            float* dL_dscales, float* dL_drots);
+
 /* K10: present[i] = (view-space z of point i) > 0.2.  Reference: checkFrustum,
  * rasterizer_impl.cu:53-63, 128-133.  `present` is one byte per Gaussian (torch.bool). */
 int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -139,6 +153,15 @@ int gsr_debug_export_binning(void* stream, int64_t R, int W, int H, const void* 
                              uint32_t* point_list);
 int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32_t* ranges, float* final_T,
                            uint32_t* n_contrib);
+
+/* Performance introspection (tools/wave_profile.py): run K6 with per-wave instrumentation.  One record
+ * of 4 x u64 per launched workgroup: {s_memtime at start, at end, XCC_ID<<32 | HW_ID,
+ * deepest list position<<32 | batches<<20 | tile range length}; records of workgroups that exit
+ * before doing any work stay zero.  *n_records_host = number of workgroups (call with max_records = 0
+ * to query; returns GSR_ERR_BAD_ARGUMENT in that case after setting it). */
+int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                                    const void* binning, void* image, float* out_color, float* out_depth,
+                                    uint64_t* records, int64_t max_records, int64_t* n_records_host);
 
 #ifdef __cplusplus
 }
