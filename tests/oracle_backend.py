@@ -1,0 +1,80 @@
+"""TEST INFRASTRUCTURE: a CPU stand-in for `diff_gaussian_rasterization._C` built on the oracle.
+
+It exists so that the host-side logic of the drop-in package (the L1 autograd wrapper, the
+`render()` mirror, the gradient bucket, the multi-view all-reduce) can be exercised on a machine
+without a GPU, and it is BASELINE config 1 ("10k random Gaussians, 256x256, CPU").  It is installed
+by monkeypatching inside tests only; the product never imports it.
+"""
+import itertools
+
+import numpy as np
+import torch
+
+from gaussianeditor_amd.diff_gaussian_rasterization import _C as real_C
+from oracle import cpu as O
+
+_registry = {}
+_ids = itertools.count(1)
+
+
+def _opt(t):
+    return None if t is None or t.numel() == 0 else t.detach().cpu()
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    H, W = int(image_height), int(image_width)
+    f = O.forward(means3D, _opt(scales), _opt(rotations), opacity, _opt(sh), _opt(colors), _opt(cov3D_precomp),
+                  viewmatrix, projmatrix, campos, background, W, H, tan_fovx, tan_fovy, scale_modifier, degree, prefiltered)
+    key = next(_ids)
+    _registry[key] = f
+    tag = torch.tensor([key], dtype=torch.int64).view(torch.uint8).clone()
+    z = torch.zeros(0, dtype=torch.uint8)
+    return (int(f["num_rendered"]), torch.from_numpy(f["color"]), torch.from_numpy(f["depth"]),
+            torch.from_numpy(f["radii"]), tag, z, z)
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+    f = _registry[int(geomBuffer.view(torch.int64)[0])]
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    g = O.backward(f, dL_dout_color, means3D, _opt(scales), _opt(rotations), _opt(sh), _opt(colors), _opt(cov3D_precomp),
+                   viewmatrix, projmatrix, campos, background, W, H, tan_fovx, tan_fovy, scale_modifier, degree)
+    P = means3D.size(0)
+    M = sh.size(1) if sh.size(0) != 0 else 0
+    out = []
+    for name, key, shape in (("means2D", "dL_dmeans2D", (P, 3)), ("colors_precomp", "dL_dcolors", (P, 3)),
+                             ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
+                             ("cov3Ds_precomp", "dL_dcov3D", (P, 6)), ("sh", "dL_dsh", (P, M, 3)),
+                             ("scales", "dL_dscales", (P, 3)), ("rotations", "dL_drotations", (P, 4))):
+        t = real_C._alloc(name, shape, False, means3D.device)  # honours the gradient-bucket allocator
+        t.copy_(torch.from_numpy(np.ascontiguousarray(g[key])).reshape(shape))
+        out.append(t)
+    return tuple(out)
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    return torch.from_numpy(O.mark_visible(means3D, viewmatrix, projmatrix))
+
+
+def apply_weights(background, means3D, weights, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                  projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
+                  image_weights, cnt, debug):
+    w = np.ascontiguousarray(weights.numpy())
+    c = np.ascontiguousarray(cnt.numpy().reshape(-1))
+    O.apply_weights(means3D, _opt(scales), _opt(rotations), opacity, _opt(cov3D_precomp), viewmatrix, projmatrix, campos,
+                    int(image_width), int(image_height), tan_fovx, tan_fovy, image_weights, w, c, scale_modifier)
+    weights.copy_(torch.from_numpy(w))
+    cnt.copy_(torch.from_numpy(c).reshape(cnt.shape))
+
+
+def install(monkeypatch):
+    """Route the drop-in's native calls to the oracle for the duration of one test."""
+    import gaussianeditor_amd.diff_gaussian_rasterization as dgr
+
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "apply_weights"):
+        monkeypatch.setattr(dgr._C, name, globals()[name])

@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the multi-view data-parallel step (one view per rank, one flat SUM
+all-reduce of the gradient bucket, MAX all-reduce of the radii) equals a single process rendering
+both views and summing.  The native library is replaced by the oracle stand-in on CPU."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import make_case, oracle_backward, oracle_forward, rel_err, seed_gradient, settings
+
+P, W, H = 1200, 64, 48
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytest as _pt
+
+    import oracle_backend
+    from gaussianeditor_amd.multiview import GradBucket, multiview_step
+
+    mpatch = _pt.MonkeyPatch()
+    oracle_backend.install(mpatch)
+    try:
+        case = make_case(P, W, H, seed=5, s0=0.07, view=rank, nviews=world)
+        sc = case["sc"]
+        bucket = GradBucket(P, 16, "cpu")
+        G = seed_gradient(H, W, 100 + rank) * H * W
+        params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+        color, radii, depth, grads = multiview_step(settings(case, "cpu"), params, G, bucket)
+        # the gradients are views of the flat bucket: no copies between the backward and the collective
+        assert grads["sh"].data_ptr() == bucket.views["sh"].data_ptr()
+        assert bucket.flat.numel() == P * (14 + 3 * 16)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=bucket.flat.numpy(), radii=radii.numpy())
+    finally:
+        mpatch.undo()
+        dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    # replicas hold identical reduced buffers
+    assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["radii"], r1["radii"])
+    # single-process reference: sum over the two views
+    tot, rad = None, None
+    for v in range(world):
+        case = make_case(P, W, H, seed=5, s0=0.07, view=v, nviews=world)
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
+        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales",
+                                                          "dL_drotations", "dL_dmeans2D")])
+        tot = flat if tot is None else tot + flat
+        rad = f["radii"] if rad is None else np.maximum(rad, f["radii"])
+    assert rel_err(r0["flat"], tot) < 1e-6
+    assert np.array_equal(r0["radii"], rad)
+
+
+def test_bucket_layout_and_allocator():
+    from gaussianeditor_amd.multiview import GradBucket
+
+    b = GradBucket(8, 16, "cpu")
+    assert [tuple(b.views[k].shape) for k in ("means3D", "sh", "opacities", "scales", "rotations", "means2D")] == \
+        [(8, 3), (8, 16, 3), (8, 1), (8, 3), (8, 4), (8, 3)]
+    b.flat.fill_(1.0)
+    v = b.allocator("means2D", (8, 3), True)
+    assert v is b.views["means2D"] and float(v.abs().sum()) == 0.0 and float(b.views["sh"].sum()) == 8 * 48
+    assert b.allocator("sh", (8, 4, 3), False) is None          # shape mismatch -> private tensor
+    assert b.allocator("colors_precomp", (8, 3), True) is None  # not a parameter gradient
+    # unaligned segments (P % 4 != 0) fall back to private tensors instead of misaligned dwordx4 stores
+    b2 = GradBucket(7, 16, "cpu")
+    assert b2.allocator("rotations", (7, 4), False) is None or b2.views["rotations"].data_ptr() % 16 == 0
