@@ -90,33 +90,44 @@ __device__ __forceinline__ V3 operator*(float s, V3 a) { return {s * a.x, s * a.
 __device__ __forceinline__ V3 operator*(V3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// Loads the SH coefficients of one Gaussian into registers.  M == 16 (the standard
-// 3DGS ply) is a 192-byte, 16-byte-aligned record: 12 dwordx4 loads.
-template <int MAXC>
-__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int ncoef, V3 (&sh)[MAXC]) {
-  const float* p = shs + idx * (size_t)M * 3;
-  if (M == 16 && MAXC == 16) {
-    const float4* q = reinterpret_cast<const float4*>(p);
-    float f[48];
+// Loads the SH coefficients of one Gaussian into registers.  M == 16 (the standard 3DGS ply) is a
+// 192-byte, 16-byte-aligned record read with dwordx4 loads.  All loads of a degree are issued
+// UNCONDITIONALLY back to back (the switch is on the wave-uniform active degree): a per-load guard
+// makes hipcc wait for each load before the next branch, i.e. one memory round trip per load.
+template <int NV>
+__device__ __forceinline__ void load_sh_vec(const float4* __restrict__ q, V3 (&sh)[16]) {
+  float f[48];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) {
-      // coefficients beyond the active degree are never read (uniform branch)
-      if (i * 4 < ncoef * 3) {
-        const float4 v = q[i];
-        f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
-      } else {
-        f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
-      }
+  for (int i = 0; i < 12; ++i) {
+    if (i < NV) {
+      const float4 v = q[i];
+      f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
+    } else {
+      f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
     }
+  }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sh[k] = {f[3 * k], f[3 * k + 1], f[3 * k + 2]};
+  for (int k = 0; k < 16; ++k) sh[k] = {f[3 * k], f[3 * k + 1], f[3 * k + 2]};
+}
+
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, int D, V3 (&sh)[16]) {
+  const float* p = shs + idx * (size_t)M * 3;
+  if (M == 16) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+    switch (D) {  // floats needed: 3 (D+1)^2 = 3, 12, 27, 48
+      case 0: load_sh_vec<1>(q, sh); break;
+      case 1: load_sh_vec<3>(q, sh); break;
+      case 2: load_sh_vec<7>(q, sh); break;
+      default: load_sh_vec<12>(q, sh); break;
+    }
   } else {
+    // generic record length: clamp the index instead of guarding the load (same reason)
+    const int ncoef = (D + 1) * (D + 1);
 #pragma unroll
-    for (int k = 0; k < MAXC; ++k) {
-      if (k < ncoef)
-        sh[k] = {p[3 * k], p[3 * k + 1], p[3 * k + 2]};
-      else
-        sh[k] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < 16; ++k) {
+      const int kk = k < ncoef ? k : ncoef - 1;
+      const V3 v = {p[3 * kk], p[3 * kk + 1], p[3 * kk + 2]};
+      sh[k] = k < ncoef ? v : V3{0.f, 0.f, 0.f};
     }
   }
 }
@@ -216,8 +227,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
           const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
           dir = {dir.x / len, dir.y / len, dir.z / len};
           V3 sh[16];
-          const int ncoef = (a.D + 1) * (a.D + 1);
-          load_sh<16>(a.shs, (size_t)idx, a.M, ncoef, sh);
+          load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
           V3 result = SH_C0 * sh[0];
           if (a.D > 0) {
             const float x = dir.x, y = dir.y, z = dir.z;
@@ -432,7 +442,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_backward_kernel(const 
       const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
       const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
       V3 sh[16];
-      load_sh<16>(a.shs, (size_t)idx, a.M, ncoef, sh);
+      load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
       const uint8_t cl = a.clamped[idx];
       V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
       dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
