@@ -49,24 +49,27 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
 }
 
 // ----------------------------------------------------------------------------------
-// K4 pass, kernel 1: per-block digit histogram.  hist is bin-major: hist[bin*nblocks+block].
+// K4: stable LSD radix sort, `BITS`-bit digits (8 or 9), SORT_KPB keys per block.
+// Pass = histogram -> per-bin scan -> scatter.  hist is bin-major: hist[bin*nblocks+block].
 // ----------------------------------------------------------------------------------
+template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t R, int shift,
                                                                 uint32_t* __restrict__ hist, uint32_t nblocks) {
-  __shared__ uint32_t h[SORT_BINS];
-  h[threadIdx.x] = 0;
+  constexpr int BINS = 1 << BITS;
+  __shared__ uint32_t h[BINS];
+  for (int i = threadIdx.x; i < BINS; i += SORT_THREADS) h[i] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
 #pragma unroll 4
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (k < R) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (SORT_BINS - 1)], 1u);
+    if (k < R) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (BINS - 1)], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  for (int i = threadIdx.x; i < BINS; i += SORT_THREADS) hist[(size_t)i * nblocks + blockIdx.x] = h[i];
 }
 
-// K4 pass, kernel 2: one block per bin; exclusive scan of that bin's nblocks counts in place.
+// One block per bin; exclusive scan of that bin's nblocks counts in place.
 __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_total,
                                                                 uint32_t nblocks) {
   __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
@@ -83,10 +86,14 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __res
   if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-// K4 pass, kernel 3: stable scatter.  Wave w of a block owns 1024 consecutive keys and
-// walks them 64 at a time in memory order; a key's rank among equal digits is
-// (count of that digit in earlier iterations of this wave) + (lower lanes with the same
-// digit in this iteration, from 8 ballots).
+// Stable scatter.  Wave w of a block owns 1024 consecutive keys and walks them 64 at a time in
+// memory order; a key's rank among equal digits of its wave is (count of that digit in earlier
+// iterations) + (lower lanes with the same digit in this iteration, from BITS ballots).  The
+// block's keys/values are then permuted into digit order IN LDS and written out with consecutive
+// threads covering consecutive sorted slots, so every digit's run is one contiguous global store
+// stream (a direct scatter issues 64 isolated 8-byte stores per instruction on the low-entropy-free
+// mantissa digits).
+template <int BITS>
 __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    uint64_t* __restrict__ keys_out,
@@ -94,36 +101,60 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
                                                                    const uint32_t* __restrict__ hist,
                                                                    const uint32_t* __restrict__ bin_total,
                                                                    uint32_t nblocks) {
+  constexpr int BINS = 1 << BITS;
   constexpr int NW = SORT_THREADS / 64;
-  __shared__ uint32_t cnt[NW][SORT_BINS];
+  constexpr int BPT = BINS / SORT_THREADS;  // bins handled per thread (1 or 2)
+  __shared__ uint32_t cnt[NW][BINS];        // per-wave digit counts -> per-wave local bases
+  __shared__ uint32_t gbase[BINS];          // global position of the block's first key of each digit
+  __shared__ uint32_t lexcl[BINS];          // position of each digit's run inside the block-sorted order
   __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
+  __shared__ uint64_t skey[SORT_KPB];
+  __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
 #pragma unroll
-  for (int i = 0; i < NW; ++i) cnt[i][threadIdx.x] = 0;
-  // global base of bin `threadIdx.x` for this block
-  uint32_t tot;
-  const uint32_t bin_base = block_excl_scan_u32<SORT_THREADS>(bin_total[threadIdx.x], &tot, smem);
-  const uint32_t my_base = bin_base + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+  for (int i = 0; i < NW; ++i)
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) cnt[i][threadIdx.x * BPT + b] = 0;
+  {
+    // global base of every bin: exclusive scan of bin_total over bins, plus this block's offset inside the bin
+    uint32_t t[BPT], tsum = 0;
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+      t[b] = bin_total[threadIdx.x * BPT + b];
+      tsum += t[b];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32<SORT_THREADS>(tsum, &tot, smem);
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+      const int bin = threadIdx.x * BPT + b;
+      gbase[bin] = run + hist[(size_t)bin * nblocks + blockIdx.x];
+      run += t[b];
+    }
+  }
   __syncthreads();
 
-  const int64_t wbase = (int64_t)blockIdx.x * SORT_KPB + (int64_t)w * (SORT_ITEMS * 64);
+  const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
+  const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
   uint64_t key[SORT_ITEMS];
+  uint32_t val[SORT_ITEMS];
   uint16_t rank[SORT_ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
-    const bool valid = k < R;
-    key[i] = valid ? keys_in[k] : ~0ull;
+    const int64_t kc = k < R ? k : R - 1;  // unconditional loads (clamped), validity handled below
+    key[i] = keys_in[kc];
+    val[i] = vals_in[kc];
   }
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const bool valid = k < R;
-    const uint32_t d = (uint32_t)(key[i] >> shift) & (SORT_BINS - 1);
+    const uint32_t d = (uint32_t)(key[i] >> shift) & (BINS - 1);
     uint64_t m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < SORT_RADIX_BITS; ++b) {
+    for (int b = 0; b < BITS; ++b) {
       const uint64_t bb = __ballot((d >> b) & 1u);
       m &= ((d >> b) & 1u) ? bb : ~bb;
     }
@@ -136,13 +167,27 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
   }
   __syncthreads();
   {
-    // exclusive prefix over the waves of this block for bin threadIdx.x, plus the global base
-    uint32_t run = my_base;
+    // per digit: block total, exclusive prefix over the waves, and the digit's offset in block-sorted order
+    uint32_t tsum = 0, tb[BPT];
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const uint32_t c = cnt[i][threadIdx.x];
-      cnt[i][threadIdx.x] = run;
-      run += c;
+    for (int b = 0; b < BPT; ++b) {
+      const int bin = threadIdx.x * BPT + b;
+      uint32_t run = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t c = cnt[i][bin];
+        cnt[i][bin] = run;
+        run += c;
+      }
+      tb[b] = run;
+      tsum += run;
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32<SORT_THREADS>(tsum, &tot, smem);
+#pragma unroll
+    for (int b = 0; b < BPT; ++b) {
+      lexcl[threadIdx.x * BPT + b] = run;
+      run += tb[b];
     }
   }
   __syncthreads();
@@ -150,10 +195,23 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     if (k < R) {
-      const uint32_t d = (uint32_t)(key[i] >> shift) & (SORT_BINS - 1);
-      const uint32_t pos = cnt[w][d] + rank[i];
-      keys_out[pos] = key[i];
-      vals_out[pos] = vals_in[k];
+      const uint32_t d = (uint32_t)(key[i] >> shift) & (BINS - 1);
+      const uint32_t lp = lexcl[d] + cnt[w][d] + rank[i];
+      skey[lp] = key[i];
+      sval[lp] = val[i];
+    }
+  }
+  __syncthreads();
+  const int nvalid = (int)min((int64_t)SORT_KPB, R - bbase);
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int j = i * SORT_THREADS + (int)threadIdx.x;
+    if (j < nvalid) {
+      const uint64_t kk = skey[j];
+      const uint32_t d = (uint32_t)(kk >> shift) & (BINS - 1);
+      const uint32_t pos = gbase[d] + ((uint32_t)j - lexcl[d]);
+      keys_out[pos] = kk;
+      vals_out[pos] = sval[j];
     }
   }
 }
@@ -228,12 +286,20 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
   hipLaunchKernelGGL(emit_keys_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, b.keys[0], b.vals[0]);
   int cur = 0;
   for (int p = 0; p < b.passes; ++p) {
-    const int shift = p * SORT_RADIX_BITS;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], R, shift, b.hist,
-                       b.nblocks);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(SORT_BINS), dim3(SORT_THREADS), 0, s, b.hist, b.bin_total, b.nblocks);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], b.vals[cur],
-                       b.keys[cur ^ 1], b.vals[cur ^ 1], R, shift, b.hist, b.bin_total, b.nblocks);
+    const int shift = p * b.digit_bits;
+    if (b.digit_bits == 9) {
+      hipLaunchKernelGGL(sort_hist_kernel<9>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], R, shift, b.hist,
+                         b.nblocks);
+      hipLaunchKernelGGL(sort_scan_kernel, dim3(512), dim3(SORT_THREADS), 0, s, b.hist, b.bin_total, b.nblocks);
+      hipLaunchKernelGGL(sort_scatter_kernel<9>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], b.vals[cur],
+                         b.keys[cur ^ 1], b.vals[cur ^ 1], R, shift, b.hist, b.bin_total, b.nblocks);
+    } else {
+      hipLaunchKernelGGL(sort_hist_kernel<8>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], R, shift, b.hist,
+                         b.nblocks);
+      hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SORT_THREADS), 0, s, b.hist, b.bin_total, b.nblocks);
+      hipLaunchKernelGGL(sort_scatter_kernel<8>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], b.vals[cur],
+                         b.keys[cur ^ 1], b.vals[cur ^ 1], R, shift, b.hist, b.bin_total, b.nblocks);
+    }
     cur ^= 1;
   }
   const int64_t nbr = (R + 255) / 256;

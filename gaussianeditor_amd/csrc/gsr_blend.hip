@@ -315,24 +315,46 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ----------------------------------------------------------------------------------
 // K7: renderCUDA (backward), DGR/cuda_rasterizer/backward.cu:399-557.
 // ----------------------------------------------------------------------------------
-__device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
+// Wave-level ordering of LDS traffic inside a multi-wave workgroup: a wave runs in lockstep, so all
+// that is needed is that the compiler keeps program order and waits for the LDS queue.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile
+
+// One tile, processed by a 4-wave workgroup (wave w = quadrant w).  The four waves walk the tile's list
+// back to front in the SAME 64-entry chunks; each wave culls / compacts / evaluates the chunk for its own
+// 64 pixels exactly as before, but the wave totals of the nine gradient terms are summed over the four
+// quadrants in LDS (ds_add_f32), and only then does one global atomic per (tile, instance, term) leave
+// the CU.  The global float atomics execute at the memory side on this chip and were the largest single
+// cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
+// 2-3 of a tile's 4 quadrants.
+template <int ABLATE>  // 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
+__device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
+                                              float4 (*s2)[WAVE], uint32_t* sid, float (*sacc)[WAVE], uint32_t* s_maxc) {
+  const int w = (int)(threadIdx.x >> 6), lane = lane_id();
   PixelWave pw;
-  if (!setup_wave(a, tile, quad, pw)) return;
-  const int lane = lane_id();
-  const uint2 range = a.ranges[pw.tile];
-  if (range.y <= range.x) return;
+  const bool has_pixels = setup_wave(a, tile, (uint32_t)w, pw);
+  const uint2 range = a.ranges[tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
   const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
+  const bool live = has_pixels && pw.inside;
 
-  const float T_final = pw.inside ? a.final_T[pix] : 0.f;
+  const float T_final = live ? a.final_T[pix] : 0.f;
   float T = T_final;
-  const uint32_t last_contributor = pw.inside ? a.n_contrib[pix] : 0u;
+  const uint32_t last_contributor = live ? a.n_contrib[pix] : 0u;
   const uint32_t maxc = wave_max_u32(last_contributor);
-  if (maxc == 0) return;
+  if (lane == 0) s_maxc[w] = maxc;
+  __syncthreads();
+  const uint32_t tile_max = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
+  __syncthreads();
+  if (tile_max == 0) return;  // uniform over the workgroup
 
   float dpx[3] = {0.f, 0.f, 0.f};
-  if (pw.inside) {
+  if (live) {
     dpx[0] = a.dL_dpix[pix];
     dpx[1] = a.dL_dpix[HW + pix];
     dpx[2] = a.dL_dpix[2 * HW + pix];
@@ -344,36 +366,32 @@ __device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile,
 
   float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f};
   float last_alpha = 0.f;
-
-  __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
-  __shared__ uint32_t sid[WAVE];
-  __shared__ float sacc[9][WAVE];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
-  // back to front over positions [0, maxc) of the tile's list
-  ChunkWalker<false> walk(a, range.x, maxc);
+  // back to front over positions [0, tile_max) of the tile's list, all four waves in the same chunks
+  ChunkWalker<false> walk(a, range.x, tile_max);
   for (; walk.valid(); walk.advance()) {
-    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+    __syncthreads();  // (A) the previous chunk's flush is complete: sacc is zero again, sid is free
+    const uint32_t csize = walk.chunk_size();
+    if (w == 0 && (uint32_t)lane < csize) sid[lane] = walk.cur.id;
+    const uint32_t pos = walk.lane_pos();
+    const bool keep = ((uint32_t)lane < csize) && (pos < maxc) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
     const uint64_t m = __ballot(keep);
-    if (m == 0) continue;
     const uint32_t cnt = (uint32_t)__popcll(m);
     const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
-    __syncthreads();
     if (keep) {
       const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
-      sid[slot] = walk.cur.id;
-      s0[slot] = walk.cur.r0;
-      s1[slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(walk.lane_pos()));
-      s2[slot] = walk.cur.r2;
+      s0[w][slot] = walk.cur.r0;
+      s1[w][slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(pos));
+      // .w carries the entry's index inside the chunk (= the lane that holds it): the LDS accumulator slot
+      s2[w][slot] = make_float4(walk.cur.r2.x, walk.cur.r2.y, walk.cur.r2.z, __uint_as_float((uint32_t)lane));
     }
     if ((uint32_t)lane >= cnt && (uint32_t)lane < cnt4) {
-      s0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: alpha 0 => never contributes
-      s1[lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
-      s2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+      s0[w][lane] = make_float4(0.f, 0.f, 0.f, 0.f);  // null entry: alpha 0 => never contributes
+      s1[w][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0xffffffffu));
+      s2[w][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) sacc[k][lane] = 0.f;
-    __syncthreads();
+    wave_lds_sync();
 
     for (uint32_t j = 0; j < cnt4; j += GROUP) {
       float G[GROUP], al[GROUP], dxs[GROUP], dys[GROUP];
@@ -382,9 +400,9 @@ __device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile,
       bool any = false;
 #pragma unroll
       for (int u = 0; u < GROUP; ++u) {
-        const float4 g = s1[j + u];
-        cos_[u] = s0[j + u];
-        cols[u] = s2[j + u];
+        const float4 g = s1[w][j + u];
+        cos_[u] = s0[w][j + u];
+        cols[u] = s2[w][j + u];
         const uint32_t c = __float_as_uint(g.w);  // 0-based position of this instance in the tile list
         dxs[u] = g.x - pfx;
         dys[u] = g.y - pfy;
@@ -395,18 +413,19 @@ __device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile,
         any = any || contrib[u];
       }
       if (!__any(any)) continue;  // wave-uniform
+      if (ABLATE == 4) continue;  // experiment: footprint + exp only
 
       float v[9][GROUP];
 #pragma unroll
       for (int u = 0; u < GROUP; ++u) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) v[k][u] = 0.f;
+        // Only the per-pixel recurrences run under the lane mask; they hand three scalars (zero for
+        // lanes that do not contribute) to the straight-line code that forms the nine terms, so no
+        // term needs a zero-initialising move or a select.
+        float mG = 0.f, mA = 0.f, mD = 0.f;
         if (contrib[u]) {
-          const float4 co = cos_[u];
-          const float alpha = al[u], dx = dxs[u], dy = dys[u];
+          const float alpha = al[u];
           const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
           T = T * inv_one_m;  // T / (1 - alpha), backward.cu:503
-          const float dchannel_dcolor = alpha * T;
           float dL_dalpha = 0.0f;
           const float cc[3] = {cols[u].x, cols[u].y, cols[u].z};
 #pragma unroll
@@ -414,57 +433,93 @@ __device__ __forceinline__ void backward_item(const BlendArgs& a, uint32_t tile,
             accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
             last_color[ch] = cc[ch];
             dL_dalpha += (cc[ch] - accum_rec[ch]) * dpx[ch];
-            v[6 + ch][u] = dchannel_dcolor * dpx[ch];
           }
           dL_dalpha *= T;
           last_alpha = alpha;
           dL_dalpha += (-T_final * inv_one_m) * bg_dot_dpixel;
-          const float dL_dG = co.w * dL_dalpha;
-          const float gdx = G[u] * dx, gdy = G[u] * dy;
-          const float dG_ddelx = -gdx * co.x - gdy * co.y;
-          const float dG_ddely = -gdy * co.z - gdx * co.y;
-          v[0][u] = dL_dG * dG_ddelx * ddelx_dx;
-          v[1][u] = dL_dG * dG_ddely * ddely_dy;
-          v[2][u] = -0.5f * gdx * dx * dL_dG;
-          v[3][u] = -0.5f * gdx * dy * dL_dG;
-          v[4][u] = -0.5f * gdy * dy * dL_dG;
-          v[5][u] = G[u] * dL_dalpha;
+          mG = G[u];
+          mA = dL_dalpha;
+          mD = alpha * T;  // dchannel_dcolor
         }
+        const float4 co = cos_[u];
+        const float dx = dxs[u], dy = dys[u];
+        const float dL_dG = co.w * mA;
+        const float gdx = mG * dx, gdy = mG * dy;
+        const float dG_ddelx = -gdx * co.x - gdy * co.y;
+        const float dG_ddely = -gdy * co.z - gdx * co.y;
+        v[0][u] = dL_dG * dG_ddelx * ddelx_dx;
+        v[1][u] = dL_dG * dG_ddely * ddely_dy;
+        v[2][u] = -0.5f * gdx * dx * dL_dG;
+        v[3][u] = -0.5f * gdx * dy * dL_dG;
+        v[4][u] = -0.5f * gdy * dy * dL_dG;
+        v[5][u] = mG * mA;
+        v[6][u] = mD * dpx[0];
+        v[7][u] = mD * dpx[1];
+        v[8][u] = mD * dpx[2];
       }
-      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave total of entry j + r
+      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave total of entry j + r,
+      // which that lane adds to the tile-level accumulator of the entry's chunk slot.
+      const uint32_t my_slot = __float_as_uint(cols[0].w) * (uint32_t)((lane >> 4) == 0) +
+                               __float_as_uint(cols[1].w) * (uint32_t)((lane >> 4) == 1) +
+                               __float_as_uint(cols[2].w) * (uint32_t)((lane >> 4) == 2) +
+                               __float_as_uint(cols[3].w) * (uint32_t)((lane >> 4) == 3);
 #pragma unroll
       for (int k = 0; k < 9; ++k) {
-        const float tot = wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
-        if ((lane & 15) == 15) sacc[k][j + (uint32_t)(lane >> 4)] = tot;
+        const float tot = (ABLATE == 1 || ABLATE == 3) ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3])  // experiment: no reduction
+                                                       : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
+        if ((lane & 15) == 15 && tot != 0.f) atomicAdd(&sacc[k][my_slot], tot);  // ds_add_f32
       }
     }
-    __syncthreads();
-    if ((uint32_t)lane < cnt) {
-      float r[9];
-      bool any = false;
+    __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc
+    {
+      // flush: thread (w, lane) owns chunk slot `lane` for terms w, w+4, w+8
+      const uint32_t p = (uint32_t)lane;
+      if (p < csize) {
+        const size_t id = sid[p];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        r[k] = sacc[k][lane];
-        any |= (r[k] != 0.f);
-      }
-      if (any) {
-        const size_t id = sid[lane];
-        unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 0], r[0]);
-        unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 1], r[1]);
-        unsafeAtomicAdd(&a.dL_dconic[4 * id + 0], r[2]);
-        unsafeAtomicAdd(&a.dL_dconic[4 * id + 1], r[3]);
-        unsafeAtomicAdd(&a.dL_dconic[4 * id + 3], r[4]);
-        unsafeAtomicAdd(&a.dL_dopacity[id], r[5]);
-        unsafeAtomicAdd(&a.dL_dcolors[3 * id + 0], r[6]);
-        unsafeAtomicAdd(&a.dL_dcolors[3 * id + 1], r[7]);
-        unsafeAtomicAdd(&a.dL_dcolors[3 * id + 2], r[8]);
+        for (int kk = 0; kk < 3; ++kk) {
+          const int k = w + BWD_WAVES * kk;
+          if (k < 9) {
+            const float r = sacc[k][p];
+            if (r != 0.f) {
+              sacc[k][p] = 0.f;
+              if (ABLATE != 2 && ABLATE != 3) {
+                float* dst = k < 2   ? &a.dL_dmean2D[3 * id + k]
+                             : k < 4 ? &a.dL_dconic[4 * id + (k - 2)]
+                             : k == 4 ? &a.dL_dconic[4 * id + 3]
+                             : k == 5 ? &a.dL_dopacity[id]
+                                      : &a.dL_dcolors[3 * id + (k - 6)];
+                unsafeAtomicAdd(dst, r);
+              }
+            }
+          }
+        }
       }
     }
   }
 }
 
-__global__ void __launch_bounds__(WAVE) blend_backward_kernel(const BlendArgs a) {
-  run_work_queue(a, false, [&](uint32_t tile, uint32_t quad, bool) { backward_item(a, tile, quad); });
+template <int ABLATE>
+__global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const BlendArgs a) {
+  __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
+  __shared__ uint32_t sid[WAVE];
+  __shared__ float sacc[9][WAVE];
+  __shared__ uint32_t s_maxc[BWD_WAVES];
+  __shared__ uint32_t s_item;
+  for (int i = threadIdx.x; i < 9 * WAVE; i += WAVE * BWD_WAVES) (&sacc[0][0])[i] = 0.f;
+  // tile-granular queue: queue x (one per XCD) owns the non-empty tiles x, x+8, ... of work_order
+  const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID
+  const uint32_t nwork = a.work_meta[0];
+  const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
+  uint32_t* head = a.queue + x * QUEUE_STRIDE;
+  for (;;) {
+    if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t q = s_item;
+    __syncthreads();
+    if (q >= n_x) break;
+    backward_tile<ABLATE>(a, a.work_order[x + 8u * q], s0, s1, s2, sid, sacc, s_maxc);
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -584,7 +639,17 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   hipError_t e = reset_queue(s, a);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(blend_backward_kernel, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+  // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
+  static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
+  // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
+  const dim3 g(blend_grid_size() / BWD_WAVES), b(WAVE * BWD_WAVES);
+  switch (ablate) {
+    case 1: hipLaunchKernelGGL(blend_backward_kernel<1>, g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(blend_backward_kernel<2>, g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(blend_backward_kernel<3>, g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL(blend_backward_kernel<4>, g, b, 0, s, a); break;
+    default: hipLaunchKernelGGL(blend_backward_kernel<0>, g, b, 0, s, a); break;
+  }
   return hipGetLastError();
 }
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {

@@ -91,17 +91,17 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
 constexpr int SORT_THREADS = 256;
 constexpr int SORT_ITEMS = 16;                          // keys per thread
 constexpr int SORT_KPB = SORT_THREADS * SORT_ITEMS;     // keys per block (4096)
-constexpr int SORT_RADIX_BITS = 8;
-constexpr int SORT_BINS = 1 << SORT_RADIX_BITS;
+constexpr int SORT_MAX_BINS = 512;                      // 9-bit digits at most
 
 // Per-instance state ("binningBuffer"): ping-pong key/value arrays + histograms.
 struct Binning {
   uint64_t* keys[2];
   uint32_t* vals[2];
-  uint32_t* hist;       // (SORT_BINS * nblocks)
-  uint32_t* bin_total;  // (SORT_BINS)
+  uint32_t* hist;       // (bins * nblocks), bin-major
+  uint32_t* bin_total;  // (bins)
   uint32_t nblocks;
-  int passes;           // ceil(key_bits / 8)
+  int passes;           // ceil(key_bits / 9)
+  int digit_bits;       // ceil(key_bits / passes): 8 or 9 (45-bit keys @1080p: 5 passes of 9 bits)
   int final_buf;        // which ping-pong side holds the sorted result (= passes & 1)
   size_t bytes;
 };
@@ -122,13 +122,16 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, i
   char* p = (char*)base;
   Binning b;
   b.nblocks = (uint32_t)((R + SORT_KPB - 1) / SORT_KPB);
-  b.passes = (sort_key_bits(W, H) + SORT_RADIX_BITS - 1) / SORT_RADIX_BITS;
+  const int bits = sort_key_bits(W, H);
+  b.passes = (bits + 8) / 9;
+  b.digit_bits = (bits + b.passes - 1) / b.passes;
+  if (b.digit_bits < 8) b.digit_bits = 8;
   b.final_buf = b.passes & 1;
   size_t off = 0;
   for (int i = 0; i < 2; ++i) { b.keys[i] = (uint64_t*)(p + off); off += align_up(sizeof(uint64_t) * (size_t)R); }
   for (int i = 0; i < 2; ++i) { b.vals[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)R); }
-  b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_BINS * (size_t)b.nblocks);
-  b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_BINS);
+  b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_MAX_BINS * (size_t)b.nblocks);
+  b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_MAX_BINS);
   b.bytes = R > 0 ? off : 0;
   return b;
 }
