@@ -1,11 +1,23 @@
-// gsr_binning.hip -- K3 (emit keys), K4 (stable LSD radix sort of 64-bit keys with 32-bit
-// values), K5 (tile ranges).
+// gsr_binning.hip -- K3 (emit), K4 (sort), K5 (tile ranges) and the blend work list.
 //
-// K4 replaces cub::DeviceRadixSort::SortPairs (rasterizer_impl.cu:256-261).  Every pass is
-// three kernels (histogram -> per-bin scan -> scatter); there is no decoupled look-back,
-// so no inter-workgroup hand-off inside a launch (per-XCD L2s are not coherent; a kernel
-// boundary is the cheapest correct fence, ~1.5 us each).  Stability comes from ranking
-// with wave64 ballots in key order, never from atomics.
+// The reference builds one 64-bit key (tile | depth bits) per (Gaussian, tile) instance and runs a
+// stable radix sort over all R instances on 32 + getHigherMsb(T) key bits (rasterizer_impl.cu:67-100,
+// 253-261: 45 bits at 1080p).  Every instance of a Gaussian carries the SAME depth, so the identical
+// order is obtained far cheaper as two stable sorts (a stable sort by the minor key followed by a stable
+// sort by the major key):
+//
+//   1. stable LSD radix sort of the P Gaussians by their 32 depth bits (value = index, culled ones
+//      last).  P is ~5x smaller than R, and it runs inside gsr_preprocess, i.e. under the host's
+//      blocking readback of num_rendered (launch_depth_order);
+//   2. instances are emitted in that Gaussian order, so the instance array is already depth-ordered,
+//      ties in emission order = ascending Gaussian index exactly like the reference's;
+//   3. stable LSD radix sort of the R instances by tile id only: 13 bits at 1080p = 2 passes over
+//      8-byte (tile, index) pairs instead of 6 passes over 12-byte pairs.
+//
+// A radix pass is three kernels (histogram -> per-bin scan -> scatter); there is no decoupled
+// look-back, so no inter-workgroup hand-off inside a launch (per-XCD L2s are not coherent; a kernel
+// boundary is the cheapest correct fence).  Stability comes from ranking with wave64 ballots in key
+// order, never from atomics.
 #include "gsr_kernels.h"
 
 namespace gsr {
@@ -18,55 +30,27 @@ __device__ __forceinline__ int f2i_sat(float v) {
 }
 
 // ----------------------------------------------------------------------------------
-// K3: duplicateWithKeys, rasterizer_impl.cu:67-100.  The per-Gaussian write offset is
-// block_offs[block] + (exclusive scan of tiles_touched inside the block).
+// Stable LSD radix sort pass on 32-bit keys with 32-bit values, 8-bit digits (256 bins; a pass may
+// use fewer significant bits through `mask`), SORT_KPB keys per block.
+// hist is bin-major: hist[bin*nblocks+block].  IOTA: the input values are the element indices.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
-                                                               const Geom g, uint64_t* __restrict__ keys,
-                                                               uint32_t* __restrict__ vals) {
-  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
-  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  const uint32_t n = idx < P ? g.tiles[idx] : 0u;
-  uint32_t total;
-  uint32_t off = g.block_offs[blockIdx.x] + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
-  if (n == 0) return;
-  const float4 r1 = g.rec1[idx];
-  const int radius = radii[idx];
-  const float r = (float)radius;
-  // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle)
-  const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
-  const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
-  const uint32_t maxx = (uint32_t)min(gx, max(0, f2i_sat((r1.x + r + (float)TILE - 1.0f) / (float)TILE)));
-  const uint32_t maxy = (uint32_t)min(gy, max(0, f2i_sat((r1.y + r + (float)TILE - 1.0f) / (float)TILE)));
-  const uint64_t dbits = (uint64_t)__float_as_uint(r1.z);
-  for (uint32_t y = miny; y < maxy; y++)
-    for (uint32_t x = minx; x < maxx; x++) {
-      const uint64_t key = ((uint64_t)(y * (uint32_t)gx + x) << 32) | dbits;
-      keys[off] = key;
-      vals[off] = (uint32_t)idx;
-      off++;
-    }
-}
+constexpr int RBITS = 8;
+constexpr int RBINS = 1 << RBITS;
 
-// ----------------------------------------------------------------------------------
-// K4: stable LSD radix sort, `BITS`-bit digits (8 or 9), SORT_KPB keys per block.
-// Pass = histogram -> per-bin scan -> scatter.  hist is bin-major: hist[bin*nblocks+block].
-// ----------------------------------------------------------------------------------
-template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint64_t* __restrict__ keys, int64_t R, int shift,
-                                                                uint32_t* __restrict__ hist, uint32_t nblocks) {
-  constexpr int BINS = 1 << BITS;
-  __shared__ uint32_t h[BINS];
-  for (int i = threadIdx.x; i < BINS; i += SORT_THREADS) h[i] = 0;
+__global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+                                                                uint32_t mask, uint32_t* __restrict__ hist,
+                                                                uint32_t nblocks) {
+  __shared__ uint32_t h[RBINS];
+  h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
 #pragma unroll 4
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (k < R) atomicAdd(&h[(uint32_t)(keys[k] >> shift) & (BINS - 1)], 1u);
+    if (k < n) atomicAdd(&h[(keys[k] >> shift) & mask], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < BINS; i += SORT_THREADS) hist[(size_t)i * nblocks + blockIdx.x] = h[i];
+  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // One block per bin; exclusive scan of that bin's nblocks counts in place.
@@ -86,75 +70,56 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __res
   if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
 }
 
-// Stable scatter.  Wave w of a block owns 1024 consecutive keys and walks them 64 at a time in
-// memory order; a key's rank among equal digits of its wave is (count of that digit in earlier
-// iterations) + (lower lanes with the same digit in this iteration, from BITS ballots).  The
-// block's keys/values are then permuted into digit order IN LDS and written out with consecutive
-// threads covering consecutive sorted slots, so every digit's run is one contiguous global store
-// stream (a direct scatter issues 64 isolated 8-byte stores per instruction on the low-entropy-free
-// mantissa digits).
-template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64_t* __restrict__ keys_in,
+// Stable scatter.  Wave w of a block owns 1024 consecutive keys and walks them 64 at a time in memory
+// order; a key's rank among equal digits of its wave is (count of that digit in earlier iterations) +
+// (lower lanes with the same digit in this iteration, from 8 ballots).  The block's pairs are then
+// permuted into digit order IN LDS and written out with consecutive threads covering consecutive
+// sorted slots, so every digit's run is one contiguous global store stream.
+template <bool IOTA>
+__global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
-                                                                   uint64_t* __restrict__ keys_out,
-                                                                   uint32_t* __restrict__ vals_out, int64_t R, int shift,
-                                                                   const uint32_t* __restrict__ hist,
+                                                                   uint32_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out, int64_t n, int shift,
+                                                                   uint32_t mask, const uint32_t* __restrict__ hist,
                                                                    const uint32_t* __restrict__ bin_total,
                                                                    uint32_t nblocks) {
-  constexpr int BINS = 1 << BITS;
   constexpr int NW = SORT_THREADS / 64;
-  constexpr int BPT = BINS / SORT_THREADS;  // bins handled per thread (1 or 2)
-  __shared__ uint32_t cnt[NW][BINS];        // per-wave digit counts -> per-wave local bases
-  __shared__ uint32_t gbase[BINS];          // global position of the block's first key of each digit
-  __shared__ uint32_t lexcl[BINS];          // position of each digit's run inside the block-sorted order
+  __shared__ uint32_t cnt[NW][RBINS];   // per-wave digit counts -> per-wave local bases
+  __shared__ uint32_t gbase[RBINS];     // global position of the block's first key of each digit
+  __shared__ uint32_t lexcl[RBINS];     // position of each digit's run inside the block-sorted order
   __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
-  __shared__ uint64_t skey[SORT_KPB];
+  __shared__ uint32_t skey[SORT_KPB];
   __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
 #pragma unroll
-  for (int i = 0; i < NW; ++i)
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) cnt[i][threadIdx.x * BPT + b] = 0;
+  for (int i = 0; i < NW; ++i) cnt[i][threadIdx.x] = 0;
   {
-    // global base of every bin: exclusive scan of bin_total over bins, plus this block's offset inside the bin
-    uint32_t t[BPT], tsum = 0;
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) {
-      t[b] = bin_total[threadIdx.x * BPT + b];
-      tsum += t[b];
-    }
     uint32_t tot;
-    uint32_t run = block_excl_scan_u32<SORT_THREADS>(tsum, &tot, smem);
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) {
-      const int bin = threadIdx.x * BPT + b;
-      gbase[bin] = run + hist[(size_t)bin * nblocks + blockIdx.x];
-      run += t[b];
-    }
+    const uint32_t run = block_excl_scan_u32<SORT_THREADS>(bin_total[threadIdx.x], &tot, smem);
+    gbase[threadIdx.x] = run + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
   }
   __syncthreads();
 
   const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
   const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
-  uint64_t key[SORT_ITEMS];
-  uint32_t val[SORT_ITEMS];
+  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
   uint16_t rank[SORT_ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
-    const int64_t kc = k < R ? k : R - 1;  // unconditional loads (clamped), validity handled below
+    const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
     key[i] = keys_in[kc];
-    val[i] = vals_in[kc];
+    val[i] = IOTA ? (uint32_t)kc : vals_in[kc];
   }
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
-    const bool valid = k < R;
-    const uint32_t d = (uint32_t)(key[i] >> shift) & (BINS - 1);
+    const bool valid = k < n;
+    const uint32_t d = (key[i] >> shift) & mask;
     uint64_t m = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < BITS; ++b) {
+    for (int b = 0; b < RBITS; ++b) {
       const uint64_t bb = __ballot((d >> b) & 1u);
       m &= ((d >> b) & 1u) ? bb : ~bb;
     }
@@ -168,47 +133,35 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
   __syncthreads();
   {
     // per digit: block total, exclusive prefix over the waves, and the digit's offset in block-sorted order
-    uint32_t tsum = 0, tb[BPT];
+    uint32_t run = 0;
 #pragma unroll
-    for (int b = 0; b < BPT; ++b) {
-      const int bin = threadIdx.x * BPT + b;
-      uint32_t run = 0;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t c = cnt[i][bin];
-        cnt[i][bin] = run;
-        run += c;
-      }
-      tb[b] = run;
-      tsum += run;
+    for (int i = 0; i < NW; ++i) {
+      const uint32_t c = cnt[i][threadIdx.x];
+      cnt[i][threadIdx.x] = run;
+      run += c;
     }
     uint32_t tot;
-    uint32_t run = block_excl_scan_u32<SORT_THREADS>(tsum, &tot, smem);
-#pragma unroll
-    for (int b = 0; b < BPT; ++b) {
-      lexcl[threadIdx.x * BPT + b] = run;
-      run += tb[b];
-    }
+    lexcl[threadIdx.x] = block_excl_scan_u32<SORT_THREADS>(run, &tot, smem);
   }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
-    if (k < R) {
-      const uint32_t d = (uint32_t)(key[i] >> shift) & (BINS - 1);
+    if (k < n) {
+      const uint32_t d = (key[i] >> shift) & mask;
       const uint32_t lp = lexcl[d] + cnt[w][d] + rank[i];
       skey[lp] = key[i];
       sval[lp] = val[i];
     }
   }
   __syncthreads();
-  const int nvalid = (int)min((int64_t)SORT_KPB, R - bbase);
+  const int nvalid = (int)min((int64_t)SORT_KPB, n - bbase);
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int j = i * SORT_THREADS + (int)threadIdx.x;
     if (j < nvalid) {
-      const uint64_t kk = skey[j];
-      const uint32_t d = (uint32_t)(kk >> shift) & (BINS - 1);
+      const uint32_t kk = skey[j];
+      const uint32_t d = (kk >> shift) & mask;
       const uint32_t pos = gbase[d] + ((uint32_t)j - lexcl[d]);
       keys_out[pos] = kk;
       vals_out[pos] = sval[j];
@@ -216,18 +169,106 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint64
   }
 }
 
+// Sorts (keys[0], vals[0]) by key bits [0, sum(digits)); result in buffer (npass & 1).
+static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
+                             const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first) {
+  const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
+  int cur = 0, shift = 0;
+  for (int p = 0; p < npass; ++p) {
+    const uint32_t mask = (1u << digit_bits[p]) - 1u;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
+    if (p == 0 && iota_first)
+      hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
+                         keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+    else
+      hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
+                         keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+    shift += digit_bits[p];
+    cur ^= 1;
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Depth order of the Gaussians + prefix of tiles_touched in that order.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, const uint32_t* __restrict__ order,
+                                                                       const uint32_t* __restrict__ tiles,
+                                                                       uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  const uint32_t n = i < P ? tiles[order[i]] : 0u;
+  uint32_t total;
+  (void)block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) scan_blocks_kernel(const uint32_t* __restrict__ sums, uint32_t* __restrict__ offs,
+                                                          int nb) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  uint32_t carry = 0;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + (int)threadIdx.x;
+    const uint32_t v = i < nb ? sums[i] : 0u;
+    uint32_t chunk_total;
+    const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk_total, smem);
+    if (i < nb) offs[i] = carry + ex;
+    carry += chunk_total;
+  }
+}
+
+hipError_t launch_depth_order(hipStream_t s, int P, const Geom& g) {
+  static const int digits[4] = {8, 8, 8, 8};  // 32 depth bits; 4 passes => result back in buffer 0
+  radix_sort_pairs(s, g.dkey, g.dval, P, 4, digits, g.ghist, g.gbin_total, true);
+  const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[0], g.tiles, g.block_sums);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, g.block_offs, nb);
+  return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------------
+// K3: duplicateWithKeys, rasterizer_impl.cu:67-100, in depth order of the Gaussians.  Thread i
+// handles Gaussian order[i]; its write offset is block_offs[block] + in-block exclusive scan.
+// Only the tile id is written as key (the depth is implied by the position).
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
+                                                               const Geom g, uint32_t* __restrict__ tkeys,
+                                                               uint32_t* __restrict__ vals) {
+  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  const uint32_t idx = i < P ? g.dval[0][i] : 0u;
+  const uint32_t n = i < P ? g.tiles[idx] : 0u;
+  uint32_t total;
+  uint32_t off = g.block_offs[blockIdx.x] + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
+  if (n == 0) return;
+  const float4 r1 = g.rec1[idx];
+  const int radius = radii[idx];
+  const float r = (float)radius;
+  // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle)
+  const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
+  const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
+  const uint32_t maxx = (uint32_t)min(gx, max(0, f2i_sat((r1.x + r + (float)TILE - 1.0f) / (float)TILE)));
+  const uint32_t maxy = (uint32_t)min(gy, max(0, f2i_sat((r1.y + r + (float)TILE - 1.0f) / (float)TILE)));
+  for (uint32_t y = miny; y < maxy; y++)
+    for (uint32_t x = minx; x < maxx; x++) {
+      tkeys[off] = y * (uint32_t)gx + x;
+      vals[off] = idx;
+      off++;
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // K5: identifyTileRanges, rasterizer_impl.cu:105-125 (ranges zeroed beforehand, :263-265).
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint32_t* __restrict__ tkeys,
                                                          uint2* __restrict__ ranges) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t currtile = (uint32_t)(keys[idx] >> 32);
+  const uint32_t currtile = tkeys[idx];
   if (idx == 0)
     ranges[currtile].x = 0;
   else {
-    const uint32_t prevtile = (uint32_t)(keys[idx - 1] >> 32);
+    const uint32_t prevtile = tkeys[idx - 1];
     if (currtile != prevtile) {
       ranges[prevtile].y = (uint32_t)idx;
       ranges[currtile].x = (uint32_t)idx;
@@ -283,28 +324,25 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(emit_keys_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, b.keys[0], b.vals[0]);
-  int cur = 0;
-  for (int p = 0; p < b.passes; ++p) {
-    const int shift = p * b.digit_bits;
-    if (b.digit_bits == 9) {
-      hipLaunchKernelGGL(sort_hist_kernel<9>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], R, shift, b.hist,
-                         b.nblocks);
-      hipLaunchKernelGGL(sort_scan_kernel, dim3(512), dim3(SORT_THREADS), 0, s, b.hist, b.bin_total, b.nblocks);
-      hipLaunchKernelGGL(sort_scatter_kernel<9>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], b.vals[cur],
-                         b.keys[cur ^ 1], b.vals[cur ^ 1], R, shift, b.hist, b.bin_total, b.nblocks);
-    } else {
-      hipLaunchKernelGGL(sort_hist_kernel<8>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], R, shift, b.hist,
-                         b.nblocks);
-      hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(SORT_THREADS), 0, s, b.hist, b.bin_total, b.nblocks);
-      hipLaunchKernelGGL(sort_scatter_kernel<8>, dim3(b.nblocks), dim3(SORT_THREADS), 0, s, b.keys[cur], b.vals[cur],
-                         b.keys[cur ^ 1], b.vals[cur ^ 1], R, shift, b.hist, b.bin_total, b.nblocks);
-    }
-    cur ^= 1;
-  }
+  hipLaunchKernelGGL(emit_keys_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, b.tkey[0], b.vals[0]);
+  radix_sort_pairs(s, b.tkey, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
   const int64_t nbr = (R + 255) / 256;
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.keys[cur], im.ranges);
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.tkey[b.final_buf], im.ranges);
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta);
+  return hipGetLastError();
+}
+
+// Test-only: rebuild the reference's 64-bit sorted keys, (tile << 32) | depth bits.
+__global__ void __launch_bounds__(256) export_keys_kernel(int64_t R, const uint32_t* __restrict__ tkeys,
+                                                         const uint32_t* __restrict__ vals, const float4* __restrict__ rec1,
+                                                         uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  keys[i] = ((uint64_t)tkeys[i] << 32) | (uint64_t)__float_as_uint(rec1[vals[i]].z);
+}
+hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys) {
+  hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, b.tkey[b.final_buf],
+                     b.vals[b.final_buf], g.rec1, keys);
   return hipGetLastError();
 }
 

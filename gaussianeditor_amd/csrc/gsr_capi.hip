@@ -270,13 +270,14 @@ int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D,
   return GSR_OK;
 }
 
-int gsr_debug_export_binning(void* stream, int64_t R, int W, int H, const void* binning, uint64_t* keys,
-                             uint32_t* point_list) {
+int gsr_debug_export_binning(void* stream, int P, int64_t R, int W, int H, const void* geom, const void* binning,
+                             uint64_t* keys, uint32_t* point_list) {
   if (R <= 0) return GSR_OK;
-  if (!binning) return GSR_ERR_BAD_ARGUMENT;
+  if (!binning || !geom) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
   hipStream_t s = (hipStream_t)stream;
-  if (keys) GSR_HIP(hipMemcpyAsync(keys, b.keys[b.final_buf], sizeof(uint64_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+  if (keys) GSR_HIP(launch_export_keys(s, R, b, g, keys));
   if (point_list)
     GSR_HIP(hipMemcpyAsync(point_list, b.vals[b.final_buf], sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
   return GSR_OK;

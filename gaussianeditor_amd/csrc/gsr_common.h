@@ -34,9 +34,14 @@ struct Geom {
   float* cov3D;          // (P,6)   computed or copied from cov3D_precomp
   uint32_t* tiles;       // (P)     tiles_touched
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
-  uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block
+  uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order
   uint32_t* block_offs;  // (nb)    exclusive prefix of block_sums
   uint64_t* total;       // (1)     num_rendered
+  // depth ordering of the Gaussians (stable LSD radix sort of (depth bits, index); culled Gaussians last)
+  uint32_t* dkey[2];     // (P)     ping-pong depth keys
+  uint32_t* dval[2];     // (P)     ping-pong Gaussian indices; dval[0] holds the final order (4 passes)
+  uint32_t* ghist;       // (256 * ceil(P/4096)) per-block digit counts of the depth sort
+  uint32_t* gbin_total;  // (512)
   size_t bytes;
 };
 
@@ -54,6 +59,11 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   g.clamped = (uint8_t*)(p + off);     off += align_up((size_t)P);
   g.block_sums = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
   g.block_offs = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
+  const size_t nsb = ((size_t)P + 4096 - 1) / 4096;
+  for (int i = 0; i < 2; ++i) { g.dkey[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)P); }
+  for (int i = 0; i < 2; ++i) { g.dval[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)P); }
+  g.ghist = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * 512 * nsb);
+  g.gbin_total = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * 512);
   g.bytes = off;
   return g;
 }
@@ -93,15 +103,18 @@ constexpr int SORT_ITEMS = 16;                          // keys per thread
 constexpr int SORT_KPB = SORT_THREADS * SORT_ITEMS;     // keys per block (4096)
 constexpr int SORT_MAX_BINS = 512;                      // 9-bit digits at most
 
-// Per-instance state ("binningBuffer"): ping-pong key/value arrays + histograms.
+// Per-instance state ("binningBuffer"): ping-pong (tile id, Gaussian index) arrays + histograms.
+// Instances are emitted in depth order of their Gaussians, so only the tile id remains to be sorted
+// (stably): getHigherMsb(T) bits in ceil(bits/8) passes.
 struct Binning {
-  uint64_t* keys[2];
-  uint32_t* vals[2];
+  uint32_t* tkey[2];    // (R) tile ids
+  uint32_t* vals[2];    // (R) Gaussian indices; vals[final_buf] is the reference's point_list
   uint32_t* hist;       // (bins * nblocks), bin-major
   uint32_t* bin_total;  // (bins)
   uint32_t nblocks;
-  int passes;           // ceil(key_bits / 9)
-  int digit_bits;       // ceil(key_bits / passes): 8 or 9 (45-bit keys @1080p: 5 passes of 9 bits)
+  int tile_bits;        // getHigherMsb(T)
+  int passes;           // ceil(tile_bits / 8)
+  int digit_bits[4];    // bits sorted by each pass (balanced split, <= 8)
   int final_buf;        // which ping-pong side holds the sorted result (= passes & 1)
   size_t bytes;
 };
@@ -122,13 +135,17 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, i
   char* p = (char*)base;
   Binning b;
   b.nblocks = (uint32_t)((R + SORT_KPB - 1) / SORT_KPB);
-  const int bits = sort_key_bits(W, H);
-  b.passes = (bits + 8) / 9;
-  b.digit_bits = (bits + b.passes - 1) / b.passes;
-  if (b.digit_bits < 8) b.digit_bits = 8;
+  b.tile_bits = sort_key_bits(W, H) - 32;
+  b.passes = (b.tile_bits + 7) / 8;
+  int left = b.tile_bits;
+  for (int i = 0; i < 4; ++i) {
+    const int remaining_passes = b.passes - i;
+    b.digit_bits[i] = remaining_passes > 0 ? (left + remaining_passes - 1) / remaining_passes : 0;
+    left -= b.digit_bits[i];
+  }
   b.final_buf = b.passes & 1;
   size_t off = 0;
-  for (int i = 0; i < 2; ++i) { b.keys[i] = (uint64_t*)(p + off); off += align_up(sizeof(uint64_t) * (size_t)R); }
+  for (int i = 0; i < 2; ++i) { b.tkey[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)R); }
   for (int i = 0; i < 2; ++i) { b.vals[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)R); }
   b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_MAX_BINS * (size_t)b.nblocks);
   b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_MAX_BINS);

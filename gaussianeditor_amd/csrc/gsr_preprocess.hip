@@ -1,5 +1,5 @@
-// gsr_preprocess.hip -- per-Gaussian kernels: K1 (forward preprocess), K2 (scan of the
-// per-block tile counts), K8+K9 fused (backward preprocess), K10 (frustum mark).
+// gsr_preprocess.hip -- per-Gaussian kernels: K1 (forward preprocess, incl. num_rendered), K8+K9 fused
+// (backward preprocess), K10 (frustum mark).  K2 (the tile-count prefix) lives in gsr_binning.hip.
 //
 // All of them are HBM-streaming kernels: one thread per Gaussian, 256 Gaussians per
 // block, every input byte read once and every output byte written once.  Arithmetic
@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
     const float* view = cam.view;
     const float* proj = cam.proj;
     int my_radius_i = 0;
+    float my_depth = 0.f;
     do {
       const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       // in_frustum, auxiliary.h:139-164: only the near test survives
@@ -258,35 +259,18 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
       a.g.rec1[idx] = make_float4(pix, piy, p_view.z, my_radius);
       a.g.rec2[idx] = col;
       my_radius_i = radius_i;
+      my_depth = p_view.z;
       my_tiles = area;
     } while (false);
     a.radii[idx] = my_radius_i;
     a.g.tiles[idx] = my_tiles;
+    // key of the depth ordering (gsr_binning.hip): depth bits, culled Gaussians after every live one
+    a.g.dkey[0][idx] = my_tiles ? __float_as_uint(my_depth) : 0xffffffffu;
   }
+  // num_rendered = sum of tiles_touched: one 64-bit atomic per block (g.total zeroed before the launch)
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);
-  if (threadIdx.x == 0) a.g.block_sums[blockIdx.x] = total;
-}
-
-// ----------------------------------------------------------------------------------
-// K2 (second level): exclusive scan of the per-block sums by one 1024-thread block;
-// writes num_rendered.  Replaces cub::DeviceScan::InclusiveSum, rasterizer_impl.cu:229-232
-// (the per-Gaussian offsets themselves are rebuilt inside the emit kernel from
-// block_offs + an in-block scan, so no P-sized offsets array ever touches HBM).
-// ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) scan_blocks_kernel(const uint32_t* __restrict__ sums, uint32_t* __restrict__ offs,
-                                                          uint64_t* __restrict__ total, int nb) {
-  __shared__ uint32_t smem[1024 / 64 + 1];
-  uint64_t carry = 0;
-  for (int base = 0; base < nb; base += 1024) {
-    const int i = base + (int)threadIdx.x;
-    const uint32_t v = i < nb ? sums[i] : 0u;
-    uint32_t chunk_total;
-    const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk_total, smem);
-    if (i < nb) offs[i] = (uint32_t)(carry + ex);
-    carry += chunk_total;
-  }
-  if (threadIdx.x == 0) *total = carry;
+  if (threadIdx.x == 0 && total) atomicAdd(reinterpret_cast<unsigned long long*>(a.g.total), (unsigned long long)total);
 }
 
 // ----------------------------------------------------------------------------------
@@ -566,9 +550,13 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_backward_kernel(const 
 // ----------------------------------------------------------------------------------
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipError_t e = hipMemsetAsync(a.g.total, 0, sizeof(uint64_t), s);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(preprocess_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, a.g.block_sums, a.g.block_offs, a.g.total, nb);
-  return hipGetLastError();
+  // K2 + first half of K4: depth order of the Gaussians and the tile-count prefix in that order.  Enqueued
+  // before the caller blocks on num_rendered, so it runs under that host round trip.
+  e = launch_depth_order(s, a.P, a.g);
+  return e != hipSuccess ? e : hipGetLastError();
 }
 // Test-only introspection: unpack the gather records into the reference's separate arrays.
 __global__ void __launch_bounds__(GAUSS_BLOCK) export_geom_kernel(int P, const Geom g, float* means2D, float* depths,

@@ -69,7 +69,8 @@ int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]);
 int gsr_sort_key_bits(int W, int H);
 
 /* K1 + K2: per-Gaussian preprocessing (SH -> RGB, 3D -> 2D covariance, conic,
- * radius, tile rectangle) and the prefix sum over tiles_touched; then the ONE
+ * radius, tile rectangle), the depth ordering of the Gaussians (first half of K4, see gsr_bin) and the
+ * prefix sum over tiles_touched in that order; then the ONE
  * blocking device->host readback of the path: *num_rendered_host = total number
  * of (Gaussian, tile) instances.  Reference: FORWARD::preprocess + InclusiveSum +
  * cudaMemcpy, rasterizer_impl.cu:217-239 (and :381-403 for apply_weights).
@@ -86,8 +87,10 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                    int prefiltered, int skip_color, int32_t* radii, void* geom, int64_t* num_rendered_host);
 
-/* K3 + K4 + K5: emit one (tile|depth, Gaussian) pair per touched tile, stable radix
- * sort on the low gsr_sort_key_bits() bits, and per-tile [begin,end) ranges.
+/* K3 + K4 + K5: emit one (tile, Gaussian) pair per touched tile in depth order of the Gaussians, stable
+ * radix sort on the tile id (together with the depth ordering done in gsr_preprocess this yields exactly the
+ * order of the reference's stable sort on the low gsr_sort_key_bits() bits of (tile << 32 | depth bits)),
+ * and per-tile [begin,end) ranges.
  * Reference: duplicateWithKeys + cub::DeviceRadixSort::SortPairs + identifyTileRanges,
  * rasterizer_impl.cu:248-271.  `binning` holds sizes[1] bytes for this R. */
 int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, const void* geom, void* binning,
@@ -149,8 +152,8 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
  *   keys (R) u64 sorted, point_list (R) u32 sorted; ranges (T,2) u32; final_T (N) f32; n_contrib (N) u32. */
 int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
                           float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped);
-int gsr_debug_export_binning(void* stream, int64_t R, int W, int H, const void* binning, uint64_t* keys,
-                             uint32_t* point_list);
+int gsr_debug_export_binning(void* stream, int P, int64_t R, int W, int H, const void* geom, const void* binning,
+                             uint64_t* keys, uint32_t* point_list);
 int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32_t* ranges, float* final_T,
                            uint32_t* n_contrib);
 

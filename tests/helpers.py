@@ -67,8 +67,8 @@ def hip_state(P, R, W, H, geom, binning, img):
     _native.check("export_geom", L.gsr_debug_export_geom(s, P, geom.data_ptr(), p("means2D"), p("depths"), p("cov3D"),
                                                          p("rgb"), p("conic_opacity"), p("tiles_touched"), p("clamped")))
     if R > 0:
-        _native.check("export_binning", L.gsr_debug_export_binning(s, R, W, H, binning.data_ptr(), p("keys"),
-                                                                   p("point_list")))
+        _native.check("export_binning", L.gsr_debug_export_binning(s, P, R, W, H, geom.data_ptr(), binning.data_ptr(),
+                                                                   p("keys"), p("point_list")))
     _native.check("export_image", L.gsr_debug_export_image(s, W, H, img.data_ptr(), p("ranges"), p("final_T"),
                                                            p("n_contrib")))
     torch.cuda.synchronize(dev)

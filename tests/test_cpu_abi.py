@@ -39,7 +39,7 @@ def test_scratch_sizes_and_sort_bits():
     assert L.gsr_sort_key_bits(1920, 1080) == 45
     g0, b0, i0 = _native.scratch_sizes(1000, 0, 640, 480)
     g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480)
-    assert b0 == 0 and b1 > 5000 * 24 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
+    assert b0 == 0 and b1 > 5000 * 16 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
     with pytest.raises(_native.GsrError):
         _native.scratch_sizes(-1, 0, 640, 480)
 
