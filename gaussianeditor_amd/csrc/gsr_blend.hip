@@ -364,7 +364,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   for (int i = 0; i < 3; i++) bg_dot_dpixel += a.bg[i] * dpx[i];
   const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
-  float accum_rec[3] = {0.f, 0.f, 0.f}, last_color[3] = {0.f, 0.f, 0.f};
+  float B_acc = 0.f, last_cdot = 0.f;  // sum_ch accum_rec[ch]*dL_dpixel[ch], sum_ch last_color[ch]*dL_dpixel[ch]
   float last_alpha = 0.f;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 
@@ -418,29 +418,27 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
       float v[9][GROUP];
 #pragma unroll
       for (int u = 0; u < GROUP; ++u) {
-        // Only the per-pixel recurrences run under the lane mask; they hand three scalars (zero for
-        // lanes that do not contribute) to the straight-line code that forms the nine terms, so no
-        // term needs a zero-initialising move or a select.
-        float mG = 0.f, mA = 0.f, mD = 0.f;
-        if (contrib[u]) {
-          const float alpha = al[u];
-          const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
-          T = T * inv_one_m;  // T / (1 - alpha), backward.cu:503
-          float dL_dalpha = 0.0f;
-          const float cc[3] = {cols[u].x, cols[u].y, cols[u].z};
-#pragma unroll
-          for (int ch = 0; ch < 3; ch++) {
-            accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-            last_color[ch] = cc[ch];
-            dL_dalpha += (cc[ch] - accum_rec[ch]) * dpx[ch];
-          }
-          dL_dalpha *= T;
-          last_alpha = alpha;
-          dL_dalpha += (-T_final * inv_one_m) * bg_dot_dpixel;
-          mG = G[u];
-          mA = dL_dalpha;
-          mD = alpha * T;  // dchannel_dcolor
-        }
+        // backward.cu:503-534 with the colour recurrence collapsed: the reference keeps accum_rec[ch] and
+        // last_color[ch] per channel and forms sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch]; the recurrence is
+        // linear and dL_dpixel is constant for the pixel, so B = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the
+        // same recurrence with the scalar cdot = sum_ch c[ch] * dL_dpixel[ch] in place of the colour.  One
+        // dependent chain instead of three, and everything that does not depend on the pixel's running state
+        // (rcp, cdot) sits outside it.  Lanes that do not contribute keep their state through selects and
+        // hand zeros to the term formation below.
+        const bool on = contrib[u];
+        const float alpha = al[u];
+        const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
+        const float cdot = cols[u].x * dpx[0] + cols[u].y * dpx[1] + cols[u].z * dpx[2];
+        const float Tn = T * inv_one_m;                            // T / (1 - alpha), backward.cu:503
+        const float Bn = B_acc + last_alpha * (last_cdot - B_acc);  // accum_rec update, backward.cu:515
+        float dL_dalpha = (cdot - Bn) * Tn + (-T_final * inv_one_m) * bg_dot_dpixel;
+        T = on ? Tn : T;
+        B_acc = on ? Bn : B_acc;
+        last_alpha = on ? alpha : last_alpha;
+        last_cdot = on ? cdot : last_cdot;
+        const float mG = on ? G[u] : 0.f;
+        const float mA = on ? dL_dalpha : 0.f;
+        const float mD = on ? alpha * Tn : 0.f;  // dchannel_dcolor
         const float4 co = cos_[u];
         const float dx = dxs[u], dy = dys[u];
         const float dL_dG = co.w * mA;
@@ -459,15 +457,16 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
       }
       // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave total of entry j + r,
       // which that lane adds to the tile-level accumulator of the entry's chunk slot.
-      const uint32_t my_slot = __float_as_uint(cols[0].w) * (uint32_t)((lane >> 4) == 0) +
-                               __float_as_uint(cols[1].w) * (uint32_t)((lane >> 4) == 1) +
-                               __float_as_uint(cols[2].w) * (uint32_t)((lane >> 4) == 2) +
-                               __float_as_uint(cols[3].w) * (uint32_t)((lane >> 4) == 3);
+      float tot[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const float tot = (ABLATE == 1 || ABLATE == 3) ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3])  // experiment: no reduction
-                                                       : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
-        if ((lane & 15) == 15 && tot != 0.f) atomicAdd(&sacc[k][my_slot], tot);  // ds_add_f32
+      for (int k = 0; k < 9; ++k)
+        tot[k] = (ABLATE == 1 || ABLATE == 3) ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3])  // experiment: no reduction
+                                              : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
+      if ((lane & 15) == 15) {
+        // lanes 15/31/47/63 hold the totals of entries j..j+3; one masked region, nine ds_add_f32
+        const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[k][my_slot], tot[k]);
       }
     }
     __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc
