@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=6, help="oracle train iterations timed for cpu_baseline")
+    ap.add_argument("--cpu-iters", type=int, default=15, help="oracle train iterations timed for cpu_baseline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,6 +207,16 @@ def main():
                          f"in {cpu_s:.1f} s with OpenMP over {O.num_threads()} threads; host has {os.cpu_count()} logical cores",
                "pixel_instances_per_view": int(f["pixel_instances"])}
 
+    # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself; it reports the per-launch value
+    # measured with rocprofv3 on this same workload and committed under profiles/ (null for any other workload).
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+        if tj["workload"] == {"gaussians": P, "width": W, "height": H} and dominant in tj["per_launch_bytes"]:
+            traffic, traffic_src = tj["per_launch_bytes"][dominant], tj["source"]
+    except Exception:
+        pass
+
     if rank == 0:
         iters_per_s = world * args.steps / train_s
         renders_per_s = world * args.steps / fwd_s
@@ -234,7 +244,7 @@ def main():
             "stage_algorithmic_bytes": ab,
             "hbm_fraction_train_iter": (sum(ab.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None},
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
