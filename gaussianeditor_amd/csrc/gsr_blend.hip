@@ -416,57 +416,68 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
       if (ABLATE == 4) continue;  // experiment: footprint + exp only
 
       float v[9][GROUP];
+      {
+#pragma clang fp contract(fast)  // gradients are tolerance-checked (<= 1e-5), not bit-compared: let a*b+c fuse here
 #pragma unroll
-      for (int u = 0; u < GROUP; ++u) {
-        // backward.cu:503-534 with the colour recurrence collapsed: the reference keeps accum_rec[ch] and
-        // last_color[ch] per channel and forms sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch]; the recurrence is
-        // linear and dL_dpixel is constant for the pixel, so B = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the
-        // same recurrence with the scalar cdot = sum_ch c[ch] * dL_dpixel[ch] in place of the colour.  One
-        // dependent chain instead of three, and everything that does not depend on the pixel's running state
-        // (rcp, cdot) sits outside it.  Lanes that do not contribute keep their state through selects and
-        // hand zeros to the term formation below.
-        const bool on = contrib[u];
-        const float alpha = al[u];
-        const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
-        const float cdot = cols[u].x * dpx[0] + cols[u].y * dpx[1] + cols[u].z * dpx[2];
-        const float Tn = T * inv_one_m;                            // T / (1 - alpha), backward.cu:503
-        const float Bn = B_acc + last_alpha * (last_cdot - B_acc);  // accum_rec update, backward.cu:515
-        float dL_dalpha = (cdot - Bn) * Tn + (-T_final * inv_one_m) * bg_dot_dpixel;
-        T = on ? Tn : T;
-        B_acc = on ? Bn : B_acc;
-        last_alpha = on ? alpha : last_alpha;
-        last_cdot = on ? cdot : last_cdot;
-        const float mG = on ? G[u] : 0.f;
-        const float mA = on ? dL_dalpha : 0.f;
-        const float mD = on ? alpha * Tn : 0.f;  // dchannel_dcolor
-        const float4 co = cos_[u];
-        const float dx = dxs[u], dy = dys[u];
-        const float dL_dG = co.w * mA;
-        const float gdx = mG * dx, gdy = mG * dy;
-        const float dG_ddelx = -gdx * co.x - gdy * co.y;
-        const float dG_ddely = -gdy * co.z - gdx * co.y;
-        v[0][u] = dL_dG * dG_ddelx * ddelx_dx;
-        v[1][u] = dL_dG * dG_ddely * ddely_dy;
-        v[2][u] = -0.5f * gdx * dx * dL_dG;
-        v[3][u] = -0.5f * gdx * dy * dL_dG;
-        v[4][u] = -0.5f * gdy * dy * dL_dG;
-        v[5][u] = mG * mA;
-        v[6][u] = mD * dpx[0];
-        v[7][u] = mD * dpx[1];
-        v[8][u] = mD * dpx[2];
+        for (int u = 0; u < GROUP; ++u) {
+          // backward.cu:503-534 with the colour recurrence collapsed: the reference keeps accum_rec[ch] and
+          // last_color[ch] per channel and forms sum_ch (c[ch] - accum_rec[ch]) * dL_dpixel[ch]; the recurrence is
+          // linear and dL_dpixel is constant for the pixel, so B = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the
+          // same recurrence with the scalar cdot = sum_ch c[ch] * dL_dpixel[ch] in place of the colour.  Lanes that
+          // do not contribute keep their state through selects and hand zeros on.
+          const bool on = contrib[u];
+          const float alpha = al[u];
+          const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
+          const float cdot = cols[u].x * dpx[0] + cols[u].y * dpx[1] + cols[u].z * dpx[2];
+          const float Tn = T * inv_one_m;                            // T / (1 - alpha), backward.cu:503
+          const float Bn = B_acc + last_alpha * (last_cdot - B_acc);  // accum_rec update, backward.cu:515
+          const float dL_dalpha = (cdot - Bn) * Tn + (-T_final * inv_one_m) * bg_dot_dpixel;
+          T = on ? Tn : T;
+          B_acc = on ? Bn : B_acc;
+          last_alpha = on ? alpha : last_alpha;
+          last_cdot = on ? cdot : last_cdot;
+          // Per lane only the MOMENTS of q = G * dL/dalpha are formed; every per-entry constant of
+          // backward.cu:538-554 (conic, opacity, 0.5*W, 0.5*H, -0.5) is applied after the wave reduction.
+          const float q = on ? G[u] * dL_dalpha : 0.f;
+          const float mD = on ? alpha * Tn : 0.f;  // dchannel_dcolor
+          const float dx = dxs[u], dy = dys[u];
+          const float qx = q * dx, qy = q * dy;
+          v[0][u] = q;
+          v[1][u] = qx;
+          v[2][u] = qy;
+          v[3][u] = qx * dx;
+          v[4][u] = qx * dy;
+          v[5][u] = qy * dy;
+          v[6][u] = mD * dpx[0];
+          v[7][u] = mD * dpx[1];
+          v[8][u] = mD * dpx[2];
+        }
       }
-      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave total of entry j + r,
-      // which that lane adds to the tile-level accumulator of the entry's chunk slot.
+      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave totals of entry j + r;
+      // that lane turns the moments into the reference's nine terms and adds them to the tile-level
+      // accumulator of the entry's chunk slot.
       float tot[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k)
         tot[k] = (ABLATE == 1 || ABLATE == 3) ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3])  // experiment: no reduction
                                               : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
       if ((lane & 15) == 15) {
-        // lanes 15/31/47/63 hold the totals of entries j..j+3; one masked region, nine ds_add_f32
-        const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[k][my_slot], tot[k]);
+        const uint32_t e = j + (uint32_t)(lane >> 4);
+        const float4 co = s0[w][e];  // conic.x, conic.y, conic.z, opacity of entry e
+        const uint32_t my_slot = __float_as_uint(s2[w][e].w);
+        const float o = co.w;
+        const float gx_ = -ddelx_dx * o * (co.x * tot[1] + co.y * tot[2]);  // dL_dmean2D.x, backward.cu:545
+        const float gy_ = -ddely_dy * o * (co.z * tot[2] + co.y * tot[1]);  // dL_dmean2D.y, backward.cu:546
+        const float h = -0.5f * o;
+        atomicAdd(&sacc[0][my_slot], gx_);
+        atomicAdd(&sacc[1][my_slot], gy_);
+        atomicAdd(&sacc[2][my_slot], h * tot[3]);  // dL_dconic.x, backward.cu:549
+        atomicAdd(&sacc[3][my_slot], h * tot[4]);  // dL_dconic.y, backward.cu:550
+        atomicAdd(&sacc[4][my_slot], h * tot[5]);  // dL_dconic.w, backward.cu:551
+        atomicAdd(&sacc[5][my_slot], tot[0]);      // dL_dopacity, backward.cu:554
+        atomicAdd(&sacc[6][my_slot], tot[6]);      // dL_dcolors,  backward.cu:523
+        atomicAdd(&sacc[7][my_slot], tot[7]);
+        atomicAdd(&sacc[8][my_slot], tot[8]);
       }
     }
     __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc
