@@ -246,3 +246,39 @@ def test_validation_errors():
         rast(x, x, o, shs=sc["features"].to(DEV))
     with pytest.raises(RuntimeError, match="means3D must have dimensions"):
         rast(x.reshape(-1), x, o, shs=sc["features"].to(DEV), scales=sc["scaling"].to(DEV), rotations=sc["rotation"].to(DEV))
+
+
+def test_headline_workload_full_size(oracle):
+    """BASELINE.json's metric configuration itself: synth-v1 1,000,000 Gaussians (SH3) at 1920x1080, view 0.
+    Every stage against the oracle at full size (the oracle needs a few seconds on the host cores)."""
+    import math
+
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+    from gaussianeditor_amd.synth import ring_cameras, synth_scene
+
+    P, W, H = 1_000_000, 1920, 1080
+    sc = synth_scene(P, seed=0, s0=0.01)
+    cam = ring_cameras(8, W, H)[0]
+    case = dict(sc=sc, cam=cam, W=W, H=H, tfx=math.tan(cam.FoVx / 2), tfy=math.tan(cam.FoVy / 2), bg=sc["bg"], D=3)
+    f, (R, color, depth, radii, geom, binning, img) = _compare_forward(oracle, case)
+    assert R == f["num_rendered"] > 4_000_000
+    # size-independent structure: ranges partition [0, R), lists are depth-sorted inside each tile
+    st = hip_state(P, R, W, H, geom, binning, img)
+    rl = st["ranges"].astype(np.int64)
+    assert (rl[:, 1] - rl[:, 0]).sum() == R
+    keys = st["keys"]
+    assert np.all(keys[1:] >= keys[:-1])
+    # gradients at full size
+    G = seed_gradient(H, W, 0)
+    g = oracle_backward(oracle, case, f, G)
+    leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
+    xyz, op, sh, scl, rot = leaf(sc["xyz"]), leaf(sc["opacity"]), leaf(sc["features"]), leaf(sc["scaling"]), leaf(sc["rotation"])
+    m2d = torch.zeros_like(xyz, requires_grad=True)
+    c2, _, _ = GaussianRasterizer(settings(case, DEV))(xyz, m2d, op, shs=sh, scales=scl, rotations=rot)
+    assert torch.equal(c2.detach(), color)  # run-to-run identical forward (work-queue order never affects results)
+    (c2 * G.to(DEV)).sum().backward()
+    for name, t in (("dL_dmeans3D", xyz), ("dL_dopacity", op), ("dL_dsh", sh), ("dL_dscales", scl),
+                    ("dL_drotations", rot), ("dL_dmeans2D", m2d)):
+        e = rel_err(t.grad.cpu().numpy(), g[name].reshape(t.shape))
+        print(name, "rel err @1M/1080p", e)
+        assert e <= 1e-5, name
