@@ -194,10 +194,12 @@ static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* c
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, const uint32_t* __restrict__ order,
                                                                        const uint32_t* __restrict__ tiles,
+                                                                       uint32_t* __restrict__ tiles_sorted,
                                                                        uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   const uint32_t n = i < P ? tiles[order[i]] : 0u;
+  if (i < P) tiles_sorted[i] = n;  // the emit kernel reads the counts coalesced instead of gathering them again
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -221,7 +223,8 @@ hipError_t launch_depth_order(hipStream_t s, int P, const Geom& g) {
   static const int digits[4] = {8, 8, 8, 8};  // 32 depth bits; 4 passes => result back in buffer 0
   radix_sort_pairs(s, g.dkey, g.dval, P, 4, digits, g.ghist, g.gbin_total, true);
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[0], g.tiles, g.block_sums);
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[0], g.tiles, g.dkey[1],
+                     g.block_sums);  // dkey[1] is free after the 4-pass sort: reuse it for the depth-ordered counts
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, g.block_offs, nb);
   return hipGetLastError();
 }
@@ -237,13 +240,12 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   const uint32_t idx = i < P ? g.dval[0][i] : 0u;
-  const uint32_t n = i < P ? g.tiles[idx] : 0u;
+  const uint32_t n = i < P ? g.dkey[1][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
   uint32_t total;
   uint32_t off = g.block_offs[blockIdx.x] + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   if (n == 0) return;
-  const float4 r1 = g.rec1[idx];
-  const int radius = radii[idx];
-  const float r = (float)radius;
+  const float4 r1 = g.rec1[idx];   // the only gather: mean2D, depth, radius (K1 stores (float)radii[idx] in .w)
+  const float r = r1.w;
   // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle)
   const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
   const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
