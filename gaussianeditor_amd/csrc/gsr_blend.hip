@@ -207,7 +207,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       __syncthreads();
       if (keep) {
         const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
-        s0[slot] = walk.cur.r0;
+        s0[slot] = make_float4(-0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w);
         s1[slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(walk.lane_pos() + 1u));
         s2[slot] = walk.cur.r2;
       }
@@ -233,8 +233,8 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
           const float4 co = s0[j + u];
           cc[u] = s2[j + u];
           const float dx = gg[u].x - pfx, dy = gg[u].y - pfy;
-          const float power = blend_power(co.x, co.y, co.z, dx, dy);
-          al[u] = fminf(0.99f, co.w * gsr_expf(power));
+          const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
+          al[u] = fminf(0.99f, co.w * gsr_expf_noclamp(power));
           ok[u] = !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
         }
 #pragma unroll
@@ -243,14 +243,15 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
           const float test_T = T * (1.0f - al[u]);
           const bool term = hit && (test_T < 0.0001f);
           done = done || term;
-          const bool b = hit && !term;
-          const float w = al[u] * T;
-          C0 = b ? __builtin_fmaf(cc[u].x, w, C0) : C0;
-          C1 = b ? __builtin_fmaf(cc[u].y, w, C1) : C1;
-          C2 = b ? __builtin_fmaf(cc[u].z, w, C2) : C2;
-          D = b ? __builtin_fmaf(gg[u].z, w, D) : D;
-          T = b ? test_T : T;
-          last_contributor = b ? __float_as_uint(gg[u].w) : last_contributor;
+          if (hit && !term) {  // kept as a lane-masked region: 6 instructions under exec instead of 10 selects
+            const float w = al[u] * T;
+            C0 = __builtin_fmaf(cc[u].x, w, C0);
+            C1 = __builtin_fmaf(cc[u].y, w, C1);
+            C2 = __builtin_fmaf(cc[u].z, w, C2);
+            D = __builtin_fmaf(gg[u].z, w, D);
+            T = test_T;
+            last_contributor = __float_as_uint(gg[u].w);
+          }
         }
       }
     }

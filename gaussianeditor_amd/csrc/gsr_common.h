@@ -178,6 +178,31 @@ __device__ __forceinline__ float gsr_expf(float x) {
   return __builtin_amdgcn_ldexpf(p, (int)n);
 }
 
+// gsr_expf without the lower clamp, for uses where any result below ~1e-37 is equivalent to 0 because it
+// is only compared against the 1/255 threshold (v_ldexp_f32 handles every exponent; for t < -126 the
+// result is subnormal or zero either way).  Bit-identical to gsr_expf for x >= -86.6.
+__device__ __forceinline__ float gsr_expf_noclamp(float x) {
+  const float t = x * 0x1.715476p+0f;
+  const float n = __builtin_rintf(t);
+  const float f = t - n;
+  float p = 0x1.44138ap-13f;
+  p = __builtin_fmaf(p, f, 0x1.5f0890p-10f);
+  p = __builtin_fmaf(p, f, 0x1.3b2a54p-7f);
+  p = __builtin_fmaf(p, f, 0x1.c6af6cp-5f);
+  p = __builtin_fmaf(p, f, 0x1.ebfbe0p-3f);
+  p = __builtin_fmaf(p, f, 0x1.62e430p-1f);
+  p = __builtin_fmaf(p, f, 1.0f);
+  return __builtin_amdgcn_ldexpf(p, (int)n);
+}
+
+// blend_power with the conic pre-scaled at staging time: (hA, B_, hC) = (-0.5 A, -B, -0.5 C).  Scaling by
+// -0.5 / -1 commutes with every rounding, so the result is bit-identical to blend_power(A, B, C, dx, dy).
+__device__ __forceinline__ float blend_power_prescaled(float hA, float nB, float hC, float dx, float dy) {
+  const float a = (hA * dx) * dx;
+  const float s = __builtin_fmaf(hC * dy, dy, a);
+  return __builtin_fmaf(nB * dx, dy, s);
+}
+
 // Gaussian footprint exponent, forward.cu:335-338 with the fma placement of the spec.
 __device__ __forceinline__ float blend_power(float cx, float cy, float cz, float dx, float dy) {
   const float a = (cx * dx) * dx;
