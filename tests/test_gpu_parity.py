@@ -282,3 +282,61 @@ def test_headline_workload_full_size(oracle):
         e = rel_err(t.grad.cpu().numpy(), g[name].reshape(t.shape))
         print(name, "rel err @1M/1080p", e)
         assert e <= 1e-5, name
+
+
+@pytest.mark.parametrize("P,W,H,s0,scale_xyz", [
+    (64, 16, 16, 0.5, 0.3),       # one tile, huge splats: every Gaussian covers the whole image
+    (1, 8, 8, 0.2, 0.0),          # a single Gaussian, image smaller than a tile
+    (300, 33, 17, 0.6, 0.5),      # ragged edge tiles in both directions, tiles_touched = all tiles
+    (5000, 640, 360, 0.4, 1.0),   # long lists: ~all Gaussians in every tile (many 64-entry chunks per tile)
+    (257, 48, 48, 0.05, 1.0),     # P just over one 256-Gaussian block
+    (4097, 64, 64, 0.05, 1.0),    # P just over one 4096-key sort block
+])
+def test_edge_geometries(oracle, P, W, H, s0, scale_xyz):
+    case = make_case(P, W, H, seed=21, s0=s0, scale_xyz=scale_xyz)
+    f, _ = _compare_forward(oracle, case)
+    G = seed_gradient(H, W, 21) * (H * W)
+    g = oracle_backward(oracle, case, f, G)
+    h = _grads_hip(case, G)
+    for k, v in h.items():
+        assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+def test_degenerate_inputs(oracle):
+    """Zero opacity, zero scale (det of the dilated cov2D stays > 0), coincident Gaussians with identical depth
+    (the sort must keep them in index order), opacity > 1 (alpha clamp at 0.99)."""
+    case = make_case(2000, 96, 96, seed=22, s0=0.08)
+    sc = case["sc"]
+    sc["opacity"][:200] = 0.0
+    sc["opacity"][200:300] = 1.5
+    sc["scaling"][300:400] = 0.0
+    sc["xyz"][400:600] = sc["xyz"][400:401]          # 200 coincident centres: identical depth bits and tiles
+    sc["scaling"][400:600] = sc["scaling"][400:401]
+    sc["rotation"][400:600] = sc["rotation"][400:401]
+    f, _ = _compare_forward(oracle, case)
+    same = f["keys"][1:] == f["keys"][:-1]
+    assert same.sum() > 100 and np.all(f["point_list"][1:][same] > f["point_list"][:-1][same])
+    G = seed_gradient(96, 96, 22) * (96 * 96)
+    g = oracle_backward(oracle, case, f, G)
+    h = _grads_hip(case, G)
+    for k, v in h.items():
+        assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+def test_non_contiguous_and_sliced_inputs(oracle):
+    """The L1 API accepts whatever torch hands it: transposed / strided / sliced tensors are made contiguous
+    (rasterize_points.cu:80-91 calls .contiguous() on every input)."""
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(3001, 80, 64, seed=23, s0=0.06)
+    sc = case["sc"]
+    f = oracle_forward(oracle, case)
+    big = torch.randn(3001 + 5, 3, device=DEV)
+    big[5:] = sc["xyz"].to(DEV)
+    xyz = big[5:]                                      # sliced view with a storage offset (15 floats: not 16-B aligned)
+    feats = sc["features"].to(DEV).permute(1, 0, 2).contiguous().permute(1, 0, 2)  # non-contiguous (P,M,3)
+    rot = sc["rotation"].to(DEV)[:, [0, 1, 2, 3]].t().contiguous().t()              # column-major (P,4)
+    color, radii, depth = GaussianRasterizer(settings(case, DEV))(xyz, torch.zeros_like(xyz), sc["opacity"].to(DEV),
+                                                                 shs=feats, scales=sc["scaling"].to(DEV), rotations=rot)
+    assert np.array_equal(radii.cpu().numpy(), f["radii"])
+    assert np.array_equal(color.cpu().numpy(), f["color"])
