@@ -42,7 +42,21 @@ def _worker(rank, world, port, out_dir):
         bucket = GradBucket(P, 16, "cpu")
         G = seed_gradient(H, W, 100 + rank) * H * W
         params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
-        color, radii, depth, grads = multiview_step(settings(case, "cpu"), params, G, bucket)
+        from gaussianeditor_amd.multiview import allreduce_view_grads, render_view_grads
+
+        color, radii, depth, grads = render_view_grads(settings(case, "cpu"), params["xyz"], params["opacity"],
+                                                       params["features"], params["scaling"], params["rotation"], G, bucket)
+        local = bucket.flat.clone()
+        mode_sparse = allreduce_view_grads(bucket, radii.clone(), sparse=True, sparse_threshold=1.0)
+        sparse_result = bucket.flat.clone()
+        bucket.flat.copy_(local)
+        mode_dense = allreduce_view_grads(bucket, radii, sparse=False)
+        assert (mode_sparse, mode_dense) == ("sparse", "dense")
+        # the packed exchange of the union rows reproduces the dense all-reduce
+        assert torch.allclose(sparse_result, bucket.flat, rtol=0, atol=0) or \
+            float((sparse_result - bucket.flat).abs().max()) <= 1e-6 * float(bucket.flat.abs().max())
+        touched = float((local.view(-1) != 0).float().mean())
+        assert 0.0 < touched < 1.0
         # the gradients are views of the flat bucket: no copies between the backward and the collective
         assert grads["sh"].data_ptr() == bucket.views["sh"].data_ptr()
         assert bucket.flat.numel() == P * (14 + 3 * 16)
