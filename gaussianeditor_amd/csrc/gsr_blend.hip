@@ -382,7 +382,8 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
     const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
     if (keep) {
       const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
-      s0[w][slot] = walk.cur.r0;
+      // conic pre-scaled as in the forward: (-0.5 A, -B, -0.5 C), exact
+      s0[w][slot] = make_float4(-0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w);
       s1[w][slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(pos));
       // .w carries the entry's index inside the chunk (= the lane that holds it): the LDS accumulator slot
       s2[w][slot] = make_float4(walk.cur.r2.x, walk.cur.r2.y, walk.cur.r2.z, __uint_as_float((uint32_t)lane));
@@ -407,8 +408,8 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
         const uint32_t c = __float_as_uint(g.w);  // 0-based position of this instance in the tile list
         dxs[u] = g.x - pfx;
         dys[u] = g.y - pfy;
-        const float power = blend_power(cos_[u].x, cos_[u].y, cos_[u].z, dxs[u], dys[u]);
-        G[u] = gsr_expf(power);
+        const float power = blend_power_prescaled(cos_[u].x, cos_[u].y, cos_[u].z, dxs[u], dys[u]);
+        G[u] = gsr_expf_noclamp(power);  // only used where alpha >= 1/255, i.e. far above the clamp
         al[u] = fminf(0.99f, cos_[u].w * G[u]);
         contrib[u] = (c < last_contributor) && !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
         any = any || contrib[u];
@@ -464,11 +465,12 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
                                               : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
       if ((lane & 15) == 15) {
         const uint32_t e = j + (uint32_t)(lane >> 4);
-        const float4 co = s0[w][e];  // conic.x, conic.y, conic.z, opacity of entry e
+        const float4 co = s0[w][e];  // (-0.5 conic.x, -conic.y, -0.5 conic.z, opacity) of entry e
         const uint32_t my_slot = __float_as_uint(s2[w][e].w);
         const float o = co.w;
-        const float gx_ = -ddelx_dx * o * (co.x * tot[1] + co.y * tot[2]);  // dL_dmean2D.x, backward.cu:545
-        const float gy_ = -ddely_dy * o * (co.z * tot[2] + co.y * tot[1]);  // dL_dmean2D.y, backward.cu:546
+        // -(A t1 + B t2) = 2 (-0.5 A) t1 + (-B) t2
+        const float gx_ = ddelx_dx * o * (2.f * co.x * tot[1] + co.y * tot[2]);  // dL_dmean2D.x, backward.cu:545
+        const float gy_ = ddely_dy * o * (2.f * co.z * tot[2] + co.y * tot[1]);  // dL_dmean2D.y, backward.cu:546
         const float h = -0.5f * o;
         atomicAdd(&sacc[0][my_slot], gx_);
         atomicAdd(&sacc[1][my_slot], gy_);
@@ -571,7 +573,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
     if (keep) {
       const uint32_t slot = (uint32_t)__popcll(km & lt_mask);
       sid[slot] = walk.cur.id;
-      s0[slot] = walk.cur.r0;
+      s0[slot] = make_float4(-0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w);
       s1[slot] = walk.cur.r1;
     }
 #pragma unroll
@@ -583,8 +585,8 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
       const float4 g = s1[j];
       const float4 co = s0[j];
       const float dx = g.x - pfx, dy = g.y - pfy;
-      const float power = blend_power(co.x, co.y, co.z, dx, dy);
-      const float alpha = fminf(0.99f, co.w * gsr_expf(power));
+      const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
+      const float alpha = fminf(0.99f, co.w * gsr_expf_noclamp(power));
       bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.0f - alpha);
       const bool term = hit && (test_T < 0.0001f);
