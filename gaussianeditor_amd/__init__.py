@@ -16,3 +16,14 @@ def install() -> None:
 
     _sys.modules["diff_gaussian_rasterization"] = _dgr
     _sys.modules["diff_gaussian_rasterization._C"] = _dgr._C
+    # the other two hard imports of scene/gaussian_model.py (:24, :26)
+    from . import simple_knn as _knn
+
+    _sys.modules["simple_knn"] = _knn
+    _sys.modules["simple_knn._C"] = _knn._C
+    try:  # a real `plyfile` installation wins
+        import plyfile as _ply  # noqa: F401
+    except ImportError:
+        from .compat import plyfile as _ply
+
+        _sys.modules["plyfile"] = _ply

@@ -31,6 +31,8 @@ SIGNATURES = {
     "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
+    "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

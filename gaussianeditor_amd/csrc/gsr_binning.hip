@@ -219,6 +219,12 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(const uint32_t* __res
   }
 }
 
+// exported for the other translation units (gsr_knn.hip)
+void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
+                          const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first) {
+  radix_sort_pairs(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first);
+}
+
 hipError_t launch_depth_order(hipStream_t s, int P, const Geom& g) {
   static const int digits[4] = {8, 8, 8, 8};  // 32 depth bits; 4 passes => result back in buffer 0
   radix_sort_pairs(s, g.dkey, g.dval, P, 4, digits, g.ghist, g.gbin_total, true);

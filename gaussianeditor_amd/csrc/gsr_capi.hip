@@ -257,6 +257,19 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   return GSR_OK;
 }
 
+int gsr_knn_workspace_size(int P, size_t* bytes) {
+  if (P < 0 || !bytes) return GSR_ERR_BAD_ARGUMENT;
+  *bytes = knn_workspace_bytes(P);
+  return GSR_OK;
+}
+
+int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace, float* mean_dist2) {
+  if (P == 0) return GSR_OK;
+  if (P < 0 || !points || !workspace || !mean_dist2) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_knn((hipStream_t)stream, P, points, workspace, mean_dist2));
+  return GSR_OK;
+}
+
 int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
                           float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
   if (P <= 0) return GSR_OK;

@@ -92,6 +92,8 @@ hipError_t launch_depth_order(hipStream_t s, int P, const Geom& g);
 hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys);
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
                           const Binning& b, const Image& im);
+size_t knn_workspace_bytes(int P);
+hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
 unsigned blend_grid_size();
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);

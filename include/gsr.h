@@ -144,6 +144,14 @@ int gsr_mark_visible(void* stream, int P, const float* means3D, const float* vie
 int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const void* geom, const void* binning,
                       const void* image, const float* image_weights, float* weights, int32_t* cnt);
 
+/* ---- the simple-knn submodule -------------------------------------------------
+ * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest other points (exact), i.e.
+ * `simple_knn._C.distCUDA2(points)` (gaussiansplatting/submodules/simple-knn/spatial.cu:15-25, simple_knn.cu:185-221),
+ * used by GaussianModel.create_from_pcd (gaussiansplatting/scene/gaussian_model.py:288-291).
+ * points (P,3) f32, mean_dist2 (P) f32, workspace: gsr_knn_workspace_size(P) bytes of device scratch. */
+int gsr_knn_workspace_size(int P, size_t* bytes);
+int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace, float* mean_dist2);
+
 /* ---- introspection used by the parity tests (not needed by the drop-in) ----
  * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
  * scratch buffers into caller-provided DEVICE arrays (any may be NULL):

@@ -229,3 +229,13 @@ def apply_weights(means3D, scales, rotations, opacities, cov3D_precomp, viewmatr
     if st != 0:
         raise ValueError(f"Unsupported number of channels: {C}")
     return geom, binning
+
+
+def knn_mean_dist2(points) -> np.ndarray:
+    """simple_knn.distCUDA2 restated (brute force, exact): (P,3) -> (P,) float32."""
+    pts = _f32(points)
+    P = 0 if pts is None else pts.shape[0]
+    out = np.zeros(P, np.float32)
+    if P:
+        lib().gsro_knn_mean_dist2(c_i(P), _p(pts), _p(out))
+    return out

@@ -852,6 +852,32 @@ int gsro_trace_weights(int W, int H, int C, const uint32_t* ranges, const uint32
   return 0;
 }
 
+// distCUDA2 of the simple-knn submodule (gaussiansplatting/submodules/simple-knn/simple_knn.cu:131-183,
+// spatial.cu:15-25): mean of the squared distances to the 3 nearest OTHER points.  The reference's Morton order
+// and box pruning only accelerate an exact search, so the restatement is the brute-force search with the same
+// float arithmetic (updateKBest<3>, simple_knn.cu:131-145; (b0 + b1 + b2) / 3.0f, :182).  O(P^2): small P only.
+int gsro_knn_mean_dist2(int P, const float* pts, float* out) {
+#pragma omp parallel for schedule(dynamic, 64)
+  for (int i = 0; i < P; ++i) {
+    float best[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f};
+    const float rx = pts[3 * i], ry = pts[3 * i + 1], rz = pts[3 * i + 2];
+    for (int j = 0; j < P; ++j) {
+      if (j == i) continue;
+      const float dx = pts[3 * j] - rx, dy = pts[3 * j + 1] - ry, dz = pts[3 * j + 2] - rz;
+      float dist = dx * dx + dy * dy + dz * dz;
+      for (int k = 0; k < 3; k++) {
+        if (best[k] > dist) {
+          const float t = best[k];
+          best[k] = dist;
+          dist = t;
+        }
+      }
+    }
+    out[i] = (best[0] + best[1] + best[2]) / 3.0f;
+  }
+  return 0;
+}
+
 int gsro_num_threads() {
 #if defined(_OPENMP)
   return omp_get_max_threads();

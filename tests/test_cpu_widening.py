@@ -1,0 +1,137 @@
+"""CPU: the SURVEY.md section 8(f) rank-1 "import enablers" -- the oracle of simple_knn.distCUDA2 pinned against an
+independent exact k-NN (scipy cKDTree), and the PLY shim against the byte layout the reference's save_ply/load_ply and
+fetchPly/storePly rely on (scene/gaussian_model.py:410-505, scene/dataset_readers.py:155-178)."""
+import io
+import sys
+
+import numpy as np
+import pytest
+
+from gaussianeditor_amd.compat import plyfile as ply
+
+
+def _kdtree_mean3(pts):
+    from scipy.spatial import cKDTree
+
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    return (d[:, 1:] ** 2).mean(axis=1)
+
+
+@pytest.mark.parametrize("P,kind", [(4, "uniform"), (257, "uniform"), (3000, "uniform"), (3000, "clustered")])
+def test_oracle_knn_matches_kdtree(oracle, P, kind):
+    rng = np.random.default_rng(P)
+    pts = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    if kind == "clustered":
+        pts = (pts * 0.01 + rng.integers(0, 5, (P, 1)).astype(np.float32)).astype(np.float32)
+    got = oracle.knn_mean_dist2(pts)
+    want = _kdtree_mean3(pts)
+    assert got.dtype == np.float32 and got.shape == (P,)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-12)
+
+
+def test_oracle_knn_duplicates_and_tiny(oracle):
+    # coincident points are neighbours at distance 0 (only the query index itself is skipped, simple_knn.cu:133-160)
+    pts = np.array([[0, 0, 0], [0, 0, 0], [1, 0, 0], [0, 2, 0], [0, 0, 3]], np.float32)
+    got = oracle.knn_mean_dist2(pts)
+    assert got[0] == np.float32((0 + 1 + 4) / 3.0) and got[1] == got[0]
+    assert oracle.knn_mean_dist2(np.zeros((0, 3), np.float32)).shape == (0,)
+
+
+def _gaussian_table(P, n_rest=45, seed=0):
+    names = ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(n_rest)]
+    names += ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+    rng = np.random.default_rng(seed)
+    attrs = rng.standard_normal((P, len(names))).astype(np.float32)
+    tab = np.empty(P, dtype=[(n, "f4") for n in names])
+    tab[:] = list(map(tuple, attrs))
+    return names, attrs, tab
+
+
+def test_ply_roundtrip_gaussian_checkpoint(tmp_path):
+    names, attrs, tab = _gaussian_table(123)
+    path = str(tmp_path / "point_cloud.ply")
+    ply.PlyData([ply.PlyElement.describe(tab, "vertex")]).write(path)
+    # the exact bytes: ASCII header, then P rows of 62 little-endian floats
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode("ascii").splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 123"]
+    assert lines[3:] == [f"property float {n}" for n in names]
+    assert body == attrs.astype("<f4").tobytes()
+
+    back = ply.PlyData.read(path)
+    v = back.elements[0]
+    assert v.name == "vertex" and v.count == 123 and len(back) == 1 and "vertex" in back
+    assert [p.name for p in v.properties] == names
+    rest = sorted((p.name for p in v.properties if p.name.startswith("f_rest_")), key=lambda s: int(s.split("_")[-1]))
+    assert len(rest) == 45  # load_ply's 3*(max_sh_degree+1)**2 - 3 check (gaussian_model.py:479)
+    for i, n in enumerate(names):
+        assert np.array_equal(np.asarray(v[n]), attrs[:, i])
+    assert np.array_equal(np.asarray(back["vertex"]["opacity"]), attrs[:, names.index("opacity")])
+
+
+def test_ply_colmap_points_mixed_types_and_streams():
+    # storePly / fetchPly layout: float xyz + normals, uchar rgb (dataset_readers.py:155-178)
+    P = 50
+    rng = np.random.default_rng(3)
+    dt = [("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"), ("red", "u1"), ("green", "u1"),
+          ("blue", "u1")]
+    tab = np.empty(P, dtype=dt)
+    for n, t in dt:
+        tab[n] = rng.uniform(0, 255, P).astype(t)
+    buf = io.BytesIO()
+    ply.PlyData([ply.PlyElement.describe(tab, "vertex")]).write(buf)
+    assert len(buf.getvalue().split(b"end_header\n", 1)[1]) == P * 27
+    buf.seek(0)
+    v = ply.PlyData.read(buf)["vertex"]
+    for n, t in dt:
+        assert np.array_equal(v[n], tab[n]) and v[n].dtype == np.dtype(t)
+
+    # ascii and big-endian files (as written by other tools) are readable too
+    txt = b"ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 2\nproperty float x\nproperty uchar red\nend_header\n" \
+          b"0.5 7\n-1.25 255\n"
+    a = ply.PlyData.read(io.BytesIO(txt))
+    assert a.comments == ["made by hand"] and a.text
+    assert np.array_equal(a["vertex"]["x"], np.float32([0.5, -1.25])) and np.array_equal(a["vertex"]["red"], np.uint8([7, 255]))
+    be = b"ply\nformat binary_big_endian 1.0\nelement vertex 1\nproperty int k\nproperty double w\nend_header\n" + \
+         np.array([(5, 2.5)], dtype=[("k", ">i4"), ("w", ">f8")]).tobytes()
+    b = ply.PlyData.read(io.BytesIO(be))["vertex"]
+    assert int(b["k"][0]) == 5 and float(b["w"][0]) == 2.5
+    out = io.BytesIO()
+    ply.PlyData(a.elements, text=True).write(out)
+    again = ply.PlyData.read(io.BytesIO(out.getvalue()))["vertex"]
+    assert np.array_equal(again["x"], a["vertex"]["x"]) and np.array_equal(again["red"], a["vertex"]["red"])
+
+
+def test_ply_errors():
+    with pytest.raises(ply.PlyParseError):
+        ply.PlyData.read(io.BytesIO(b"plx\n"))
+    with pytest.raises(ply.PlyParseError):  # truncated body
+        ply.PlyData.read(io.BytesIO(b"ply\nformat binary_little_endian 1.0\nelement vertex 2\nproperty float x\nend_header\n\0\0\0\0"))
+    with pytest.raises(ply.PlyParseError):  # list properties (meshes) are outside what the path needs
+        ply.PlyData.read(io.BytesIO(b"ply\nformat ascii 1.0\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n"))
+    with pytest.raises(TypeError):
+        ply.PlyElement.describe(np.zeros((3, 3), np.float32), "vertex")
+    with pytest.raises(KeyError):
+        ply.PlyData([])["vertex"]
+
+
+def test_install_registers_import_enablers(monkeypatch):
+    import gaussianeditor_amd
+
+    for name in ("simple_knn", "simple_knn._C", "plyfile", "diff_gaussian_rasterization", "diff_gaussian_rasterization._C"):
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    try:
+        gaussianeditor_amd.install()
+    except OSError:
+        pytest.skip("libgsr_hip.so not built")
+    import plyfile
+    from simple_knn._C import distCUDA2
+
+    assert hasattr(plyfile, "PlyData") and hasattr(plyfile, "PlyElement")
+    import torch
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        distCUDA2(torch.zeros(8, 3))
+    for name in ("simple_knn", "simple_knn._C", "plyfile", "diff_gaussian_rasterization", "diff_gaussian_rasterization._C"):
+        monkeypatch.delitem(sys.modules, name, raising=False)

@@ -340,3 +340,62 @@ def test_non_contiguous_and_sliced_inputs(oracle):
                                                                  shs=feats, scales=sc["scaling"].to(DEV), rotations=rot)
     assert np.array_equal(radii.cpu().numpy(), f["radii"])
     assert np.array_equal(color.cpu().numpy(), f["color"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# simple_knn.distCUDA2 (reference simple-knn/simple_knn.cu, called at
+# scene/gaussian_model.py:276 to initialise the scales of a new point cloud)
+def _dist2(pts):
+    from gaussianeditor_amd.simple_knn._C import distCUDA2
+
+    out = distCUDA2(torch.from_numpy(pts).to(DEV))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize("P,kind", [(1, "uniform"), (3, "uniform"), (4, "uniform"), (1000, "uniform"), (1025, "uniform"),
+                                    (20000, "uniform"), (20000, "clustered"), (5000, "plane"), (3000, "duplicates")])
+def test_knn_bit_exact_vs_oracle(oracle, P, kind):
+    rng = np.random.default_rng(P + len(kind))
+    pts = rng.uniform(-1, 1, (P, 3)).astype(np.float32)
+    if kind == "clustered":
+        pts = (pts * 0.01 + rng.integers(0, 5, (P, 3)).astype(np.float32)).astype(np.float32)
+    elif kind == "plane":
+        pts[:, 2] = 0.25  # degenerate bounding box along one axis
+    elif kind == "duplicates":
+        pts[P // 2:] = pts[:P - P // 2]
+    want = oracle.knn_mean_dist2(pts)
+    got = _dist2(pts)
+    assert got.dtype == np.float32 and got.shape == (P,)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_knn_full_size_vs_kdtree():
+    from scipy.spatial import cKDTree
+
+    P = 1_000_000
+    rng = np.random.default_rng(7)
+    pts = rng.standard_normal((P, 3)).astype(np.float32)
+    got = _dist2(pts)
+    sel = rng.choice(P, 20000, replace=False)
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts[sel].astype(np.float64), k=4)
+    want = (d[:, 1:] ** 2).mean(axis=1)
+    np.testing.assert_allclose(got[sel], want, rtol=3e-5, atol=1e-12)
+    assert np.isfinite(got).all() and (got > 0).all()
+
+
+def test_knn_input_validation():
+    from gaussianeditor_amd.simple_knn._C import distCUDA2
+
+    assert distCUDA2(torch.zeros(0, 3, device=DEV)).shape == (0,)
+    with pytest.raises(RuntimeError):
+        distCUDA2(torch.zeros(8, 3))  # host tensor
+    with pytest.raises(RuntimeError):
+        distCUDA2(torch.zeros(8, 4, device=DEV))
+    with pytest.raises(RuntimeError):
+        distCUDA2(torch.zeros(8, 3, device=DEV, dtype=torch.float64))
+    # non-contiguous input is accepted (made contiguous on the way in)
+    base = torch.rand(64, 6, device=DEV)
+    a = distCUDA2(base[:, ::2])
+    b = distCUDA2(base[:, ::2].contiguous())
+    assert torch.equal(a, b)
