@@ -169,12 +169,15 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
   }
 }
 
-// Sorts (keys[0], vals[0]) by key bits [0, sum(digits)); result in buffer (npass & 1).
+// Sorts (keys[0], vals[0]) by key bits [0, sum(digits)); result in buffer (npass & 1).  Passes [p0, npass) of the
+// sequence are launched (pass p reads buffer p & 1), so a caller can enqueue a prefix of the passes, decide how
+// many more are needed and continue.
 static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
-                             const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first) {
+                             const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0) {
   const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
-  int cur = 0, shift = 0;
-  for (int p = 0; p < npass; ++p) {
+  int cur = p0 & 1, shift = 0;
+  for (int p = 0; p < p0; ++p) shift += digit_bits[p];
+  for (int p = p0; p < npass; ++p) {
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
@@ -195,8 +198,10 @@ static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* c
 __global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, const uint32_t* __restrict__ order,
                                                                        const uint32_t* __restrict__ tiles,
                                                                        uint32_t* __restrict__ tiles_sorted,
-                                                                       uint32_t* __restrict__ block_sums) {
+                                                                       uint32_t* __restrict__ block_sums,
+                                                                       uint32_t* __restrict__ hdr, uint32_t final_buf) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[GEOM_HDR_FINAL] = final_buf;  // for emit_keys_kernel (gsr_bin)
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   const uint32_t n = i < P ? tiles[order[i]] : 0u;
   if (i < P) tiles_sorted[i] = n;  // the emit kernel reads the counts coalesced instead of gathering them again
@@ -225,12 +230,21 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
   radix_sort_pairs(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first);
 }
 
-hipError_t launch_depth_order(hipStream_t s, int P, const Geom& g) {
-  static const int digits[4] = {8, 8, 8, 8};  // 32 depth bits; 4 passes => result back in buffer 0
-  radix_sort_pairs(s, g.dkey, g.dval, P, 4, digits, g.ghist, g.gbin_total, true);
+// Depth order of the Gaussians: passes [p0, p1) of the 8-bit LSD sort on the depth bits.  Only the bits in which
+// the smallest and the largest key differ need sorting (the rest is a common prefix), so the caller enqueues the
+// first passes, learns the key range from K1 and adds what is missing.
+static const int kDepthDigits[4] = {8, 8, 8, 8};
+hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1) {
+  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0);
+  return hipGetLastError();
+}
+// After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).
+hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes) {
+  const int fin = passes & 1;
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[0], g.tiles, g.dkey[1],
-                     g.block_sums);  // dkey[1] is free after the 4-pass sort: reuse it for the depth-ordered counts
+  // dkey[fin ^ 1] (the input of the last pass) is dead: reuse it for the depth-ordered counts
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[fin], g.tiles, g.dkey[fin ^ 1],
+                     g.block_sums, reinterpret_cast<uint32_t*>(g.total), (uint32_t)fin);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, g.block_offs, nb);
   return hipGetLastError();
 }
@@ -245,8 +259,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
                                                                uint32_t* __restrict__ vals) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  const uint32_t idx = i < P ? g.dval[0][i] : 0u;
-  const uint32_t n = i < P ? g.dkey[1][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
+  const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
+  const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
+  const uint32_t n = i < P ? g.dkey[fin ^ 1u][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
   uint32_t total;
   uint32_t off = g.block_offs[blockIdx.x] + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   if (n == 0) return;

@@ -1,5 +1,5 @@
 // gsr_capi.hip -- the C ABI declared in include/gsr.h: argument checking, scratch carving and
-// kernel sequencing.  No device memory is allocated here and no global state is kept.
+// kernel sequencing.  No device memory is allocated here; the only state is the pinned readback slot (host_slot).
 #include <math.h>
 #include <string.h>
 
@@ -19,6 +19,30 @@ inline int hip_fail(hipError_t e) {
     hipError_t _e = (expr);                    \
     if (_e != hipSuccess) return hip_fail(_e); \
   } while (0)
+
+// Pinned landing slot + event of the num_rendered readback, one per (host thread, device).  This is the only
+// state the library keeps; it owns no device memory.
+struct HostSlot {
+  uint32_t* words = nullptr;  // GEOM_HDR_BYTES
+  hipEvent_t ready = nullptr;
+};
+HostSlot* host_slot() {
+  constexpr int MAX_DEV = 64;
+  static thread_local HostSlot slots[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  HostSlot& h = slots[dev];
+  if (h.words == nullptr) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&h.ready, hipEventDisableTiming) != hipSuccess) {
+      (void)hipHostFree(p);
+      return nullptr;
+    }
+    h.words = (uint32_t*)p;
+  }
+  return &h;
+}
 
 inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
                                  int queue_kind) {
@@ -103,10 +127,35 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.radii = radii;
   a.g = carve_geom(geom, P);
   GSR_HIP(launch_preprocess(s, a));
-  // the one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239)
+  // The one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239).  K1 already holds
+  // num_rendered (and the range of the depth keys), so the copy goes to pinned memory right behind K1, followed by
+  // an event; the first two passes of the depth sort are enqueued behind it and run while the host wakes up.
+  HostSlot* slot = host_slot();
+  if (slot == nullptr) return hip_fail(hipErrorOutOfMemory);
+  GSR_HIP(hipMemcpyAsync(slot->words, a.g.total, GEOM_HDR_BYTES, hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipEventRecord(slot->ready, s));
+  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2));
+  // busy-wait: hipEventSynchronize sleeps on an interrupt, which costs far more than the ~80 us being waited for
+  for (;;) {
+    const hipError_t q = hipEventQuery(slot->ready);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) return hip_fail(q);
+  }
   uint64_t total = 0;
-  GSR_HIP(hipMemcpyAsync(&total, a.g.total, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-  GSR_HIP(hipStreamSynchronize(s));
+  uint32_t kmax = 0, kinv = 0;
+  for (int i = 0; i < GEOM_HDR_SLOTS; ++i) {
+    const uint32_t* w = slot->words + i * GEOM_HDR_SLOT_WORDS;
+    total += (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    kmax = w[GEOM_HDR_KEYMAX] > kmax ? w[GEOM_HDR_KEYMAX] : kmax;
+    kinv = w[GEOM_HDR_KEYINVMAX] > kinv ? w[GEOM_HDR_KEYINVMAX] : kinv;
+  }
+  // bits above the highest one in which min and max key differ are a common prefix of every visible key
+  const uint32_t kmin = ~kinv;
+  int nbits = 0;
+  for (uint32_t d = total ? (kmax ^ kmin) : 0u; d; d >>= 1) ++nbits;
+  const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
+  if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
+  GSR_HIP(launch_depth_finish(s, P, a.g, passes));
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
   *num_rendered_host = (int64_t)total;
   return GSR_OK;

@@ -139,8 +139,11 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t id
 
 __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  __shared__ uint32_t skmax[2];
+  if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   uint32_t my_tiles = 0;
+  uint32_t kmax = 0u, kinv = 0u;  // max of the depth key / of its complement over the visible Gaussians of the wave
   if (idx < a.P) {
     Cam cam;
     load_cam(cam, a.viewmatrix, a.projmatrix, a.skip_color || a.colors_precomp ? nullptr : a.campos);
@@ -266,11 +269,31 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
     a.g.tiles[idx] = my_tiles;
     // key of the depth ordering (gsr_binning.hip): depth bits, culled Gaussians after every live one
     a.g.dkey[0][idx] = my_tiles ? __float_as_uint(my_depth) : 0xffffffffu;
+    if (my_tiles) {
+      kmax = __float_as_uint(my_depth);
+      kinv = ~kmax;
+    }
   }
-  // num_rendered = sum of tiles_touched: one 64-bit atomic per block (g.total zeroed before the launch)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+    kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, d, 64));
+  }
+  // num_rendered = sum of tiles_touched: one 64-bit atomic per block (the header is zeroed before the launch)
   uint32_t total;
-  (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);
-  if (threadIdx.x == 0 && total) atomicAdd(reinterpret_cast<unsigned long long*>(a.g.total), (unsigned long long)total);
+  (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);  // (its barriers also order the skmax init)
+  if (lane_id() == 0 && kinv) {
+    atomicMax(&skmax[0], kmax);
+    atomicMax(&skmax[1], kinv);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && total) {
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(a.g.total) + (blockIdx.x % GEOM_HDR_SLOTS) * GEOM_HDR_SLOT_WORDS;
+    atomicAdd(reinterpret_cast<unsigned long long*>(hdr), (unsigned long long)total);
+    // range of the depth keys (max, and max of the complement = ~min): the host sizes the depth sort with it
+    atomicMax(hdr + GEOM_HDR_KEYMAX, skmax[0]);
+    atomicMax(hdr + GEOM_HDR_KEYINVMAX, skmax[1]);
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -550,13 +573,10 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_backward_kernel(const 
 // ----------------------------------------------------------------------------------
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipError_t e = hipMemsetAsync(a.g.total, 0, sizeof(uint64_t), s);
+  hipError_t e = hipMemsetAsync(a.g.total, 0, GEOM_HDR_BYTES, s);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(preprocess_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
-  // K2 + first half of K4: depth order of the Gaussians and the tile-count prefix in that order.  Enqueued
-  // before the caller blocks on num_rendered, so it runs under that host round trip.
-  e = launch_depth_order(s, a.P, a.g);
-  return e != hipSuccess ? e : hipGetLastError();
+  return hipGetLastError();
 }
 // Test-only introspection: unpack the gather records into the reference's separate arrays.
 __global__ void __launch_bounds__(GAUSS_BLOCK) export_geom_kernel(int P, const Geom g, float* means2D, float* depths,
