@@ -256,14 +256,18 @@ hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes) 
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
                                                                const Geom g, uint32_t* __restrict__ tkeys,
-                                                               uint32_t* __restrict__ vals) {
+                                                               uint32_t* __restrict__ vals, uint2* __restrict__ ranges) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  // the ranges of tiles no instance falls into stay (0,0) (reference: cudaMemset, rasterizer_impl.cu:263-265);
+  // cleared here, two launches ahead of tile_ranges_kernel, instead of by a memset of its own
+  if (i < gx * gy) ranges[i] = make_uint2(0u, 0u);
   const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
   const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
   const uint32_t n = i < P ? g.dkey[fin ^ 1u][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
   uint32_t total;
-  uint32_t off = g.block_offs[blockIdx.x] + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
+  const uint32_t boff = (int)blockIdx.x * GAUSS_BLOCK < P ? g.block_offs[blockIdx.x] : 0u;  // (extra blocks only clear ranges)
+  uint32_t off = boff + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   if (n == 0) return;
   const float4 r1 = g.rec1[idx];   // the only gather: mean2D, depth, radius (K1 stores (float)radii[idx] in .w)
   const float r = r1.w;
@@ -307,8 +311,12 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint3
 // never results.
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
-                                                            uint32_t* __restrict__ order, uint32_t* __restrict__ meta) {
+                                                            uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
+                                                            uint32_t* __restrict__ queues) {
   __shared__ uint32_t hist[WORK_BUCKETS + 1], cursor[WORK_BUCKETS + 1];
+  // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
+  // own zeroed again (gsr_blend.hip: retire_queue), so this is the only place that clears them
+  for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) queues[(size_t)i * QUEUE_STRIDE] = 0u;
   for (int i = threadIdx.x; i <= WORK_BUCKETS; i += 1024) hist[i] = 0;
   __syncthreads();
   auto bucket_of = [](uint32_t len) -> uint32_t {
@@ -340,18 +348,21 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
                           const Binning& b, const Image& im) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
-  hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
-  if (e != hipSuccess) return e;
   if (R <= 0) {
-    hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta);
+    hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
+                       im.queue_heads);
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(emit_keys_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, b.tkey[0], b.vals[0]);
+  hipLaunchKernelGGL(emit_keys_kernel, dim3(max(nbg, (gx * gy + GAUSS_BLOCK - 1) / GAUSS_BLOCK)), dim3(GAUSS_BLOCK), 0, s, P, gx,
+                     gy, radii, g, b.tkey[0], b.vals[0], im.ranges);
   radix_sort_pairs(s, b.tkey, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
   const int64_t nbr = (R + 255) / 256;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.tkey[b.final_buf], im.ranges);
-  hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta);
+  hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
+                       im.queue_heads);
   return hipGetLastError();
 }
 

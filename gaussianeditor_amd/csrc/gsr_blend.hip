@@ -49,6 +49,26 @@ __device__ __forceinline__ bool setup_wave(const BlendArgs& a, uint32_t tile, ui
 // its cursor counts quadrant items (4 per non-empty tile) and then, if `with_empty`, one item
 // per empty tile.  A wave serves the queue of the XCD it happens to run on (HW_REG_XCC_ID, a
 // placement hint only: any wave may run any item).
+// Called by ONE thread of every workgroup after its last (failed) pop: the workgroup that retires last puts the
+// cursors of this queue kind back to zero, so the next launch of the kind finds them cleared without a memset.
+// (Every pop of every other workgroup has returned before that workgroup's retire increment is issued.)
+// Two levels, one counter per 64 workgroups and one on top: memory-side atomics on ONE line serialise at ~6 ns
+// each, which for 4096 workgroups retiring together measured 20 us on the tail of the forward kernel.
+__device__ __forceinline__ void retire_queue(uint32_t* queue) {
+  const uint32_t nwg = gridDim.x, grp = blockIdx.x >> 6, ngrp = (nwg + 63u) >> 6;
+  if (ngrp > (uint32_t)QUEUE_GROUPS) return;  // (launchers fall back to a memset for such grids)
+  const uint32_t gsize = min(64u, nwg - (grp << 6));
+  uint32_t* top = queue + 8 * QUEUE_STRIDE;
+  uint32_t* gcnt = queue + 9 * QUEUE_STRIDE;
+  if (__hip_atomic_fetch_add(gcnt + grp * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gsize - 1u) return;
+  if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != ngrp - 1u) return;
+#pragma unroll
+  for (int x = 0; x < 8; ++x) __hip_atomic_store(queue + x * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (uint32_t i = 0; i < ngrp; ++i)
+    __hip_atomic_store(gcnt + i * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <class F>
 __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
   const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID
@@ -69,6 +89,7 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
     else
       item(a.work_order[nwork + x + 8u * (q - 4u * n_x)], 0u, true);
   }
+  if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
 
 constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
@@ -533,6 +554,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
     if (q >= n_x) break;
     backward_tile<ABLATE>(a, a.work_order[x + 8u * q], s0, s1, s2, sid, sacc, s_maxc);
   }
+  if (a.self_reset && threadIdx.x == 0) retire_queue(a.queue);
 }
 
 // ----------------------------------------------------------------------------------
@@ -637,11 +659,17 @@ unsigned blend_grid_size() {
   }();
   return n;
 }
-static hipError_t reset_queue(hipStream_t s, const BlendArgs& a) {
-  return hipMemsetAsync(a.queue, 0, sizeof(uint32_t) * QUEUE_STRIDE * 8, s);
+// The cursors are zero on entry (cleared by tile_worklist_kernel, then by every launch's last workgroup).
+// GSR_QUEUE_MEMSET=1 (timing experiments), or a grid too large for the retire counters: clear them with a memset
+// before the launch instead.
+static hipError_t prepare_queue(hipStream_t s, BlendArgs& a, unsigned grid) {
+  static const bool env_memset = [] { const char* e = getenv("GSR_QUEUE_MEMSET"); return e && atoi(e) != 0; }();
+  const bool use_memset = env_memset || (grid + 63u) / 64u > (unsigned)QUEUE_GROUPS;
+  a.self_reset = use_memset ? 0 : 1;
+  return use_memset ? hipMemsetAsync(a.queue, 0, sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES, s) : hipSuccess;
 }
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
-  hipError_t e = reset_queue(s, a);
+  hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
   if (a.profile)
     hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
@@ -650,7 +678,7 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
-  hipError_t e = reset_queue(s, a);
+  hipError_t e = prepare_queue(s, a, blend_grid_size() / BWD_WAVES);
   if (e != hipSuccess) return e;
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
@@ -666,7 +694,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
-  hipError_t e = reset_queue(s, a);
+  hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
   const unsigned grid = blend_grid_size();
   switch (a.C) {

@@ -62,7 +62,7 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.bg = bg;
   a.final_T = im.final_T;
   a.n_contrib = im.n_contrib;
-  a.queue = im.queue_heads + (size_t)queue_kind * 8 * QUEUE_STRIDE;
+  a.queue = im.queue_heads + (size_t)queue_kind * QUEUE_LINES * QUEUE_STRIDE;
   return a;
 }
 }  // namespace

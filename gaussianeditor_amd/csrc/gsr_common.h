@@ -82,13 +82,15 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
 constexpr int WORK_BUCKETS = 128;     // tiles are bucketed by ceil(len/64), longest first
 constexpr int QUEUE_STRIDE = 32;      // u32 words between queue heads (128 B: one head per cache line)
 constexpr int QUEUE_KINDS = 3;        // forward, backward, trace
+constexpr int QUEUE_GROUPS = 128;     // retire counters: one per 64 workgroups of a launch (grids of up to 8192)
+constexpr int QUEUE_LINES = 8 + 1 + QUEUE_GROUPS;  // per kind: 8 per-XCD heads, the top retire counter, the group counters
 struct Image {
   uint2* ranges;        // (T)  [begin,end) into point_list
   float* final_T;       // (N)
   uint32_t* n_contrib;  // (N)
   uint32_t* work_order; // (T)  tile ids: non-empty tiles, longest list first (bucketed), then the empty tiles
   uint32_t* work_meta;  // [0] = number of non-empty tiles
-  uint32_t* queue_heads;// (QUEUE_KINDS x 8 XCDs) work-queue cursors, QUEUE_STRIDE words apart
+  uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
   size_t bytes;
 };
 __host__ __device__ inline Image carve_image(void* base, int W, int H) {
@@ -102,7 +104,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.n_contrib = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * N);
   im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * T);
   im.work_meta = (uint32_t*)(p + off);  off += 256;
-  im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * 8 * QUEUE_KINDS);
+  im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
   im.bytes = off;
   return im;
 }

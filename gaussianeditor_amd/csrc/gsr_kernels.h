@@ -56,7 +56,8 @@ struct BlendArgs {
   int W, H, gx, gy;
   const uint32_t* work_order;  // tile ids, longest first, empty tiles last
   const uint32_t* work_meta;   // [0] = number of non-empty tiles
-  uint32_t* queue;             // 8 per-XCD cursors of this launch, QUEUE_STRIDE words apart (zeroed before launch)
+  uint32_t* queue;             // 8 per-XCD cursors + retire counters of this kind, QUEUE_STRIDE words apart; zero on
+                               // entry, and left zero again by the launch's last workgroup
   const uint2* ranges;
   const uint32_t* point_list;
   const float4* rec0;
@@ -79,6 +80,7 @@ struct BlendArgs {
   const float* image_weights;
   float* weights;
   int32_t* cnt;
+  int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile;
 };

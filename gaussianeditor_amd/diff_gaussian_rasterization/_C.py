@@ -148,11 +148,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dpix = _f32(dL_dout_color, "dL_dout_color")
     radii = radii.contiguous()
     has_scales = scales.numel() != 0
-    # accumulated with atomics -> zero-filled; the rest is fully written by the kernels
-    dL_dmeans2D = _alloc("means2D", (P, 3), True, dev)
-    dL_dcolors = _alloc("colors_precomp", (P, NUM_CHANNELS), True, dev)
-    dL_dopacity = _alloc("opacities", (P, 1), True, dev)
-    dL_dconic = torch.zeros((P, 4), dtype=torch.float32, device=dev)
+    # accumulated with atomics -> zero-filled (with as few fill launches as possible: one block, or two when a
+    # gradient allocator owns means2D + opacities); the rest is fully written by the kernels
+    joint = _grad_allocator("means2D+opacities", (4 * P,), True) if _grad_allocator is not None else None
+    if joint is not None:
+        dL_dmeans2D, dL_dopacity = joint[:3 * P].view(P, 3), joint[3 * P:].view(P, 1)
+        rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
+        dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
+    elif _grad_allocator is not None:
+        dL_dmeans2D = _alloc("means2D", (P, 3), True, dev)
+        dL_dopacity = _alloc("opacities", (P, 1), True, dev)
+        rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
+        dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
+    else:
+        acc = torch.zeros((11 * P,), dtype=torch.float32, device=dev)  # conic first: its rows are dwordx4-accessed
+        dL_dconic, dL_dmeans2D = acc[:4 * P].view(P, 4), acc[4 * P:7 * P].view(P, 3)
+        dL_dcolors, dL_dopacity = acc[7 * P:10 * P].view(P, NUM_CHANNELS), acc[10 * P:].view(P, 1)
     dL_dmeans3D = _alloc("means3D", (P, 3), False, dev)
     dL_dcov3D = _alloc("cov3Ds_precomp", (P, 6), False, dev)
     dL_dsh = _alloc("sh", (P, M, 3), M == 0, dev)

@@ -75,6 +75,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # radii / depth never carry a gradient: do not let autograd fill zero tensors for them on every backward
+        ctx.set_materialize_grads(False)
         return color, radii, depth
 
     @staticmethod
@@ -84,6 +86,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:  # only the (gradient-free) depth output was used downstream
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         # argument order of _C.rasterize_gaussians_backward (rasterize_points.h:38-60)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos,

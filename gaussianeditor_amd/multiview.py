@@ -25,12 +25,13 @@ from .diff_gaussian_rasterization import GaussianRasterizationSettings, Gaussian
 __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step"]
 
 #: bucket layout per Gaussian: name -> number of floats (3M for the SH block is filled in at construction)
-_SLOTS = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
+_SLOTS = ("means3D", "sh", "scales", "rotations", "means2D", "opacities")
 
 
 class GradBucket:
-    """Flat fp32 buffer `[means3D 3P | sh 3MP | opacities P | scales 3P | rotations 4P | means2D 3P]`
-    = (14 + 3M) * P floats (248 MB at P = 1M, M = 16)."""
+    """Flat fp32 buffer `[means3D 3P | sh 3MP | scales 3P | rotations 4P | means2D 3P | opacities P]`
+    = (14 + 3M) * P floats (248 MB at P = 1M, M = 16).  means2D and opacities, the two gradients the backward
+    accumulates with atomics, are adjacent so that one fill clears both."""
 
     def __init__(self, P: int, M: int, device):
         self.P, self.M = int(P), int(M)
@@ -48,6 +49,15 @@ class GradBucket:
             off += cnt
 
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool) -> Optional[torch.Tensor]:
+        if name == "means2D+opacities":  # one contiguous, zeroed (4P,) block for both accumulators
+            m2, op = self.views["means2D"], self.views["opacities"]
+            if tuple(shape) != (4 * self.P,) or m2.data_ptr() % 16 != 0 or op.data_ptr() != m2.data_ptr() + 12 * self.P:
+                return None
+            off = m2.storage_offset()
+            block = self.flat[off:off + 4 * self.P]
+            if zero:
+                block.zero_()
+            return block
         v = self.views.get(name)
         if v is None or tuple(v.shape) != tuple(shape) or v.data_ptr() % 16 != 0:
             return None

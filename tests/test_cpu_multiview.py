@@ -79,8 +79,8 @@ def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
         case = make_case(P, W, H, seed=5, s0=0.07, view=v, nviews=world)
         f = oracle_forward(oracle, case)
         g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
-        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dsh", "dL_dopacity", "dL_dscales",
-                                                          "dL_drotations", "dL_dmeans2D")])
+        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dsh", "dL_dscales", "dL_drotations",
+                                                          "dL_dmeans2D", "dL_dopacity")])
         tot = flat if tot is None else tot + flat
         rad = f["radii"] if rad is None else np.maximum(rad, f["radii"])
     assert rel_err(r0["flat"], tot) < 1e-6
@@ -98,6 +98,11 @@ def test_bucket_layout_and_allocator():
     assert v is b.views["means2D"] and float(v.abs().sum()) == 0.0 and float(b.views["sh"].sum()) == 8 * 48
     assert b.allocator("sh", (8, 4, 3), False) is None          # shape mismatch -> private tensor
     assert b.allocator("colors_precomp", (8, 3), True) is None  # not a parameter gradient
+    # the two atomically accumulated gradients are adjacent: one fill clears both
+    b.flat.fill_(1.0)
+    j = b.allocator("means2D+opacities", (32,), True)
+    assert j.data_ptr() == b.views["means2D"].data_ptr() and j.numel() == 32 and float(j.abs().sum()) == 0.0
+    assert float(b.views["opacities"].abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
     # unaligned segments (P % 4 != 0) fall back to private tensors instead of misaligned dwordx4 stores
     b2 = GradBucket(7, 16, "cpu")
     assert b2.allocator("rotations", (7, 4), False) is None or b2.views["rotations"].data_ptr() % 16 == 0
