@@ -316,7 +316,10 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
   __shared__ uint32_t hist[WORK_BUCKETS + 1], cursor[WORK_BUCKETS + 1];
   // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
   // own zeroed again (gsr_blend.hip: retire_queue), so this is the only place that clears them
-  for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) queues[(size_t)i * QUEUE_STRIDE] = 0u;
+  for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) {
+    queues[(size_t)i * QUEUE_STRIDE] = 0u;      // taken from the front / counter
+    queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // taken from the back (two-ended cursors)
+  }
   for (int i = threadIdx.x; i <= WORK_BUCKETS; i += 1024) hist[i] = 0;
   __syncthreads();
   auto bucket_of = [](uint32_t len) -> uint32_t {

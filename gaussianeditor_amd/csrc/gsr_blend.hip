@@ -69,25 +69,57 @@ __device__ __forceinline__ void retire_queue(uint32_t* queue) {
     __hip_atomic_store(gcnt + i * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Work distribution.  The persistent workgroups are placed deterministically (measured with the per-wave profile,
+// tools/wave_profile.py): with `units` = number of SIMDs (single-wave workgroups) or CUs (4-wave workgroups), block b
+// runs on unit b % units in residency slot b / units, and on XCD b % 8.  A kernel ends when its busiest SIMD does, and
+// with a plain longest-first queue every wave's FIRST item is one of the few very long lists (the per-item work is
+// extremely skewed: mean 80 evaluated entries per quadrant, maximum 800), so the four long items that happen to share
+// a SIMD decide the run time: the busiest SIMD carried 1.83x the mean load.
+// Hence the first item of every workgroup is assigned, not popped: slot 0 of unit u takes item u of its XCD's queue,
+// slot 1 item 2n-1-u, slot 2 item 2n+u, slot 3 item 4n-1-u, ... (n = units per XCD): every unit gets one item from
+// each stratum of the sorted list, folded so that the sums even out.  Everything after the first W n items is popped
+// dynamically.  The assignment is a permutation of [0, W n) whatever the real placement is, so results never depend on it.
+__device__ __forceinline__ uint32_t first_item_of_block(uint32_t units, uint32_t& queue_x, uint32_t& first_dynamic) {
+  if (units == 0u) {  // no assignment: everything is popped
+    queue_x = 0u;
+    first_dynamic = 0u;
+    return 0xffffffffu;
+  }
+  const uint32_t n = units / 8u, W = gridDim.x / units;  // launchers guarantee units % 8 == 0, gridDim.x % units == 0
+  const uint32_t b = blockIdx.x, slot = b / units, u = (b % units) / 8u;
+  queue_x = b % 8u;
+  first_dynamic = W * n;
+  return (slot & 1u) ? (slot + 1u) * n - 1u - u : slot * n + u;
+}
+
 template <class F>
 __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
-  const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID
   const uint32_t nwork = a.work_meta[0];
   const uint32_t T = (uint32_t)(a.gx * a.gy);
-  const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
   const uint32_t nempty = with_empty ? T - nwork : 0u;
-  const uint32_t e_x = nempty > x ? (nempty - x + 7u) / 8u : 0u;
-  const uint32_t total = 4u * n_x + e_x;
+  // queue x (one per XCD) owns entries x, x+8, ... of work_order: 4 quadrant items per non-empty tile, then one item
+  // per empty tile
+  auto run_item = [&](uint32_t x, uint32_t q) -> bool {
+    const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
+    const uint32_t e_x = nempty > x ? (nempty - x + 7u) / 8u : 0u;
+    if (q >= 4u * n_x + e_x) return false;
+    if (q < 4u * n_x)
+      item(a.work_order[x + 8u * (q >> 2)], q & 3u, false);
+    else
+      item(a.work_order[nwork + x + 8u * (q - 4u * n_x)], 0u, true);
+    return true;
+  };
+  uint32_t x0, base;
+  const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
+  (void)run_item(x0, q0);
+  // then serve the queue of the XCD the wave really runs on (HW_REG_XCC_ID; equal to x0 on this chip)
+  const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
   uint32_t* head = a.queue + x * QUEUE_STRIDE;
   for (;;) {
     uint32_t q = 0;
     if (lane_id() == 0) q = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
-    if (q >= total) break;
-    if (q < 4u * n_x)
-      item(a.work_order[x + 8u * (q >> 2)], q & 3u, false);
-    else
-      item(a.work_order[nwork + x + 8u * (q - 4u * n_x)], 0u, true);
+    if (!run_item(x, base + q)) break;
   }
   if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
@@ -203,9 +235,13 @@ struct ChunkWalker {
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
 template <bool PROFILE>
-__device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited) {
+__device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
+                                             uint64_t* prof_cyc) {
   PixelWave pw;
-  if (!setup_wave(a, tile, quad, pw)) return;
+  if (!setup_wave(a, tile, quad, pw)) {
+    if (a.work_est != nullptr && lane_id() == 0) a.work_est[4u * tile + quad] = 0u;
+    return;
+  }
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
@@ -213,6 +249,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   bool done = !pw.inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last_contributor = 0;
+  uint32_t evaluated = 0;  // entries this quadrant evaluated (wave-uniform): the backward's work estimate for the tile
 
   __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
@@ -220,8 +257,14 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
     ChunkWalker<true> walk(a, range.x, range.y - range.x);
     for (; walk.valid(); walk.advance()) {
       if (__all(done)) break;
+      uint64_t tc0 = 0;
+      if (PROFILE) {
+        tc0 = __builtin_amdgcn_s_memtime();
+        prof_cyc[2]++;  // chunks walked
+      }
       const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
       const uint64_t m = __ballot(keep);
+      if (PROFILE) prof_cyc[3] += __builtin_amdgcn_s_memtime() - tc0;  // wait for the chunk's records + cull
       if (m == 0) continue;
       const uint32_t cnt = (uint32_t)__popcll(m);
       const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
@@ -242,8 +285,14 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       // GROUP entries per iteration: the footprint / exp evaluations of a group are independent
       // straight-line code (ILP for a wave that is alone on its SIMD); only the short
       // transmittance chain below is serial.
+      uint64_t tc1 = 0;
+      if (PROFILE) {
+        tc1 = __builtin_amdgcn_s_memtime();
+        prof_cyc[0] += tc1 - tc0;  // chunk start -> staged
+      }
       for (uint32_t j = 0; j < cnt4; j += GROUP) {
         if (__all(done)) break;
+        evaluated += GROUP;
         if (PROFILE) prof_visited += GROUP;
         float al[GROUP];
         bool ok[GROUP];
@@ -275,8 +324,10 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
           }
         }
       }
+      if (PROFILE) prof_cyc[1] += __builtin_amdgcn_s_memtime() - tc1;  // group loop
     }
   }
+  if (a.work_est != nullptr && lane == 0) a.work_est[4u * tile + quad] = evaluated;
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
     a.final_T[pix] = T;
@@ -292,13 +343,15 @@ template <bool PROFILE>
 __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
+  uint64_t prof_cyc[4] = {0, 0, 0, 0};
   if (PROFILE) t_start = __builtin_amdgcn_s_memtime();
   run_work_queue(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE>(a, tile, quad, prof_visited);
+      forward_item<PROFILE>(a, tile, quad, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
+      if (a.work_est != nullptr && lane_id() < 4) a.work_est[4u * tile + (uint32_t)lane_id()] = 0u;
       for (uint32_t q = 0; q < 4; ++q) {
         PixelWave pw;
         if (!setup_wave(a, tile, q, pw)) continue;
@@ -315,10 +368,15 @@ __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) 
     }
   });
   if (PROFILE) {
-    // debug record per persistent wave: start, end (s_memtime ticks), XCC_ID<<32 | HW_ID, items<<32 | visited entries
+    // debug record per persistent wave (8 x u64): start, end (s_memtime ticks), XCC_ID<<32 | HW_ID,
+    // items<<32 | visited entries, then the cycle split below
     const uint64_t t_end = __builtin_amdgcn_s_memtime();
     if (lane_id() == 0) {
-      uint64_t* rec = a.profile + (size_t)blockIdx.x * 4;
+      uint64_t* rec = a.profile + (size_t)blockIdx.x * 8;
+      rec[4] = prof_cyc[0];  // cycles: chunk start -> survivors staged
+      rec[5] = prof_cyc[1];  // cycles: group loops
+      rec[6] = prof_cyc[2];  // chunks walked
+      rec[7] = prof_cyc[3];  // cycles: chunk start -> cull ballot (includes the wait for the gathered records)
       rec[0] = t_start;
       rec[1] = t_end;
       rec[2] = ((uint64_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |  // HW_REG_XCC_ID[3:0]
@@ -546,8 +604,16 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
   const uint32_t nwork = a.work_meta[0];
   const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
   uint32_t* head = a.queue + x * QUEUE_STRIDE;
+  // first tile assigned by placement (see first_item_of_block), the rest popped
+  uint32_t x0, base;
+  const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
+  {
+    const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
+    if (q0 < n0) backward_tile<ABLATE>(a, a.work_order[x0 + 8u * q0], s0, s1, s2, sid, sacc, s_maxc);
+  }
   for (;;) {
-    if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) s_item = base + __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t q = s_item;
     __syncthreads();
@@ -644,6 +710,44 @@ __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) 
   run_work_queue(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C>(a, tile, quad); });
 }
 
+// Work list of the backward blend: tiles ordered by the work the FORWARD blend measured for them (entries evaluated,
+// summed over the four quadrants; the backward revisits the same (pixel, entry) pairs), heaviest first, in buckets of
+// 16 entries; tiles in which the forward evaluated nothing have no contributor anywhere and are dropped.  The list
+// length, which orders the forward's own work list, is a poor predictor because of early termination.
+// One 1024-thread block (T is a few thousand); the order inside a bucket depends on LDS-atomic timing: scheduling
+// only, never results.
+constexpr int BWD_BUCKETS = 256;
+__global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
+                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta) {
+  __shared__ uint32_t hist[BWD_BUCKETS + 1], cursor[BWD_BUCKETS + 1];
+  for (int i = threadIdx.x; i <= BWD_BUCKETS; i += 1024) hist[i] = 0;
+  __syncthreads();
+  auto bucket_of = [](uint4 e) -> uint32_t {
+    const uint32_t w = e.x + e.y + e.z + e.w;
+    if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
+    return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
+  };
+  for (int t = threadIdx.x; t < T; t += 1024) atomicAdd(&hist[bucket_of(reinterpret_cast<const uint4*>(est)[t])], 1u);
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive scan of the bucket sizes by one wave
+    uint32_t run = 0;
+    for (int base = 0; base <= BWD_BUCKETS; base += 64) {
+      const int i = base + (int)threadIdx.x;
+      const uint32_t v = i <= BWD_BUCKETS ? hist[i] : 0u;
+      const uint32_t incl = wave_incl_scan_u32(v);
+      if (i <= BWD_BUCKETS) cursor[i] = run + incl - v;
+      run += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) meta[0] = cursor[BWD_BUCKETS];  // number of tiles with work
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint32_t pos = atomicAdd(&cursor[bucket_of(reinterpret_cast<const uint4*>(est)[t])], 1u);
+    order[pos] = (uint32_t)t;
+  }
+}
+
 // Number of persistent single-wave workgroups: (SIMDs on the device) x (waves per SIMD).
 // GSR_BLEND_WAVES_PER_SIMD overrides the default (tuning knob; read once).
 unsigned blend_grid_size() {
@@ -659,6 +763,20 @@ unsigned blend_grid_size() {
   }();
   return n;
 }
+// Placement units of a launch with `waves_per_wg`-wave workgroups (see first_item_of_block): SIMDs or CUs; 0 turns the
+// assigned first items off (GSR_BLEND_FOLD=0, or a CU count the fold does not divide).
+static unsigned blend_units(unsigned waves_per_wg) {
+  static const bool fold = [] { const char* e = getenv("GSR_BLEND_FOLD"); return !e || atoi(e) != 0; }();
+  static const unsigned cus = [] {
+    int c = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    return (unsigned)(c > 0 ? c : 256);
+  }();
+  const unsigned units = waves_per_wg == 1 ? cus * 4u : cus;
+  const unsigned grid = blend_grid_size() / waves_per_wg;
+  if (!fold || units % 8u != 0u || grid % units != 0u) return 0u;
+  return units;
+}
 // The cursors are zero on entry (cleared by tile_worklist_kernel, then by every launch's last workgroup).
 // GSR_QUEUE_MEMSET=1 (timing experiments), or a grid too large for the retire counters: clear them with a memset
 // before the launch instead.
@@ -671,6 +789,7 @@ static hipError_t prepare_queue(hipStream_t s, BlendArgs& a, unsigned grid) {
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
+  a.units = (int)blend_units(1);
   if (a.profile)
     hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
   else
@@ -680,6 +799,16 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size() / BWD_WAVES);
   if (e != hipSuccess) return e;
+  a.units = (int)blend_units(BWD_WAVES);
+  // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
+  static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
+  if (own_list && a.work_est != nullptr) {
+    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta);
+    a.work_order = a.bwd_order;
+    a.work_meta = a.bwd_meta;
+  } else {
+    a.units = 0;  // the list-length order is too poor a predictor for assigned first tiles (measured: +4 %)
+  }
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
@@ -696,6 +825,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
+  a.units = (int)blend_units(1);
   const unsigned grid = blend_grid_size();
   switch (a.C) {
     case 1: hipLaunchKernelGGL(trace_weights_kernel<1>, dim3(grid), dim3(WAVE), 0, s, a); break;

@@ -54,6 +54,9 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.gy = (H + TILE - 1) / TILE;
   a.work_order = im.work_order;
   a.work_meta = im.work_meta;
+  a.work_est = im.work_est;
+  a.bwd_order = im.bwd_order;
+  a.bwd_meta = im.bwd_meta;
   a.ranges = im.ranges;
   a.point_list = b.vals[b.final_buf];
   a.rec0 = g.rec0;
@@ -203,7 +206,7 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
   a.out_color = out_color;
   a.out_depth = out_depth;
   a.profile = records;
-  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 4 * (size_t)n, (hipStream_t)stream));
+  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 8 * (size_t)n, (hipStream_t)stream));
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }

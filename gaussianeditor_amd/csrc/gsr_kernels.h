@@ -56,6 +56,9 @@ struct BlendArgs {
   int W, H, gx, gy;
   const uint32_t* work_order;  // tile ids, longest first, empty tiles last
   const uint32_t* work_meta;   // [0] = number of non-empty tiles
+  uint32_t* work_est;          // forward: out, (T,4) evaluated entries per quadrant; null = not recorded
+  uint32_t* bwd_order;         // backward launch: scratch for its own work list (gsr_blend.hip: backward_worklist_kernel)
+  uint32_t* bwd_meta;
   uint32_t* queue;             // 8 per-XCD cursors + retire counters of this kind, QUEUE_STRIDE words apart; zero on
                                // entry, and left zero again by the launch's last workgroup
   const uint2* ranges;
@@ -81,6 +84,7 @@ struct BlendArgs {
   float* weights;
   int32_t* cnt;
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
+  int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile;
 };

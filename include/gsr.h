@@ -166,9 +166,9 @@ int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32
                            uint32_t* n_contrib);
 
 /* Performance introspection (tools/wave_profile.py): run K6 with per-wave instrumentation.  One record
- * of 4 x u64 per launched workgroup: {s_memtime at start, at end, XCC_ID<<32 | HW_ID,
- * deepest list position<<32 | batches<<20 | tile range length}; records of workgroups that exit
- * before doing any work stay zero.  *n_records_host = number of workgroups (call with max_records = 0
+ * of 8 x u64 per launched workgroup: {s_memtime at start, at end, XCC_ID<<32 | HW_ID,
+ * items<<32 | entries evaluated, cycles chunk start -> survivors staged, cycles in the group loops, chunks walked,
+ * cycles chunk start -> cull ballot}; records of workgroups that exit before doing any work stay zero.  *n_records_host = number of workgroups (call with max_records = 0
  * to query; returns GSR_ERR_BAD_ARGUMENT in that case after setting it). */
 int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                                     const void* binning, void* image, float* out_color, float* out_depth,
