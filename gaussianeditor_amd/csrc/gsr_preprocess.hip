@@ -343,7 +343,11 @@ __device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, co
   }
 }
 
-__global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_backward_kernel(const PreBwdArgs a) {
+// (amdgpu_waves_per_eu: 129 VGPRs unconstrained = 3 waves per SIMD; capped at 128 the kernel fits 4 without spilling:
+//  -8 us.  Moving the 192-byte SH rows through LDS with wave-coalesced global accesses was measured too: slower, both
+//  for the loads (two exposed latencies) and for the stores; the strided dwordx4 accesses are not the problem.)
+__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+preprocess_backward_kernel(const PreBwdArgs a) {
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   if (idx >= a.P) return;
   const int ncoef = (a.D + 1) * (a.D + 1);
