@@ -26,6 +26,7 @@ SIGNATURES = {
                                c_float, c_float, c_int, c_int, _P, _P, POINTER(c_int64)]),
     "gsr_bin": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
                              _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

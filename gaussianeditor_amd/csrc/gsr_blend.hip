@@ -182,7 +182,7 @@ __device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r
 
 // Walks list positions in chunks.  FORWARD: positions [0,len) ascending, lane l of chunk c holds
 // position 64c + l.  Otherwise descending from `top`: lane l of chunk c holds top-1-(64c+l).
-template <bool FORWARD>
+template <bool FORWARD, bool AUX = false>  // AUX: colours come from BlendArgs::colors3 (auxiliary forward render)
 struct ChunkWalker {
   const BlendArgs& a;
   uint32_t list_base;  // range.x
@@ -204,7 +204,12 @@ struct ChunkWalker {
     e.id = id;
     e.r0 = a.rec0[id];
     e.r1 = a.rec1[id];
-    e.r2 = a.rec2[id];
+    if (AUX) {  // a compile-time switch: a run-time test here costs the main kernel 8 % (measured)
+      const float* __restrict__ c = a.colors3 + 3 * (size_t)id;
+      e.r2 = make_float4(c[0], c[1], c[2], 0.f);
+    } else {
+      e.r2 = a.rec2[id];
+    }
   }
   __device__ __forceinline__ ChunkWalker(const BlendArgs& a_, uint32_t base, uint32_t n) : a(a_), list_base(base), count(n) {
     const uint32_t l = (uint32_t)lane_id();
@@ -234,7 +239,7 @@ struct ChunkWalker {
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-template <bool PROFILE>
+template <bool PROFILE, bool AUX>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
                                              uint64_t* prof_cyc) {
   PixelWave pw;
@@ -254,7 +259,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   if (range.y > range.x) {
-    ChunkWalker<true> walk(a, range.x, range.y - range.x);
+    ChunkWalker<true, AUX> walk(a, range.x, range.y - range.x);
     for (; walk.valid(); walk.advance()) {
       if (__all(done)) break;
       uint64_t tc0 = 0;
@@ -330,16 +335,18 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   if (a.work_est != nullptr && lane == 0) a.work_est[4u * tile + quad] = evaluated;
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
-    a.final_T[pix] = T;
-    a.n_contrib[pix] = last_contributor;
+    if (a.final_T != nullptr) {  // (null in an auxiliary render: the state the backward needs stays that of the main one)
+      a.final_T[pix] = T;
+      a.n_contrib[pix] = last_contributor;
+    }
     a.out_color[pix] = __builtin_fmaf(T, a.bg[0], C0);
     a.out_color[HW + pix] = __builtin_fmaf(T, a.bg[1], C1);
     a.out_color[2 * HW + pix] = __builtin_fmaf(T, a.bg[2], C2);
-    a.out_depth[pix] = D;
+    if (a.out_depth != nullptr) a.out_depth[pix] = D;
   }
 }
 
-template <bool PROFILE>
+template <bool PROFILE, bool AUX>
 __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
@@ -348,7 +355,7 @@ __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) 
   run_work_queue(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE>(a, tile, quad, prof_visited, prof_cyc);
+      forward_item<PROFILE, AUX>(a, tile, quad, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
       if (a.work_est != nullptr && lane_id() < 4) a.work_est[4u * tile + (uint32_t)lane_id()] = 0u;
@@ -357,12 +364,14 @@ __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) 
         if (!setup_wave(a, tile, q, pw)) continue;
         if (pw.inside) {
           const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
-          a.final_T[pix] = 1.0f;
-          a.n_contrib[pix] = 0u;
+          if (a.final_T != nullptr) {
+            a.final_T[pix] = 1.0f;
+            a.n_contrib[pix] = 0u;
+          }
           a.out_color[pix] = __builtin_fmaf(1.0f, a.bg[0], 0.f);
           a.out_color[HW + pix] = __builtin_fmaf(1.0f, a.bg[1], 0.f);
           a.out_color[2 * HW + pix] = __builtin_fmaf(1.0f, a.bg[2], 0.f);
-          a.out_depth[pix] = 0.f;
+          if (a.out_depth != nullptr) a.out_depth[pix] = 0.f;
         }
       }
     }
@@ -791,9 +800,11 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(1);
   if (a.profile)
-    hipLaunchKernelGGL(blend_forward_kernel<true>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((blend_forward_kernel<true, false>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+  else if (a.colors3 != nullptr)
+    hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
   else
-    hipLaunchKernelGGL(blend_forward_kernel<false>, dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((blend_forward_kernel<false, false>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {

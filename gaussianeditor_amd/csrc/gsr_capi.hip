@@ -190,6 +190,25 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   return GSR_OK;
 }
 
+int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color) return GSR_ERR_BAD_ARGUMENT;
+  if (R > 0 && (!geom || !binning || !colors)) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Image im = carve_image(image, W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
+  a.colors3 = colors;
+  a.out_color = out_color;
+  a.out_depth = out_depth;
+  // leave everything the backward of the MAIN render reads untouched
+  a.final_T = nullptr;
+  a.n_contrib = nullptr;
+  a.work_est = nullptr;
+  GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
 int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                                     const void* binning, void* image, float* out_color, float* out_depth,
                                     uint64_t* records, int64_t max_records, int64_t* n_records_host) {

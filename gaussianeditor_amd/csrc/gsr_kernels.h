@@ -66,6 +66,7 @@ struct BlendArgs {
   const float4* rec0;
   const float4* rec1;
   const float4* rec2;
+  const float* colors3;        // auxiliary forward render: (P,3) colours blended instead of rec2; null otherwise
   const float* bg;
   float* final_T;
   uint32_t* n_contrib;

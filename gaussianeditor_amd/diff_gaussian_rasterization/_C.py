@@ -118,6 +118,30 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return R, out_color, out_depth, radii, geom, binning, img
 
 
+def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
+                            image_width, debug=False):
+    """Extension (no reference counterpart): a second image of the view whose state
+    (`geomBuffer`, `binningBuffer`, `imgBuffer`, `num_rendered`) an earlier rasterize_gaussians() call returned,
+    blended with the per-Gaussian `colors` (P,3) instead -- K6 only, what the reference obtains by running the whole
+    forward again with override_color.  Forward only; the saved state of the first render is left intact."""
+    _require_cuda(colors, "colors")
+    dev = colors.device
+    P, H, W = int(colors.size(0)), int(image_height), int(image_width)
+    out = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    if colors.ndimension() != 2 or colors.size(1) != NUM_CHANNELS:
+        raise RuntimeError("aux colors must have dimensions (num_points, 3)")
+    if P == 0 or geomBuffer.numel() == 0:
+        return out.zero_()
+    colors, background = _f32(colors, "colors"), _f32(background, "bg")
+    with torch.cuda.device(dev):
+        _native.check("gsr_blend_forward_aux", _native.lib().gsr_blend_forward_aux(
+            _stream(dev), P, int(num_rendered), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
+            imgBuffer.data_ptr(), colors.data_ptr(), out.data_ptr(), None))
+        if debug:
+            torch.cuda.synchronize(dev)
+    return out
+
+
 def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
     if _grad_allocator is not None:
         t = _grad_allocator(name, tuple(shape), zero)

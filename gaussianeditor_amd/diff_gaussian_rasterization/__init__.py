@@ -61,7 +61,7 @@ def _call_native(fn, args, debug: bool, dump_path: str, message: str):
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings):
+                raster_settings, aux_colors=None):
         rs = raster_settings
         # argument order of _C.rasterize_gaussians (rasterize_points.h:17-36)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -77,10 +77,18 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.mark_non_differentiable(radii)
         # radii / depth never carry a gradient: do not let autograd fill zero tensors for them on every backward
         ctx.set_materialize_grads(False)
-        return color, radii, depth
+        if aux_colors is None:
+            return color, radii, depth
+        # extension: a second, gradient-free image of the same view with other colours (K6 only)
+        aux = _call_native(_C.rasterize_gaussians_aux,
+                           (rs.bg, aux_colors.detach(), num_rendered, geomBuffer, binningBuffer, imgBuffer, rs.image_height,
+                            rs.image_width, rs.debug), rs.debug, "snapshot_fw.dump",
+                           "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        ctx.mark_non_differentiable(radii, aux)
+        return color, radii, depth, aux
 
     @staticmethod
-    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+    def backward(ctx, grad_out_color, grad_radii, grad_depth, grad_aux=None):
         # grad_radii / grad_depth are ignored exactly as in the reference (:137, :155-177):
         # depth is a forward-only output.
         rs = ctx.raster_settings
@@ -98,13 +106,20 @@ class _RasterizeGaussians(torch.autograd.Function):
              "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # one slot per forward() input (:213-225)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, None)
+                grad_cov3Ds_precomp, None, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
+
+
+def rasterize_gaussians_with_aux(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                 raster_settings, aux_colors):
+    """rasterize_gaussians plus a second image blended with `aux_colors` (P,3): (color, radii, depth, aux_color)."""
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings, aux_colors)
 
 
 def _absent(like: torch.Tensor) -> torch.Tensor:
@@ -125,7 +140,10 @@ class GaussianRasterizer(nn.Module):
             return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                cov3D_precomp=None):
+                cov3D_precomp=None, aux_colors=None):
+        """Reference signature (:258-309) plus one extension: with `aux_colors` (P,3) a second image of the same
+        view, blended with those colours instead, is returned as a fourth value (forward only, no gradient).  It is
+        what a second call with colors_precomp=aux_colors would render, at the cost of the blend kernel alone."""
         if (shs is None) == (colors_precomp is None):
             raise Exception("Please provide excatly one of either SHs or precomputed colors!")  # sic, :271-276
         has_sr = scales is not None or rotations is not None
@@ -137,6 +155,9 @@ class GaussianRasterizer(nn.Module):
         scales = _absent(means3D) if scales is None else scales
         rotations = _absent(means3D) if rotations is None else rotations
         cov3D_precomp = _absent(means3D) if cov3D_precomp is None else cov3D_precomp
+        if aux_colors is not None:
+            return rasterize_gaussians_with_aux(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                                cov3D_precomp, self.raster_settings, aux_colors)
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
 

@@ -66,8 +66,13 @@ def camera2rasterizer(viewpoint_camera, bg_color: torch.Tensor, sh_degree: int =
     return GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, 1.0, sh_degree))
 
 
-def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
-    """gaussian_renderer/__init__.py:45-150.  Background tensor must be on the GPU."""
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None,
+           semantic_color=None):
+    """gaussian_renderer/__init__.py:45-150.  Background tensor must be on the GPU.
+
+    Extension: `semantic_color` (P,3) adds out["semantic"], the image the reference obtains from a SECOND
+    render(..., override_color=semantic_color) of the same camera (threestudio/systems/GassuianEditor.py:183-191,
+    webui.py:705-713); here it reuses the preprocessing, sort and tile ranges of this call."""
     xyz = pc.get_xyz
     # dummy (P,3) tensor whose .grad receives the screen-space mean gradient (:60-69)
     screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
@@ -98,7 +103,7 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     else:
         colors_precomp = override_color
 
-    rendered_image, radii, depth = rasterizer(
+    outs = rasterizer(
         means3D=xyz.float(),
         means2D=screenspace_points.float(),
         shs=shs,
@@ -107,11 +112,16 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         scales=None if scales is None else scales.float(),
         rotations=None if rotations is None else rotations.float(),
         cov3D_precomp=cov3D_precomp,
+        **({} if semantic_color is None else {"aux_colors": semantic_color.float()}),
     )
-    return {
+    rendered_image, radii, depth = outs[:3]
+    out = {
         "render": rendered_image,
         "viewspace_points": screenspace_points,
         "visibility_filter": radii > 0,
         "radii": radii,
         "depth_3dgs": depth,
     }
+    if semantic_color is not None:
+        out["semantic"] = outs[3]
+    return out

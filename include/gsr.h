@@ -102,6 +102,16 @@ int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, 
 int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                       const void* binning, void* image, float* out_color, float* out_depth);
 
+/* Auxiliary forward render of the SAME view with other per-Gaussian colours: blends
+ * `colors` (P,3) through the geometry / binning state an earlier gsr_preprocess + gsr_bin left in the scratch buffers,
+ * i.e. K6 only.  GaussianEditor renders every training view and every GUI frame twice, the second time with
+ * `override_color` = the semantic mask (threestudio/systems/GassuianEditor.py:166-191, webui.py:693-713); K1-K5 of that
+ * second render are identical to the first one's.  The image equals what gsr_preprocess(colors_precomp = colors) ...
+ * gsr_blend_forward would produce.  final_T / n_contrib in `image` are NOT touched, so the backward of the main render
+ * is unaffected; no backward exists for the auxiliary image.  out_depth may be NULL. */
+int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth);
+
 /* K7 + K8 + K9: the whole backward.  Reference: Rasterizer::backward,
  * rasterizer_impl.cu:289-341 (BACKWARD::render then BACKWARD::preprocess).
  *   dL_dpix (3,H,W) in.

@@ -31,6 +31,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                   viewmatrix, projmatrix, campos, background, W, H, tan_fovx, tan_fovy, scale_modifier, degree, prefiltered)
     key = next(_ids)
     _registry[key] = f
+    # inputs of the view, for rasterize_gaussians_aux (defined as: the image a second full render would produce)
+    f["_view_args"] = (means3D, _opt(scales), _opt(rotations), opacity, _opt(cov3D_precomp), viewmatrix, projmatrix, campos,
+                       W, H, tan_fovx, tan_fovy, scale_modifier, degree, prefiltered)
     tag = torch.tensor([key], dtype=torch.int64).view(torch.uint8).clone()
     z = torch.zeros(0, dtype=torch.uint8)
     return (int(f["num_rendered"]), torch.from_numpy(f["color"]), torch.from_numpy(f["depth"]),
@@ -57,6 +60,16 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return tuple(out)
 
 
+def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
+                            image_width, debug=False):
+    f = _registry[int(geomBuffer.view(torch.int64)[0])]
+    (means3D, scales, rotations, opacity, cov3D, viewmatrix, projmatrix, campos, W, H, tfx, tfy, smod, degree,
+     prefiltered) = f["_view_args"]
+    g = O.forward(means3D, scales, rotations, opacity, None, colors.detach().cpu(), cov3D, viewmatrix, projmatrix, campos,
+                  background, W, H, tfx, tfy, smod, degree, prefiltered)
+    return torch.from_numpy(g["color"])
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     return torch.from_numpy(O.mark_visible(means3D, viewmatrix, projmatrix))
 
@@ -76,5 +89,6 @@ def install(monkeypatch):
     """Route the drop-in's native calls to the oracle for the duration of one test."""
     import gaussianeditor_amd.diff_gaussian_rasterization as dgr
 
-    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "apply_weights"):
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_aux", "mark_visible",
+                 "apply_weights"):
         monkeypatch.setattr(dgr._C, name, globals()[name])

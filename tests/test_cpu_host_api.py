@@ -142,3 +142,26 @@ def test_install_registers_module_names():
     assert GaussianRasterizationSettings._fields == ("image_height", "image_width", "tanfovx", "tanfovy", "bg",
                                                      "scale_modifier", "viewmatrix", "projmatrix", "sh_degree", "campos",
                                                      "prefiltered", "debug")
+
+
+def test_render_with_semantic_color_cpu(oracle, monkeypatch):
+    """Extension: render(..., semantic_color=c) returns the normal outputs plus the image a
+    second render(..., override_color=c) would give, without gradients and without disturbing the main backward."""
+    oracle_backend.install(monkeypatch)
+    from gaussianeditor_amd.gaussian_renderer import render
+
+    case = make_case(3000, 128, 96, seed=2, s0=0.05, nviews=1, bg=(0.1, 0.0, 0.2))
+    pc = _PC(case["sc"])
+    mask = (torch.rand(3000, generator=torch.Generator().manual_seed(0)) > 0.5).float()
+    sem = mask[:, None].repeat(1, 3)
+    out = render(case["cam"], pc, PIPE, case["bg"], semantic_color=sem)
+    two = render(case["cam"], _PC(case["sc"]), PIPE, case["bg"], override_color=sem)["render"]
+    assert out["semantic"].shape == (3, 96, 128) and not out["semantic"].requires_grad
+    assert torch.equal(out["semantic"], two.detach())
+    plain = render(case["cam"], _PC(case["sc"]), PIPE, case["bg"])
+    assert torch.equal(out["render"].detach(), plain["render"].detach())
+    G = seed_gradient(96, 128, 3) * 96 * 128
+    (out["render"] * G).sum().backward()
+    pc2 = _PC(case["sc"])
+    (render(case["cam"], pc2, PIPE, case["bg"])["render"] * G).sum().backward()
+    assert torch.equal(pc.get_xyz.grad, pc2.get_xyz.grad) and torch.equal(pc.get_features.grad, pc2.get_features.grad)

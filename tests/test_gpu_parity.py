@@ -399,3 +399,59 @@ def test_knn_input_validation():
     a = distCUDA2(base[:, ::2])
     b = distCUDA2(base[:, ::2].contiguous())
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the semantic image of a view from the state of its main render (K6 only)
+@pytest.mark.parametrize("P,W,H,s0", [(3000, 128, 96, 0.05), (50000, 512, 512, 0.02)])
+def test_aux_render_equals_second_full_render(oracle, P, W, H, s0):
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(P, W, H, seed=4, s0=s0, nviews=3, view=1)
+    sc = case["sc"]
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    rs = settings(case, DEV)
+    g = torch.Generator().manual_seed(1)
+    aux = torch.rand(P, 3, generator=g)
+    aux[torch.rand(P, generator=g) > 0.5] = 0.0  # a mask-like colour table
+    leaves = [dev(sc[k]).requires_grad_(True) for k in ("xyz", "features", "opacity", "scaling", "rotation")]
+    m3, sh, op, scl, rot = leaves
+    m2 = torch.zeros_like(m3, requires_grad=True)
+    color, radii, depth, sem = GaussianRasterizer(rs)(m3, m2, op, shs=sh, scales=scl, rotations=rot, aux_colors=dev(aux))
+    assert sem.shape == (3, H, W) and not sem.requires_grad
+    # (1) bit-identical to a full second render with colors_precomp = aux ...
+    with torch.no_grad():
+        color2, _, _ = GaussianRasterizer(rs)(dev(sc["xyz"]), torch.zeros_like(m3), dev(sc["opacity"]), colors_precomp=dev(aux),
+                                               scales=dev(sc["scaling"]), rotations=dev(sc["rotation"]))
+    assert torch.equal(sem, color2)
+    # ... and to the oracle's image of that render
+    f2 = oracle_forward(oracle, case, colors_precomp=aux)
+    assert rel_err(sem.cpu().numpy(), f2["color"]) <= 1e-6
+    # (2) the main render and its backward are exactly those of a call without the extension
+    G = seed_gradient(H, W, 9).to(DEV) * H * W
+    grads = torch.autograd.grad([color], leaves + [m2], grad_outputs=[G])
+    leaves_b = [dev(sc[k]).requires_grad_(True) for k in ("xyz", "features", "opacity", "scaling", "rotation")]
+    m2b = torch.zeros_like(m3, requires_grad=True)
+    color_b, radii_b, depth_b = GaussianRasterizer(rs)(leaves_b[0], m2b, leaves_b[2], shs=leaves_b[1], scales=leaves_b[3],
+                                                       rotations=leaves_b[4])
+    assert torch.equal(color, color_b) and torch.equal(radii, radii_b) and torch.equal(depth, depth_b)
+    grads_b = torch.autograd.grad([color_b], leaves_b + [m2b], grad_outputs=[G])
+    for ga, gb in zip(grads, grads_b):
+        assert rel_err(ga.cpu().numpy(), gb.cpu().numpy()) <= 1e-5  # (float atomics re-associate between runs)
+
+
+def test_aux_render_empty_and_validation():
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(64, 64, 64, seed=1, s0=0.05)
+    sc = case["sc"]
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    rs = settings(case, DEV)
+    # nothing visible: the auxiliary image is the background, like the main one
+    far = dev(sc["xyz"] * 0.1 + case["cam"].camera_center * 2)
+    out = GaussianRasterizer(rs)(far, torch.zeros_like(far), dev(sc["opacity"]), shs=dev(sc["features"]),
+                                 scales=dev(sc["scaling"]), rotations=dev(sc["rotation"]), aux_colors=torch.ones(64, 3, device=DEV))
+    assert torch.equal(out[3], out[0])
+    with pytest.raises(RuntimeError):
+        GaussianRasterizer(rs)(dev(sc["xyz"]), torch.zeros_like(far), dev(sc["opacity"]), shs=dev(sc["features"]),
+                               scales=dev(sc["scaling"]), rotations=dev(sc["rotation"]), aux_colors=torch.ones(64, 4, device=DEV))

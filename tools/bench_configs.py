@@ -82,6 +82,17 @@ def edit_step():
 t = timed(edit_step)
 out["C3_edit_loop_512_1M"] = {"ms_per_step": 1e3 * t, "steps_per_s": 1 / t}
 
+
+def edit_step_fused():  # the same two images from ONE preprocessing / sort: render(..., semantic_color=mask)
+    a = render(cam, pc, PIPE, bg, semantic_color=mask)
+    (a["render"] * G).sum().backward()
+    for v in pc.t.values():
+        v.grad = None
+
+
+t = timed(edit_step_fused)
+out["C3_edit_loop_512_1M_fused_semantic"] = {"ms_per_step": 1e3 * t, "steps_per_s": 1 / t}
+
 # ---- C5 ----
 cams = [c.to(dev) for c in ring_cameras(12, 512, 512)]
 masks = [(torch.rand(1, 512, 512, device=dev) > 0.5).float() for _ in cams]
