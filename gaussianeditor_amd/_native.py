@@ -14,8 +14,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 GSR_ABI_VERSION = 1
 
-#: every symbol include/gsr.h declares, with (restype, argtypes)
 _P = c_void_p
+
+
+class AdamTensor(ctypes.Structure):
+    """gsr_adam_tensor (include/gsr.h)."""
+    _fields_ = [("param", _P), ("grad", _P), ("exp_avg", _P), ("exp_avg_sq", _P), ("anchor", _P), ("numel", c_int64),
+                ("row_len", ctypes.c_int32), ("masked", ctypes.c_int32), ("lr", ctypes.c_double), ("anchor_scale", c_float)]
+
+
+#: every symbol include/gsr.h declares, with (restype, argtypes)
 SIGNATURES = {
     "gsr_abi_version": (c_int, []),
     "gsr_status_string": (ctypes.c_char_p, [c_int]),
@@ -34,6 +42,8 @@ SIGNATURES = {
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
+    "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
+                            _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),

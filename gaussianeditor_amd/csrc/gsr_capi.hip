@@ -341,6 +341,20 @@ int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace
   return GSR_OK;
 }
 
+int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
+                  double eps, const uint8_t* row_mask, const float* row_weight) {
+  if (num_tensors == 0) return GSR_OK;
+  if (num_tensors < 0 || num_tensors > 8 || !tensors || step < 1) return GSR_ERR_BAD_ARGUMENT;
+  if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return GSR_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < num_tensors; ++i) {
+    const gsr_adam_tensor& t = tensors[i];
+    if (t.numel < 0 || t.row_len < 1) return GSR_ERR_BAD_ARGUMENT;
+    if (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return GSR_ERR_BAD_ARGUMENT;
+  }
+  GSR_HIP(launch_adam_step((hipStream_t)stream, num_tensors, tensors, (long long)step, beta1, beta2, eps, row_mask, row_weight));
+  return GSR_OK;
+}
+
 int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
                           float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
   if (P <= 0) return GSR_OK;

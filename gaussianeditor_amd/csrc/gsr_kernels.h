@@ -102,6 +102,8 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
                           const Binning& b, const Image& im);
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out);
+hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
+                            double beta2, double eps, const uint8_t* row_mask, const float* row_weight);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
 unsigned blend_grid_size();
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);

@@ -162,6 +162,35 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
 int gsr_knn_workspace_size(int P, size_t* bytes);
 int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace, float* mean_dist2);
 
+/* ---- fused, row-masked Adam step over all parameter groups in one launch ----
+ * Replaces, per training step, torch.optim.Adam.step() over the six groups of GaussianModel.training_setup
+ * (gaussiansplatting/scene/gaussian_model.py:336-380; lr per group, betas (0.9, 0.999), eps 1e-15, no weight decay, no
+ * amsgrad), the gradient-mask hooks of apply_grad_mask (:841-856) and, optionally, the gradient of anchor_loss
+ * (:152-184).  Arithmetic = torch/optim/adam.py::_single_tensor_adam in binary32 (see gsr_optim.hip).
+ * Every tensor is a dense float32 device array; `numel` need not be a multiple of the row length.
+ *   row_len      floats per Gaussian in this tensor (3, 45, 1, 3, 4, ...): element e belongs to row e / row_len
+ *   masked       != 0: the gradient of rows with row_mask[row] == 0 is replaced by 0 (the moments still decay and the
+ *                parameter still moves, exactly as with the reference's hooks)
+ *   anchor       NULL, or a snapshot of the parameter: anchor_scale * row_weight[row] * (param - anchor) is added to
+ *                the gradient first (anchor_scale = lambda * 2 / N of the reference's mean-reduced MSE term)
+ *   lr           this group's learning rate for this step
+ * step = the step count AFTER this update (1 for the first), shared by all tensors; row_mask (P bytes, 0/1) and
+ * row_weight (P floats) are device pointers or NULL.  At most 8 tensors per call. */
+typedef struct gsr_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  const float* anchor;
+  int64_t numel;
+  int32_t row_len;
+  int32_t masked;
+  double lr;           /* doubles where torch holds Python floats: the derived scalars are rounded to binary32 once */
+  float anchor_scale;
+} gsr_adam_tensor;
+int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
+                  double eps, const uint8_t* row_mask, const float* row_weight);
+
 /* ---- introspection used by the parity tests (not needed by the drop-in) ----
  * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
  * scratch buffers into caller-provided DEVICE arrays (any may be NULL):

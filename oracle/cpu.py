@@ -239,3 +239,25 @@ def knn_mean_dist2(points) -> np.ndarray:
     if P:
         lib().gsro_knn_mean_dist2(c_i(P), _p(pts), _p(out))
     return out
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, row_mask=None, masked=False, anchor=None,
+              anchor_scale=0.0, row_weight=None):
+    """One Adam step on float32 arrays, in place on (p, m, v); rows = p.shape[0]."""
+    import ctypes as C
+
+    for a in (p, m, v):
+        assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    g = _f32(g)
+    n = p.size
+    row_len = max(1, n // max(1, p.shape[0]))
+    mask = None if row_mask is None else np.ascontiguousarray(row_mask, dtype=np.uint8)
+    anc = None if anchor is None else _f32(anchor)
+    rw = None if row_weight is None else _f32(row_weight)
+    fn = lib().gsro_adam_step
+    fn.restype = None
+    fn.argtypes = [C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                   C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_longlong]
+    fn(n, row_len, p.ctypes.data, g.ctypes.data, m.ctypes.data, v.ctypes.data, None if anc is None else anc.ctypes.data,
+       float(anchor_scale), None if rw is None else rw.ctypes.data, None if mask is None else mask.ctypes.data,
+       int(bool(masked)), float(lr), float(beta1), float(beta2), float(eps), int(step))

@@ -887,3 +887,42 @@ int gsro_num_threads() {
 }
 
 }  // extern "C"
+
+// ----------------------------------------------------------------------------------
+// Adam step, restating torch/optim/adam.py::_single_tensor_adam (what the reference's
+// torch.optim.Adam(l, lr=0.0, eps=1e-15) executes, gaussiansplatting/scene/gaussian_model.py:369) with the row mask
+// of apply_grad_mask (:841-856) and the gradient of one anchor_loss term (:152-184).  One binary32 operation per
+// line; the scalars come from the caller in double exactly as torch derives them from Python floats.
+// ----------------------------------------------------------------------------------
+extern "C" void gsro_adam_step(long long n, int row_len, float* p, const float* g_in, float* m, float* v, const float* anchor,
+                               float anchor_scale, const float* row_weight, const unsigned char* row_mask, int masked,
+                               double lr, double beta1, double beta2, double eps, long long step) {
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  const float one_minus_b1 = (float)(1.0 - beta1), one_minus_b2 = (float)(1.0 - beta2), b2 = (float)beta2;
+  const float bc2_sqrt = (float)sqrt(bc2), neg_step = (float)(-(lr / bc1)), epsf = (float)eps;
+  for (long long e = 0; e < n; ++e) {
+    const long long row = e / row_len;
+    float g = g_in[e];
+    if (anchor) {
+      const float w = row_weight ? row_weight[row] : 1.0f;
+      const float sw = anchor_scale * w;
+      const float d = p[e] - anchor[e];
+      const float t = sw * d;
+      g = g + t;
+    }
+    if (masked && row_mask && row_mask[row] == 0) g = 0.0f;
+    const float diff = g - m[e];
+    const float lerp = one_minus_b1 * diff;
+    m[e] = m[e] + lerp;
+    const float vb = v[e] * b2;
+    const float og = one_minus_b2 * g;
+    const float ogg = og * g;
+    v[e] = vb + ogg;
+    const float sq = sqrtf(v[e]);
+    const float dn = sq / bc2_sqrt;
+    const float den = dn + epsf;
+    const float q = m[e] / den;
+    const float upd = neg_step * q;
+    p[e] = p[e] + upd;
+  }
+}

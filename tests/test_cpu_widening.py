@@ -135,3 +135,92 @@ def test_install_registers_import_enablers(monkeypatch):
         distCUDA2(torch.zeros(8, 3))
     for name in ("simple_knn", "simple_knn._C", "plyfile", "diff_gaussian_rasterization", "diff_gaussian_rasterization._C"):
         monkeypatch.delitem(sys.modules, name, raising=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the Adam oracle pinned against torch.optim.Adam itself (the reference's optimizer,
+# gaussiansplatting/scene/gaussian_model.py:369), with the gradient mask of apply_grad_mask (:841-856) and the
+# anchor-loss gradient (:152-184) obtained from autograd
+def _ref_groups(P, seed):
+    import torch
+
+    g = torch.Generator().manual_seed(seed)
+    shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, 15, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+    lrs = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+    params = {k: torch.randn(s, generator=g).requires_grad_(True) for k, s in shapes.items()}
+    return params, lrs, g
+
+
+def test_oracle_adam_matches_torch_adam(oracle):
+    import torch
+
+    P = 257
+    params, lrs, gen = _ref_groups(P, 0)
+    opt = torch.optim.Adam([{"params": [p], "lr": lrs[k], "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)
+    mine = {k: [p.detach().numpy().copy(), np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)] for k, p in params.items()}
+    for step in range(1, 6):
+        for k, p in params.items():
+            p.grad = torch.randn(p.shape, generator=gen) * (0.1 if step % 2 else 10.0)
+            if step == 3:
+                p.grad[: P // 2] = 0.0  # rows without a gradient still decay their moments and move
+        for k, p in params.items():
+            oracle.adam_step(mine[k][0], p.grad.numpy(), mine[k][1], mine[k][2], lrs[k], step, eps=1e-15)
+        opt.step()
+        for k, p in params.items():
+            st = opt.state[p]
+            # tolerance: 1e-6 of the tensor's magnitude (torch's CPU lerp / addcmul kernels contract a*b+c into fma, the
+            # oracle rounds every operation: differences of one ulp of the larger operand where terms cancel)
+            for mine_t, ref_t in ((mine[k][0], p.detach().numpy()), (mine[k][1], st["exp_avg"].numpy()),
+                                  (mine[k][2], st["exp_avg_sq"].numpy())):
+                np.testing.assert_allclose(mine_t, ref_t, rtol=1e-5, atol=1e-6 * float(np.abs(ref_t).max()))
+
+
+def test_oracle_adam_mask_and_anchor_match_autograd(oracle):
+    import torch
+
+    P = 100
+    params, lrs, gen = _ref_groups(P, 1)
+    mask = torch.rand(P, generator=gen) > 0.4
+    weight = torch.rand(P, generator=gen)  # anchor_weight_list per row (schedule[generation])
+    lam = 3.0
+    anchors = {k: p.detach().clone() + 0.05 * torch.randn(p.shape, generator=gen) for k, p in params.items()}
+    opt = torch.optim.Adam([{"params": [p], "lr": lrs[k]} for k, p in params.items()], lr=0.0, eps=1e-15)
+    masked_fields = ("xyz", "f_dc", "f_rest", "opacity", "scaling")  # apply_grad_mask's list: rotation is not in it
+    for k in masked_fields:  # the reference's hook
+        params[k].register_hook(lambda grad, m=mask: grad * (m[:, None] if grad.ndim == 2 else m[:, None, None]))
+    mine = {k: [p.detach().numpy().copy(), np.zeros(p.shape, np.float32), np.zeros(p.shape, np.float32)] for k, p in params.items()}
+    for step in range(1, 4):
+        data = {k: torch.randn(p.shape, generator=gen) for k, p in params.items()}
+        # a data term + the reference's anchor term: mean over the masked rows of w_row * (p - a)^2
+        loss = sum((p * data[k]).sum() for k, p in params.items())
+        for k, p in params.items():
+            delta = torch.nn.functional.mse_loss(p[mask], anchors[k][mask], reduction="none")
+            delta = delta * (weight[mask][:, None] if delta.ndim == 2 else weight[mask][:, None, None])
+            loss = loss + lam * delta.mean()
+        for p in params.values():
+            p.grad = None
+        loss.backward()
+        nsel = int(mask.sum())
+        for k, p in params.items():
+            n_elem = nsel * (p.numel() // P)
+            oracle.adam_step(mine[k][0], data[k].numpy(), mine[k][1], mine[k][2], lrs[k], step, eps=1e-15,
+                             row_mask=mask.numpy(), masked=k in masked_fields, anchor=anchors[k].numpy(),
+                             anchor_scale=lam * 2.0 / n_elem, row_weight=(weight * mask).numpy())
+        opt.step()
+        for k, p in params.items():
+            np.testing.assert_allclose(mine[k][0], p.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg=k)
+
+
+def test_fused_adam_has_no_cpu_fallback():
+    import torch
+
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    p = torch.zeros(4, 3, requires_grad=True)
+    p.grad = torch.ones(4, 3)
+    try:
+        opt = FusedMaskedAdam([p], lr=0.1)
+    except ImportError:
+        pytest.skip("libgsr_hip.so not built")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        opt.step()
