@@ -545,3 +545,88 @@ def test_fused_adam_mask_anchor_and_state_surgery(oracle):
     opt.step()
     assert int(opt.state[opt.param_groups[0]["params"][0]]["step"]) == 4
     assert all(torch.isfinite(g["params"][0]).all() for g in opt.param_groups)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# paths added with the scheduling / readback work
+def test_4k_image_many_tiles(oracle):
+    """3840x2160: 32 400 tiles -> 15 tile bits (two tile passes of 8 + 7 bits), 47-bit reference key."""
+    from gaussianeditor_amd import _native
+
+    assert _native.lib().gsr_sort_key_bits(3840, 2160) == 47
+    case = make_case(30000, 3840, 2160, seed=31, s0=0.01)
+    f, _ = _compare_forward(oracle, case)
+    G = seed_gradient(2160, 3840, 31) * (2160 * 3840)
+    g = oracle_backward(oracle, case, f, G)
+    h = _grads_hip(case, G)
+    for k, v in h.items():
+        assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+@pytest.mark.parametrize("kind", ["flat", "shallow", "deep"])
+def test_depth_key_ranges(oracle, kind):
+    """The depth sort runs ceil(bits/8) passes over the bits in which the smallest and the largest depth key differ
+    (2, 3 or 4): one scene per pass count, order checked against the oracle's full 64-bit-key sort."""
+    P, W, H = 6000, 160, 120
+    case = make_case(P, W, H, seed=33, s0=0.05, nviews=1)
+    g = torch.Generator().manual_seed(5)
+    cam = case["cam"]
+    fwd = -cam.camera_center / cam.camera_center.norm()  # the camera looks at the origin
+    side = torch.linalg.cross(fwd, torch.tensor([0.0, 1.0, 0.0]))
+    side = side / side.norm()
+    up = torch.linalg.cross(side, fwd)
+    u, v = torch.rand(P, generator=g) - 0.5, torch.rand(P, generator=g) - 0.5
+    if kind == "flat":      # one plane facing the camera: depths equal up to a few ulps -> 2 passes
+        d = torch.zeros(P)
+    elif kind == "shallow":  # depth 3.9 .. 4.1
+        d = (torch.rand(P, generator=g) - 0.5) * 0.2
+    else:                   # depth 0.25 .. 60: the keys differ in the exponent bits -> 4 passes
+        d = torch.exp(torch.rand(P, generator=g) * 5.5 - 1.4) - 4.0
+    spread = (4.0 + d) * 0.4
+    case["sc"]["xyz"] = (u * spread)[:, None] * side[None] + (v * spread)[:, None] * up[None] + d[:, None] * fwd[None]
+    case["sc"]["xyz"] = case["sc"]["xyz"].contiguous()
+    f, _ = _compare_forward(oracle, case)
+    depth_bits = np.unique(f["keys"] & np.uint64(0xffffffff))
+    span = int(depth_bits.max()) ^ int(depth_bits.min())
+    assert {"flat": span < (1 << 16), "shallow": (1 << 16) <= span < (1 << 24), "deep": span >= (1 << 24)}[kind], hex(span)
+
+
+def test_backward_twice_and_two_streams(oracle):
+    """(a) the saved state of a forward supports any number of backward calls (work queues re-arm themselves);
+    (b) renders issued on two streams from two host threads do not share any hidden state."""
+    import threading
+
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(20000, 320, 200, seed=35, s0=0.03)
+    sc = case["sc"]
+    dev = lambda t: t.to(DEV)  # noqa: E731
+    rs = settings(case, DEV)
+    leaves = [dev(sc[k]).requires_grad_(True) for k in ("xyz", "features", "opacity", "scaling", "rotation")]
+    m2 = torch.zeros_like(leaves[0], requires_grad=True)
+    color, radii, depth = GaussianRasterizer(rs)(leaves[0], m2, leaves[2], shs=leaves[1], scales=leaves[3], rotations=leaves[4])
+    G = seed_gradient(200, 320, 35).to(DEV) * (200 * 320)
+    g1 = torch.autograd.grad([color], leaves, grad_outputs=[G], retain_graph=True)
+    g2 = torch.autograd.grad([color], leaves, grad_outputs=[G], retain_graph=True)
+    g3 = torch.autograd.grad([color], leaves, grad_outputs=[2 * G])
+    for a, b, c in zip(g1, g2, g3):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= 1e-5
+        assert rel_err(2 * a.cpu().numpy(), c.cpu().numpy()) <= 1e-5
+
+    cases = [make_case(15000 + 1000 * i, 256, 192, seed=40 + i, s0=0.03) for i in range(2)]
+    expect = [oracle_forward(oracle, c)["color"] for c in cases]
+    results = [None, None]
+
+    def work(i):
+        st = torch.cuda.Stream(device=DEV)
+        with torch.cuda.stream(st):
+            for _ in range(5):
+                out = _run_hip_forward(cases[i])
+            st.synchronize()
+        results[i] = out[1].cpu().numpy()
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r, e in zip(results, expect):
+        assert rel_err(r, e) <= 1e-6
