@@ -40,6 +40,9 @@ SIGNATURES = {
     "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
+                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,

@@ -250,18 +250,18 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   return GSR_OK;
 }
 
-int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
-                            const float* scales, float scale_modifier, const float* rotations,
-                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                            const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                            float* dL_dscales, float* dL_drots) {
+static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                    const float* scales, float scale_modifier, const float* rotations,
+                                    const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                    const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                    const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                                    const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                    float* dL_drgb, float* dL_dscales, float* dL_drots) {
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
   if (!dL_dmeans2D || !dL_dconic || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
-  if (shs && (!dL_dsh || !campos)) return GSR_ERR_BAD_ARGUMENT;
+  if (shs && ((!dL_dsh && !dL_drgb) || !campos)) return GSR_ERR_BAD_ARGUMENT;
   if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   PreBwdArgs pa;
@@ -277,9 +277,45 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
   pa.dL_dmean2D = dL_dmeans2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolors;
   pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dcov3D = dL_dcov3D;
   pa.dL_dsh = shs ? dL_dsh : nullptr;
+  pa.dL_drgb = shs ? dL_drgb : nullptr;
   pa.dL_dscale = scales ? dL_dscales : nullptr;
   pa.dL_drot = scales ? dL_drots : nullptr;
   GSR_HIP(launch_preprocess_backward((hipStream_t)stream, pa));
+  return GSR_OK;
+}
+
+int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                            const float* scales, float scale_modifier, const float* rotations,
+                            const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            float* dL_dscales, float* dL_drots) {
+  if (shs && !dL_dsh) return GSR_ERR_BAD_ARGUMENT;
+  return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, nullptr, dL_dscales, dL_drots);
+}
+
+int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                const float* scales, float scale_modifier, const float* rotations,
+                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                                const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
+                                float* dL_dscales, float* dL_drots) {
+  if (!shs || !dL_drgb) return GSR_ERR_BAD_ARGUMENT;
+  return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots);
+}
+
+int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const float* means3D, const float* campos,
+                        const float* dL_drgb, float* dL_dsh) {
+  if (P == 0) return GSR_OK;
+  if (P < 0 || D < 0 || D > 3 || M < (D + 1) * (D + 1) || num_views < 1) return GSR_ERR_BAD_ARGUMENT;
+  if (!means3D || !campos || !dL_drgb || !dL_dsh) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_sh_grad_compose((hipStream_t)stream, P, D, M, num_views, means3D, campos, dL_drgb, dL_dsh));
   return GSR_OK;
 }
 

@@ -47,6 +47,7 @@ struct PreBwdArgs {
   float* dL_dmeans3D;       // (P,3)
   float* dL_dcov3D;         // (P,6)
   float* dL_dsh;            // (P,M,3) | null
+  float* dL_drgb;           // (P,3)   | null: the clamp-masked colour gradient, for gsr_sh_grad_compose
   float* dL_dscale;         // (P,3)   | null
   float* dL_drot;           // (P,4)   | null
 };
@@ -93,6 +94,8 @@ struct BlendArgs {
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a);
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present);
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a);
+hipError_t launch_sh_grad_compose(hipStream_t s, int P, int D, int M, int N, const float* means3D, const float* campos,
+                                  const float* dL_drgb, float* dL_dsh);
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
                               float* conic_opacity, uint8_t* clamped);
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1);

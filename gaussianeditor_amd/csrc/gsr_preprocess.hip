@@ -358,6 +358,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
   V3 dscale = {0.f, 0.f, 0.f};
   float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
+  V3 drgb = {0.f, 0.f, 0.f};  // dL_dRGB with the clamped channels zeroed (output of the "rgb" mode)
 
   if (a.radii[idx] > 0) {
     Cam cam;
@@ -459,6 +460,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
       dL_dRGB.y *= (cl & 2) ? 0.f : 1.f;
       dL_dRGB.z *= (cl & 4) ? 0.f : 1.f;
+      drgb = dL_dRGB;
       V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
       const float x = dir.x, y = dir.y, z = dir.z;
       dsh[0] = SH_C0 * dL_dRGB;
@@ -564,12 +566,79 @@ preprocess_backward_kernel(const PreBwdArgs a) {
 #pragma unroll
   for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
   if (a.dL_dsh != nullptr) store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
+  if (a.dL_drgb != nullptr) {
+    a.dL_drgb[3 * (size_t)idx] = drgb.x;
+    a.dL_drgb[3 * (size_t)idx + 1] = drgb.y;
+    a.dL_drgb[3 * (size_t)idx + 2] = drgb.z;
+  }
   if (a.dL_dscale != nullptr) {
     a.dL_dscale[3 * (size_t)idx] = dscale.x;
     a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
     a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
   }
   if (a.dL_drot != nullptr) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+}
+
+// ----------------------------------------------------------------------------------
+// SH gradient of a BATCH of views from their colour gradients (multi-GPU exchange, gaussianeditor_amd/multiview.py).
+// Per view the SH gradient is rank one: dL_dsh[k] = c_k(dir) * dL_dRGB (backward.cu:44-48, 59-61, 73-77, 92-98), and
+// dir depends only on the Gaussian's position and the view's camera centre.  So N ranks exchange 3 floats per
+// Gaussian and view (all-gather) instead of summing 3M (all-reduce of 192 B per Gaussian at M = 16), and every rank
+// rebuilds sum_v c_k(dir_v) * dL_dRGB_v itself, views in ascending order: the operations and the order of a single
+// process that accumulates the views' gradients one after the other, so all replicas hold bit-identical sums.
+// The c_k are spelled exactly as in preprocess_backward_kernel.
+// ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GAUSS_BLOCK) sh_grad_compose_kernel(int P, int D, int M, int N,
+                                                                     const float* __restrict__ means3D,
+                                                                     const float* __restrict__ campos,  // (N,3)
+                                                                     const float* __restrict__ dL_drgb,  // (N,P,3)
+                                                                     float* __restrict__ dL_dsh) {      // (P,M,3)
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  if (idx >= P) return;
+  const int ncoef = (D + 1) * (D + 1);
+  V3 dsh[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
+  const V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
+  for (int v = 0; v < N; ++v) {
+    const float* g = dL_drgb + ((size_t)v * P + idx) * 3;
+    const V3 dL_dRGB = {g[0], g[1], g[2]};
+    // a view that does not see the Gaussian (or whose colour was clamped in all channels) contributes exact zeros
+    if (dL_dRGB.x == 0.f && dL_dRGB.y == 0.f && dL_dRGB.z == 0.f) continue;
+    const V3 dir_orig = {m.x - campos[3 * v], m.y - campos[3 * v + 1], m.z - campos[3 * v + 2]};
+    const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
+    const float x = dir.x, y = dir.y, z = dir.z;
+    V3 t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = {0.f, 0.f, 0.f};
+    t[0] = SH_C0 * dL_dRGB;
+    if (D > 0) {
+      t[1] = (-SH_C1 * y) * dL_dRGB;
+      t[2] = (SH_C1 * z) * dL_dRGB;
+      t[3] = (-SH_C1 * x) * dL_dRGB;
+      if (D > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        t[4] = (SH_C2[0] * xy) * dL_dRGB;
+        t[5] = (SH_C2[1] * yz) * dL_dRGB;
+        t[6] = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB;
+        t[7] = (SH_C2[3] * xz) * dL_dRGB;
+        t[8] = (SH_C2[4] * (xx - yy)) * dL_dRGB;
+        if (D > 2) {
+          t[9] = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB;
+          t[10] = (SH_C3[1] * xy * z) * dL_dRGB;
+          t[11] = (SH_C3[2] * y * (4.f * zz - xx - yy)) * dL_dRGB;
+          t[12] = (SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * dL_dRGB;
+          t[13] = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
+          t[14] = (SH_C3[5] * z * (xx - yy)) * dL_dRGB;
+          t[15] = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dsh[k] = dsh[k] + t[k];
+  }
+  store_sh_grad(dL_dsh + (size_t)idx * M * 3, M, dsh, ncoef);
 }
 
 // ----------------------------------------------------------------------------------
@@ -609,6 +678,12 @@ hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present) {
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   hipLaunchKernelGGL(mark_visible_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, means3D, view, present);
+  return hipGetLastError();
+}
+hipError_t launch_sh_grad_compose(hipStream_t s, int P, int D, int M, int N, const float* means3D, const float* campos,
+                                  const float* dL_drgb, float* dL_dsh) {
+  const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(sh_grad_compose_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, D, M, N, means3D, campos, dL_drgb, dL_dsh);
   return hipGetLastError();
 }
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a) {

@@ -190,21 +190,57 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         dL_dcolors, dL_dopacity = acc[7 * P:10 * P].view(P, NUM_CHANNELS), acc[10 * P:].view(P, 1)
     dL_dmeans3D = _alloc("means3D", (P, 3), False, dev)
     dL_dcov3D = _alloc("cov3Ds_precomp", (P, 6), False, dev)
-    dL_dsh = _alloc("sh", (P, M, 3), M == 0, dev)
+    # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
+    # colour gradient INSTEAD of the (P,M,3) SH gradient; dL_dsh is then returned as None and rebuilt after the exchange
+    dL_drgb = _grad_allocator("sh_rgb", (P, 3), False) if (_grad_allocator is not None and M != 0) else None
+    dL_dsh = None if dL_drgb is not None else _alloc("sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc("scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc("rotations", (P, 4), not has_scales, dev)
+    L = _native.lib()
     with torch.cuda.device(dev):
-        _native.check("gsr_backward", _native.lib().gsr_backward(
-            _stream(dev), P, int(degree), M, int(R), W, H, background.data_ptr(), means3D.data_ptr(), _ptr(sh),
-            _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
-            viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy),
-            radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
-            dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-            dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
-            dL_drotations.data_ptr() if has_scales else None))
+        if dL_drgb is None:
+            _native.check("gsr_backward", L.gsr_backward(
+                _stream(dev), P, int(degree), M, int(R), W, H, background.data_ptr(), means3D.data_ptr(), _ptr(sh),
+                _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
+                viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy),
+                radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
+                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
+                dL_drotations.data_ptr() if has_scales else None))
+        else:
+            if int(R) > 0:
+                _native.check("gsr_blend_backward", L.gsr_blend_backward(
+                    _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
+                    imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr()))
+            _native.check("gsr_preprocess_backward_rgb", L.gsr_preprocess_backward_rgb(
+                _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
+                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), dL_dmeans2D.data_ptr(),
+                dL_dconic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_drgb.data_ptr(),
+                dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None))
         if debug:
             torch.cuda.synchronize(dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def sh_grad_compose(means3D, campos_all, rgb_all, degree, M):
+    """Extension for the multi-GPU exchange: dL_dsh (P,M,3) = sum over views v (ascending) of c_k(dir_v) * rgb_all[v],
+    from the views' camera centres (N,3) and clamp-masked colour gradients (N,P,3) -- gsr_sh_grad_compose."""
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P, N = int(means3D.size(0)), int(rgb_all.size(0))
+    if rgb_all.shape != (N, P, 3) or campos_all.shape != (N, 3):
+        raise RuntimeError("sh_grad_compose: expected campos (N,3) and colour gradients (N,P,3)")
+    out = torch.empty((P, int(M), 3), dtype=torch.float32, device=dev)
+    if P == 0:
+        return out
+    means3D, campos_all, rgb_all = _f32(means3D, "means3D"), _f32(campos_all, "campos"), _f32(rgb_all, "rgb")
+    with torch.cuda.device(dev):
+        _native.check("gsr_sh_grad_compose", _native.lib().gsr_sh_grad_compose(
+            _stream(dev), P, int(degree), int(M), N, means3D.data_ptr(), campos_all.data_ptr(), rgb_all.data_ptr(),
+            out.data_ptr()))
+    return out
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

@@ -11,6 +11,14 @@ all-reduce (the reference takes `torch.max` over the views, GassuianEditor.py:17
 The bucket is filled without copies: the backward's gradient tensors are *allocated as views
 into the bucket* (see `_C.set_grad_allocator`), so the kernels write straight into the
 buffer RCCL reduces.
+
+The SH gradient is 3M of the bucket's 14+3M floats per Gaussian (77 % at M = 16), but per view it is rank one:
+dL_dsh[k] = c_k(dir) * dL_dRGB with dir = normalize(mean - camera centre) (backward.cu:44-98).  In the "rgb" exchange
+mode (`GradBucket(..., sh_exchange="rgb")`, the default when more than one rank runs) the backward therefore emits
+the 3-float colour gradient instead, the ranks ALL-GATHER those (12 B per Gaussian and view) together with their
+camera centres, and every rank rebuilds the sum over views with one kernel (`gsr_sh_grad_compose`), views in
+ascending rank order -- bit for bit what one process accumulating the views gives, identical on every replica.  The
+SUM all-reduce then carries 14 floats per Gaussian: 56 MB + 12 MB per rank instead of 248 MB at 1 M Gaussians.
 """
 from __future__ import annotations
 
@@ -33,15 +41,25 @@ class GradBucket:
     = (14 + 3M) * P floats (248 MB at P = 1M, M = 16).  means2D and opacities, the two gradients the backward
     accumulates with atomics, are adjacent so that one fill clears both."""
 
-    def __init__(self, P: int, M: int, device):
+    def __init__(self, P: int, M: int, device, sh_exchange: str = "auto"):
         self.P, self.M = int(P), int(M)
+        if sh_exchange == "auto":
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            sh_exchange = "rgb" if (multi and M > 0) else "direct"
+        if sh_exchange not in ("direct", "rgb"):
+            raise ValueError("sh_exchange must be 'auto', 'direct' or 'rgb'")
+        self.sh_exchange = sh_exchange
         shapes = {"means3D": (P, 3), "sh": (P, M, 3), "opacities": (P, 1), "scales": (P, 3), "rotations": (P, 4),
                   "means2D": (P, 3)}
-        n = sum(int(torch.Size(s).numel()) for s in shapes.values())
+        slots = _SLOTS if sh_exchange == "direct" else tuple(s for s in _SLOTS if s != "sh")
+        n = sum(int(torch.Size(shapes[s]).numel()) for s in slots)
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.views: Dict[str, torch.Tensor] = {}
+        #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
+        self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
+        self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
         off = 0
-        for name in _SLOTS:
+        for name in slots:
             cnt = int(torch.Size(shapes[name]).numel())
             # every segment starts on a 16-byte boundary as long as P % 4 == 0; otherwise the kernels'
             # dwordx4 stores on (P,4) rows would be misaligned -> fall back to private tensors for those.
@@ -49,6 +67,8 @@ class GradBucket:
             off += cnt
 
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool) -> Optional[torch.Tensor]:
+        if name == "sh_rgb":  # "rgb" exchange mode: ask the backward for dL_dRGB instead of dL_dsh
+            return self.rgb if (self.rgb is not None and tuple(shape) == (self.P, 3)) else None
         if name == "means2D+opacities":  # one contiguous, zeroed (4P,) block for both accumulators
             m2, op = self.views["means2D"], self.views["opacities"]
             if tuple(shape) != (4 * self.P,) or m2.data_ptr() % 16 != 0 or op.data_ptr() != m2.data_ptr() + 12 * self.P:
@@ -77,6 +97,10 @@ class GradBucket:
     def grads(self) -> Dict[str, torch.Tensor]:
         return dict(self.views)
 
+    def flat_views(self) -> Dict[str, torch.Tensor]:
+        """The segments that live in `flat` (everything except a rebuilt SH gradient in "rgb" mode)."""
+        return {k: v for k, v in self.views.items() if self.sh_exchange == "direct" or k != "sh"}
+
 
 def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
                       dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None):
@@ -89,9 +113,16 @@ def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacitie
     color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
     ctx = bucket.capture() if bucket is not None else contextlib.nullcontext()
     with ctx:
-        g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor])
+        # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by allreduce_view_grads)
+        g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
-    return color.detach(), radii, depth.detach(), dict(zip(names, g))
+    grads = dict(zip(names, g))
+    if bucket is not None and bucket.sh_exchange == "rgb":
+        bucket.sh_degree = int(settings.sh_degree)
+        bucket.means3D_ref = m3.detach()
+        bucket.campos = settings.campos.detach().reshape(3).to(torch.float32)
+        grads["sh"] = None
+    return color.detach(), radii, depth.detach(), grads
 
 
 def _touched_rows(bucket: GradBucket) -> torch.Tensor:
@@ -99,7 +130,7 @@ def _touched_rows(bucket: GradBucket) -> torch.Tensor:
     rank's view blended has an exactly zero row in every segment (the backward writes zeros there)."""
     P = bucket.P
     t = torch.zeros(P, dtype=torch.bool, device=bucket.flat.device)
-    for name, v in bucket.views.items():
+    for name, v in bucket.flat_views().items():
         # dL_dsh[k] = basis_k(dir) * dL_dRGB with basis_0 = SH_C0 != 0 (backward.cu:47-48): the whole SH row is zero
         # iff its coefficient-0 triple is, so the 12(M-1) other bytes per Gaussian need not be scanned.
         rows = v[:, 0, :] if name == "sh" and v.shape[1] > 0 else v.reshape(P, -1)
@@ -120,7 +151,18 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
     back; otherwise the dense bucket is reduced.  Every rank takes the same branch (the mask is reduced), and
     rows outside the union are zero on every rank, so the result equals the dense all-reduce."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if bucket.sh_exchange == "rgb":  # a single view: the "sum" has one term
+            bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
+                                                     bucket.sh_degree, bucket.M)
         return "local"
+    if bucket.sh_exchange == "rgb":
+        # colour gradients + camera centres of all views, then the SH gradient of the batch, rebuilt locally
+        n = dist.get_world_size(group)
+        rgb_all = torch.empty((n, bucket.P, 3), dtype=torch.float32, device=bucket.rgb.device)
+        cam_all = torch.empty((n, 3), dtype=torch.float32, device=bucket.rgb.device)
+        dist.all_gather(list(rgb_all.unbind(0)), bucket.rgb.contiguous(), group=group)
+        dist.all_gather(list(cam_all.unbind(0)), bucket.campos.contiguous(), group=group)
+        bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, cam_all, rgb_all, bucket.sh_degree, bucket.M)
     if radii is not None:
         dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
     mode = "dense"
@@ -130,7 +172,7 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
         dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=group)
         idx = mask.nonzero(as_tuple=False).view(-1)  # one host sync; identical on every rank
         if idx.numel() <= sparse_threshold * P:
-            segs = [v.reshape(P, -1) for v in bucket.views.values()]
+            segs = [v.reshape(P, -1) for v in bucket.flat_views().values()]
             packed = torch.cat([sg.index_select(0, idx) for sg in segs], dim=1)  # (U, 14+3M)
             dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
             off = 0

@@ -142,6 +142,24 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
                             const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                             float* dL_dscales, float* dL_drots);
 
+/* Multi-GPU exchange support (gaussianeditor_amd/multiview.py).  Per view the SH gradient is
+ * rank one, dL_dsh[k] = c_k(dir) * dL_dRGB with dir = normalize(mean - campos) (backward.cu:44-98), so ranks exchange
+ * the 3-float colour gradient per Gaussian and view instead of the 3M-float SH gradient:
+ *   gsr_preprocess_backward_rgb = gsr_preprocess_backward, but instead of dL_dsh it writes dL_drgb (P,3): dL_dcolors
+ *       with the channels the forward clamped at 0 zeroed (zeros for Gaussians the view does not see);
+ *   gsr_sh_grad_compose rebuilds dL_dsh (P,M,3) = sum over v = 0..num_views-1 (ascending, binary32) of
+ *       c_k(dir_v) * dL_drgb[v] from campos (num_views,3) and dL_drgb (num_views,P,3), all device arrays: bit for bit
+ *       what accumulating the views' gsr_preprocess_backward outputs one after the other gives. */
+int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                const float* scales, float scale_modifier, const float* rotations,
+                                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                                const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
+                                float* dL_dscales, float* dL_drots);
+int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const float* means3D, const float* campos,
+                        const float* dL_drgb, float* dL_dsh);
+
 /* K10: present[i] = (view-space z of point i) > 0.2.  Reference: checkFrustum,
  * rasterizer_impl.cu:53-63, 128-133.  `present` is one byte per Gaussian (torch.bool). */
 int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

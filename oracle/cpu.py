@@ -261,3 +261,18 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, row_mask=N
     fn(n, row_len, p.ctypes.data, g.ctypes.data, m.ctypes.data, v.ctypes.data, None if anc is None else anc.ctypes.data,
        float(anchor_scale), None if rw is None else rw.ctypes.data, None if mask is None else mask.ctypes.data,
        int(bool(masked)), float(lr), float(beta1), float(beta2), float(eps), int(step))
+
+
+def sh_grad_compose(means3D, campos_all, rgb_all, D, M) -> np.ndarray:
+    """dL_dsh (P,M,3) of a batch of views from their camera centres (N,3) and clamp-masked colour gradients (N,P,3)."""
+    import ctypes as C
+
+    m, c, r = _f32(means3D), _f32(campos_all), _f32(rgb_all)
+    N, P = r.shape[0], r.shape[1]
+    out = np.zeros((P, M, 3), np.float32)
+    fn = lib().gsro_sh_grad_compose
+    fn.restype = None
+    fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if P:
+        fn(P, int(D), int(M), N, m.ctypes.data, c.ctypes.data, r.ctypes.data, out.ctypes.data)
+    return out

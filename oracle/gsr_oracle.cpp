@@ -926,3 +926,57 @@ extern "C" void gsro_adam_step(long long n, int row_len, float* p, const float* 
     p[e] = p[e] + upd;
   }
 }
+
+// ----------------------------------------------------------------------------------
+// SH gradient of a batch of views from their clamp-masked colour gradients: dL_dsh[k] = sum_v c_k(dir_v) * dL_dRGB_v,
+// views ascending, the c_k of the reference's computeColorFromSH backward (backward.cu:44-48, 59-61, 73-77, 92-98).
+// Restates what accumulating the per-view dL_dsh of the backward gives; used to check the multi-GPU exchange.
+// ----------------------------------------------------------------------------------
+extern "C" void gsro_sh_grad_compose(int P, int D, int M, int N, const float* means3D, const float* campos, const float* rgb,
+                                     float* dL_dsh) {
+  const float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+  const float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f,
+                       0.5462742152960396f};
+  const float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                       -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+  const int ncoef = (D + 1) * (D + 1);
+#pragma omp parallel for
+  for (int i = 0; i < P; ++i) {
+    float acc[16][3];
+    for (int k = 0; k < 16; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+    for (int v = 0; v < N; ++v) {
+      const float* g = rgb + ((size_t)v * P + i) * 3;
+      if (g[0] == 0.f && g[1] == 0.f && g[2] == 0.f) continue;
+      const float ox = means3D[3 * i] - campos[3 * v], oy = means3D[3 * i + 1] - campos[3 * v + 1],
+                  oz = means3D[3 * i + 2] - campos[3 * v + 2];
+      const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+      const float x = ox / len, y = oy / len, z = oz / len;
+      float c[16];
+      for (int k = 0; k < 16; ++k) c[k] = 0.f;
+      c[0] = C0;
+      if (D > 0) {
+        c[1] = -C1 * y; c[2] = C1 * z; c[3] = -C1 * x;
+        if (D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          c[4] = C2[0] * xy; c[5] = C2[1] * yz; c[6] = C2[2] * (2.f * zz - xx - yy); c[7] = C2[3] * xz; c[8] = C2[4] * (xx - yy);
+          if (D > 2) {
+            c[9] = C3[0] * y * (3.f * xx - yy);
+            c[10] = C3[1] * xy * z;
+            c[11] = C3[2] * y * (4.f * zz - xx - yy);
+            c[12] = C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+            c[13] = C3[4] * x * (4.f * zz - xx - yy);
+            c[14] = C3[5] * z * (xx - yy);
+            c[15] = C3[6] * x * (xx - 3.f * yy);
+          }
+        }
+      }
+      for (int k = 0; k < 16; ++k)
+        for (int ch = 0; ch < 3; ++ch) {
+          const float t = k < ncoef ? c[k] * g[ch] : 0.f;
+          acc[k][ch] = acc[k][ch] + t;
+        }
+    }
+    for (int k = 0; k < M; ++k)
+      for (int ch = 0; ch < 3; ++ch) dL_dsh[((size_t)i * M + k) * 3 + ch] = (k < ncoef && k < 16) ? acc[k][ch] : 0.f;
+  }
+}

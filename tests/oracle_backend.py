@@ -54,10 +54,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                              ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
                              ("cov3Ds_precomp", "dL_dcov3D", (P, 6)), ("sh", "dL_dsh", (P, M, 3)),
                              ("scales", "dL_dscales", (P, 3)), ("rotations", "dL_drotations", (P, 4))):
+        if name == "sh" and M != 0 and real_C._grad_allocator is not None:
+            rgb = real_C._grad_allocator("sh_rgb", (P, 3), False)
+            if rgb is not None:  # "rgb" exchange mode: the clamp-masked colour gradient instead of dL_dsh
+                vis = (f["radii"] > 0)[:, None]
+                masked = np.where(np.logical_and(vis, f["clamped"] == 0), g["dL_dcolors"].reshape(P, 3), 0.0)
+                rgb.copy_(torch.from_numpy(np.ascontiguousarray(masked, dtype=np.float32)))
+                out.append(None)
+                continue
         t = real_C._alloc(name, shape, False, means3D.device)  # honours the gradient-bucket allocator
         t.copy_(torch.from_numpy(np.ascontiguousarray(g[key])).reshape(shape))
         out.append(t)
     return tuple(out)
+
+
+def sh_grad_compose(means3D, campos_all, rgb_all, degree, M):
+    return torch.from_numpy(O.sh_grad_compose(means3D.detach().cpu().numpy(), campos_all.cpu().numpy(), rgb_all.cpu().numpy(),
+                                              int(degree), int(M)))
 
 
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
@@ -89,6 +102,6 @@ def install(monkeypatch):
     """Route the drop-in's native calls to the oracle for the duration of one test."""
     import gaussianeditor_amd.diff_gaussian_rasterization as dgr
 
-    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_aux", "mark_visible",
-                 "apply_weights"):
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_aux", "sh_grad_compose",
+                 "mark_visible", "apply_weights"):
         monkeypatch.setattr(dgr._C, name, globals()[name])

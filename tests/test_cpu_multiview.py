@@ -23,6 +23,37 @@ def _free_port():
     return p
 
 
+def _worker_rgb(rank, world, port, out_dir):
+    """The "rgb" exchange: colour gradients all-gathered, SH gradient rebuilt on every rank."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytest as _pt
+
+    import oracle_backend
+    from gaussianeditor_amd.multiview import GradBucket, allreduce_view_grads, render_view_grads
+
+    mpatch = _pt.MonkeyPatch()
+    oracle_backend.install(mpatch)
+    try:
+        case = make_case(P, W, H, seed=5, s0=0.07, view=rank, nviews=world)
+        sc = case["sc"]
+        bucket = GradBucket(P, 16, "cpu")  # "auto" -> "rgb" because two ranks run
+        assert bucket.sh_exchange == "rgb" and bucket.flat.numel() == P * 14
+        G = seed_gradient(H, W, 100 + rank) * H * W
+        color, radii, depth, grads = render_view_grads(settings(case, "cpu"), sc["xyz"], sc["opacity"], sc["features"],
+                                                       sc["scaling"], sc["rotation"], G, bucket)
+        assert grads["sh"] is None
+        mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0))
+        np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=bucket.flat.numpy(), sh=bucket.views["sh"].numpy(),
+                 radii=radii.numpy(), mode=np.array([mode == "sparse"]))
+    finally:
+        mpatch.undo()
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, out_dir):
     import sys
 
@@ -39,7 +70,7 @@ def _worker(rank, world, port, out_dir):
     try:
         case = make_case(P, W, H, seed=5, s0=0.07, view=rank, nviews=world)
         sc = case["sc"]
-        bucket = GradBucket(P, 16, "cpu")
+        bucket = GradBucket(P, 16, "cpu", sh_exchange="direct")  # the SH gradient travels inside the all-reduced bucket
         G = seed_gradient(H, W, 100 + rank) * H * W
         params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
         from gaussianeditor_amd.multiview import allreduce_view_grads, render_view_grads
@@ -85,6 +116,40 @@ def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
         rad = f["radii"] if rad is None else np.maximum(rad, f["radii"])
     assert rel_err(r0["flat"], tot) < 1e-6
     assert np.array_equal(r0["radii"], rad)
+
+
+def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path):
+    world = 2
+    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "rgb_rank0.npz"), np.load(tmp_path / "rgb_rank1.npz")
+    # replicas agree bit for bit, including the SH gradient each of them rebuilt on its own
+    for k in ("flat", "sh", "radii"):
+        assert np.array_equal(r0[k], r1[k]), k
+    tot, sh = None, None
+    for v in range(world):
+        case = make_case(P, W, H, seed=5, s0=0.07, view=v, nviews=world)
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
+        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dmeans2D",
+                                                          "dL_dopacity")])
+        tot = flat if tot is None else tot + flat
+        sh = g["dL_dsh"] if sh is None else sh + g["dL_dsh"]  # a single process accumulates view after view
+    assert rel_err(r0["flat"], tot) < 1e-6
+    # rebuilt from 3 floats per view = the accumulated per-view SH gradients, bit for bit
+    assert np.array_equal(r0["sh"], sh.reshape(r0["sh"].shape))
+
+
+def test_sh_grad_compose_oracle_equals_backward_sh(oracle):
+    """The restated composition against the backward's own dL_dsh, one view, degrees 0-3."""
+    for D in (0, 1, 2, 3):
+        case = make_case(1500, 96, 64, seed=7 + D, s0=0.06, sh_degree=3)
+        case["D"] = D
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(64, 96, 3) * 64 * 96)
+        vis = (f["radii"] > 0)[:, None]
+        rgb = np.where(np.logical_and(vis, f["clamped"] == 0), g["dL_dcolors"].reshape(-1, 3), 0.0).astype(np.float32)
+        sh = oracle.sh_grad_compose(case["sc"]["xyz"].numpy(), case["cam"].camera_center.numpy()[None], rgb[None], D, 16)
+        assert np.array_equal(sh, g["dL_dsh"].reshape(sh.shape)), D
 
 
 def test_bucket_layout_and_allocator():
