@@ -62,11 +62,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the rasterizer has no CPU fallback)")
+    # GSR_BENCH_SHARED_GPU=1 (testing only): run all ranks on GPU 0 with the gloo backend, to exercise the multi-rank
+    # code path on a box with a single GPU.  The numbers of such a run mean nothing.
+    shared = os.environ.get("GSR_BENCH_SHARED_GPU", "0") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from gaussianeditor_amd import _native
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
