@@ -23,6 +23,11 @@ class AdamTensor(ctypes.Structure):
                 ("row_len", ctypes.c_int32), ("masked", ctypes.c_int32), ("lr", ctypes.c_double), ("anchor_scale", c_float)]
 
 
+class CompactTensor(ctypes.Structure):
+    """gsr_compact_tensor (include/gsr.h)."""
+    _fields_ = [("src", _P), ("dst", _P), ("row_bytes", c_int64)]
+
+
 #: every symbol include/gsr.h declares, with (restype, argtypes)
 SIGNATURES = {
     "gsr_abi_version": (c_int, []),
@@ -45,6 +50,9 @@ SIGNATURES = {
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
+    "gsr_compact_workspace_size": (c_int, [c_int64, POINTER(c_size_t)]),
+    "gsr_compact_plan": (c_int, [_P, c_int64, _P, _P, POINTER(c_int64)]),
+    "gsr_compact_apply": (c_int, [_P, c_int64, _P, _P, c_int, POINTER(CompactTensor)]),
     "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
                             _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),

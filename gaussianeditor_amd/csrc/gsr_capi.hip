@@ -391,6 +391,37 @@ int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors,
   return GSR_OK;
 }
 
+int gsr_compact_workspace_size(int64_t P, size_t* bytes) {
+  if (P < 0 || !bytes) return GSR_ERR_BAD_ARGUMENT;
+  *bytes = compact_workspace_bytes(P);
+  return GSR_OK;
+}
+
+int gsr_compact_plan(void* stream, int64_t P, const uint8_t* keep, void* workspace, int64_t* kept_host) {
+  if (!kept_host) return GSR_ERR_BAD_ARGUMENT;
+  *kept_host = 0;
+  if (P == 0) return GSR_OK;
+  if (P < 0 || P >= (1ll << 32) - 1024 || !keep || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  GSR_HIP(launch_compact_plan(s, P, keep, workspace));
+  uint64_t total = 0;
+  GSR_HIP(hipMemcpyAsync(&total, compact_total_ptr(workspace, P), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  *kept_host = (int64_t)total;
+  return GSR_OK;
+}
+
+int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* workspace, int num_tensors,
+                      const gsr_compact_tensor* tensors) {
+  if (P == 0 || num_tensors == 0) return GSR_OK;
+  if (P < 0 || num_tensors < 0 || num_tensors > 32 || !keep || !workspace || !tensors) return GSR_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < num_tensors; ++i)
+    if (!tensors[i].src || tensors[i].row_bytes < 1 || tensors[i].row_bytes > (1 << 20)) return GSR_ERR_BAD_ARGUMENT;
+  // dst may be NULL only if nothing survives; the kernel then writes nothing
+  GSR_HIP(launch_compact_apply((hipStream_t)stream, P, keep, workspace, num_tensors, tensors));
+  return GSR_OK;
+}
+
 int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
                           float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
   if (P <= 0) return GSR_OK;

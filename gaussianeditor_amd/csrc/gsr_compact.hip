@@ -1,0 +1,139 @@
+// gsr_compact.hip -- stable stream compaction of the rows of MANY tensors by one keep mask (SURVEY.md section 8(f)
+// rank 4).
+//
+// The reference prunes its model with boolean-mask indexing, one tensor at a time: six parameters, their twelve Adam
+// moment tensors and five bookkeeping tensors (gaussiansplatting/scene/gaussian_model.py:568-609, prune_points /
+// _prune_optimizer): 23 x (nonzero + host sync + gather).  Here the mask is scanned once (one host readback for the
+// number of survivors, needed to size the outputs) and one launch moves the surviving rows of every tensor; the order
+// of the survivors is the original one, so the result is what `tensor[mask]` returns, bit for bit.
+#include <string.h>
+
+#include "gsr_kernels.h"
+
+namespace gsr {
+
+constexpr int CMP_ROWS = 1024;  // rows per block
+constexpr int CMP_MAX_TENSORS = 32;
+
+struct CompactWork {
+  uint32_t* block_count;  // (nb)
+  uint32_t* block_off;    // (nb) exclusive prefix
+  uint64_t* total;        // (1)
+  size_t bytes;
+};
+__host__ __device__ inline CompactWork carve_compact(void* base, int64_t P) {
+  char* p = (char*)base;
+  const size_t nb = ((size_t)P + CMP_ROWS - 1) / CMP_ROWS;
+  CompactWork w;
+  size_t off = 0;
+  w.total = (uint64_t*)(p + off);        off += 256;
+  w.block_count = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * nb);
+  w.block_off = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * nb);
+  w.bytes = off;
+  return w;
+}
+size_t compact_workspace_bytes(int64_t P) { return carve_compact(nullptr, P).bytes; }
+
+__global__ void __launch_bounds__(CMP_ROWS) compact_count_kernel(int64_t P, const uint8_t* __restrict__ keep,
+                                                                uint32_t* __restrict__ block_count) {
+  __shared__ uint32_t smem[CMP_ROWS / 64 + 1];
+  const int64_t r = (int64_t)blockIdx.x * CMP_ROWS + threadIdx.x;
+  const uint32_t k = (r < P && keep[r] != 0) ? 1u : 0u;
+  uint32_t total;
+  (void)block_excl_scan_u32<CMP_ROWS>(k, &total, smem);
+  if (threadIdx.x == 0) block_count[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) compact_scan_kernel(int64_t nb, const uint32_t* __restrict__ cnt,
+                                                           uint32_t* __restrict__ off, uint64_t* __restrict__ total) {
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  uint64_t carry = 0;
+  for (int64_t base = 0; base < nb; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? cnt[i] : 0u;
+    uint32_t chunk;
+    const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
+    if (i < nb) off[i] = (uint32_t)carry + ex;
+    carry += chunk;
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+struct CompactTensorDev {
+  const uint8_t* src;
+  uint8_t* dst;
+  uint32_t row_bytes;
+};
+struct CompactArgs {
+  CompactTensorDev t[CMP_MAX_TENSORS];
+  int64_t P;
+  const uint8_t* keep;
+  const uint32_t* block_off;
+};
+
+// grid = (row blocks, tensors)
+__global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactArgs a) {
+  __shared__ uint32_t smem[CMP_ROWS / 64 + 1];
+  __shared__ uint32_t pos[CMP_ROWS];
+  const int64_t row0 = (int64_t)blockIdx.x * CMP_ROWS;
+  const int64_t r = row0 + threadIdx.x;
+  const uint32_t k = (r < a.P && a.keep[r] != 0) ? 1u : 0u;
+  uint32_t total;
+  const uint32_t ex = block_excl_scan_u32<CMP_ROWS>(k, &total, smem);
+  pos[threadIdx.x] = k ? a.block_off[blockIdx.x] + ex : 0xffffffffu;
+  __syncthreads();
+  if (total == 0) return;
+  const CompactTensorDev t = a.t[blockIdx.y];
+  const uint32_t nrows = (uint32_t)min((int64_t)CMP_ROWS, a.P - row0);
+  if ((t.row_bytes & 3u) == 0 && (((uintptr_t)t.src | (uintptr_t)t.dst) & 3u) == 0) {
+    const uint32_t W = t.row_bytes >> 2;
+    const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(t.src) + (size_t)row0 * W;
+    uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(t.dst);
+    const uint32_t n = nrows * W;
+    for (uint32_t e = threadIdx.x; e < n; e += CMP_ROWS) {
+      const uint32_t rr = e / W, c = e - rr * W;
+      const uint32_t p = pos[rr];
+      if (p != 0xffffffffu) d[(size_t)p * W + c] = s[e];
+    }
+  } else {
+    const uint32_t W = t.row_bytes;
+    const uint8_t* __restrict__ s = t.src + (size_t)row0 * W;
+    const uint32_t n = nrows * W;
+    for (uint32_t e = threadIdx.x; e < n; e += CMP_ROWS) {
+      const uint32_t rr = e / W, c = e - rr * W;
+      const uint32_t p = pos[rr];
+      if (p != 0xffffffffu) t.dst[(size_t)p * W + c] = s[e];
+    }
+  }
+}
+
+hipError_t launch_compact_plan(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace) {
+  const CompactWork w = carve_compact(workspace, P);
+  const int64_t nb = (P + CMP_ROWS - 1) / CMP_ROWS;
+  hipLaunchKernelGGL(compact_count_kernel, dim3((unsigned)nb), dim3(CMP_ROWS), 0, s, P, keep, w.block_count);
+  hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, nb, w.block_count, w.block_off, w.total);
+  return hipGetLastError();
+}
+const uint64_t* compact_total_ptr(void* workspace, int64_t P) { return carve_compact(workspace, P).total; }
+
+hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace, int nt,
+                                const gsr_compact_tensor* tensors) {
+  if (nt <= 0 || P <= 0) return hipSuccess;
+  if (nt > CMP_MAX_TENSORS) return hipErrorInvalidValue;
+  const CompactWork w = carve_compact(workspace, P);
+  CompactArgs a;
+  memset(&a, 0, sizeof(a));
+  a.P = P;
+  a.keep = keep;
+  a.block_off = w.block_off;
+  for (int i = 0; i < nt; ++i) {
+    a.t[i].src = (const uint8_t*)tensors[i].src;
+    a.t[i].dst = (uint8_t*)tensors[i].dst;
+    a.t[i].row_bytes = (uint32_t)tensors[i].row_bytes;
+  }
+  const int64_t nb = (P + CMP_ROWS - 1) / CMP_ROWS;
+  hipLaunchKernelGGL(compact_apply_kernel, dim3((unsigned)nb, (unsigned)nt), dim3(CMP_ROWS), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace gsr

@@ -209,6 +209,25 @@ typedef struct gsr_adam_tensor {
 int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
                   double eps, const uint8_t* row_mask, const float* row_weight);
 
+/* ---- prune = stable compaction of the rows of many tensors by one mask ----
+ * Replaces the per-tensor boolean-mask indexing of GaussianModel.prune_points / _prune_optimizer
+ * (gaussiansplatting/scene/gaussian_model.py:568-609: parameters, Adam moments, bookkeeping tensors).
+ *   gsr_compact_plan   scans keep (P bytes, 0/1, device) into `workspace` (gsr_compact_workspace_size(P) bytes of device
+ *                      scratch) and returns the number of surviving rows in *kept_host (one blocking readback: the
+ *                      caller sizes the outputs with it);
+ *   gsr_compact_apply  one launch: for every tensor copies the surviving rows, in their original order, from src
+ *                      (P rows of row_bytes) to dst (kept rows) -- what `tensor[mask]` returns.  At most 32 tensors per
+ *                      call; src and dst must not overlap. */
+typedef struct gsr_compact_tensor {
+  const void* src;
+  void* dst;
+  int64_t row_bytes;
+} gsr_compact_tensor;
+int gsr_compact_workspace_size(int64_t P, size_t* bytes);
+int gsr_compact_plan(void* stream, int64_t P, const uint8_t* keep, void* workspace, int64_t* kept_host);
+int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* workspace, int num_tensors,
+                      const gsr_compact_tensor* tensors);
+
 /* ---- introspection used by the parity tests (not needed by the drop-in) ----
  * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
  * scratch buffers into caller-provided DEVICE arrays (any may be NULL):

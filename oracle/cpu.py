@@ -276,3 +276,10 @@ def sh_grad_compose(means3D, campos_all, rgb_all, D, M) -> np.ndarray:
     if P:
         fn(P, int(D), int(M), N, m.ctypes.data, c.ctypes.data, r.ctypes.data, out.ctypes.data)
     return out
+
+
+def compact_rows(arrays, keep):
+    """Prune restated: the rows of every array where `keep` is set, in their original order (numpy boolean indexing =
+    what `tensor[mask]` does in GaussianModel._prune_optimizer, gaussian_model.py:568-591)."""
+    k = np.asarray(keep).astype(bool)
+    return [np.ascontiguousarray(np.asarray(a)[k]) for a in arrays]

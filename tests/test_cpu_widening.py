@@ -224,3 +224,14 @@ def test_fused_adam_has_no_cpu_fallback():
         pytest.skip("libgsr_hip.so not built")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         opt.step()
+
+
+def test_oracle_compact_rows_is_boolean_indexing(oracle):
+    import torch
+
+    g = torch.Generator().manual_seed(0)
+    keep = torch.rand(1000, generator=g) > 0.3
+    ts = [torch.randn(1000, 3, generator=g), torch.randn(1000, 15, 3, generator=g), torch.arange(1000), keep.clone()]
+    out = oracle.compact_rows([t.numpy() for t in ts], keep.numpy())
+    for o, t in zip(out, ts):
+        assert np.array_equal(o, t[keep].numpy())

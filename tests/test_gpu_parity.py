@@ -671,3 +671,58 @@ def test_sh_grad_rebuilt_from_colour_gradients(oracle, D):
     assert rel_err(rebuilt.cpu().numpy(), direct_sum.cpu().numpy()) <= 1e-5
     ref = oracle.sh_grad_compose(m3.cpu().numpy(), torch.stack(cams).cpu().numpy(), torch.stack(rgbs).cpu().numpy(), D, 16)
     assert np.array_equal(rebuilt.cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prune = one compaction for all tensors (gsr_compact_plan / gsr_compact_apply)
+@pytest.mark.parametrize("P,frac", [(1, 1.0), (5, 0.0), (1023, 0.5), (1025, 0.5), (100000, 0.9), (100000, 0.01)])
+def test_compact_rows_equals_boolean_indexing(oracle, P, frac):
+    from gaussianeditor_amd.densify import compact_rows
+
+    g = torch.Generator().manual_seed(P)
+    keep = torch.rand(P, generator=g) < frac
+    ts = [torch.randn(P, 3, generator=g), torch.randn(P, 15, 3, generator=g), torch.randn(P, 1, generator=g),
+          torch.randn(P, 4, generator=g), torch.arange(P, dtype=torch.int64), keep.clone(), torch.randn(P, generator=g),
+          torch.randint(0, 255, (P, 3), generator=g, dtype=torch.uint8)]  # incl. 1-byte and 3-byte rows
+    out = compact_rows([t.to(DEV) for t in ts], keep.to(DEV))
+    ref = oracle.compact_rows([t.numpy() for t in ts], keep.numpy())
+    for o, r, t in zip(out, ref, ts):
+        assert o.dtype == t.dtype and tuple(o.shape[1:]) == tuple(t.shape[1:])
+        assert np.array_equal(o.cpu().numpy(), r)
+        assert torch.equal(o.cpu(), t[keep])
+
+
+def test_prune_optimizer_like_reference():
+    """prune_optimizer == GaussianModel._prune_optimizer (gaussian_model.py:568-591) on an Adam with state."""
+    from gaussianeditor_amd.densify import prune_optimizer
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    P = 5000
+    init, lrs, gen = _adam_groups(P, 9)
+
+    def build():
+        params = {k: v.clone().to(DEV).requires_grad_(True) for k, v in init.items()}
+        opt = FusedMaskedAdam([{"params": [p], "lr": lrs[k], "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)
+        g2 = torch.Generator().manual_seed(1)
+        for p in params.values():
+            p.grad = torch.randn(p.shape, generator=g2).to(DEV)
+        opt.step()
+        return opt
+
+    keep = (torch.rand(P, generator=gen) > 0.25).to(DEV)
+    a, b = build(), build()
+    new = prune_optimizer(a, keep)
+    for group in b.param_groups:  # the reference's loop
+        st = b.state.get(group["params"][0], None)
+        st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"][keep], st["exp_avg_sq"][keep]
+        del b.state[group["params"][0]]
+        group["params"][0] = torch.nn.Parameter(group["params"][0][keep].requires_grad_(True))
+        b.state[group["params"][0]] = st
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert new[ga["name"]] is pa and pa.requires_grad and torch.equal(pa, pb)
+        assert torch.equal(a.state[pa]["exp_avg"], b.state[pb]["exp_avg"])
+        assert torch.equal(a.state[pa]["exp_avg_sq"], b.state[pb]["exp_avg_sq"])
+    for p in (g["params"][0] for g in a.param_groups):
+        p.grad = torch.ones_like(p)
+    a.step()  # the pruned optimizer keeps working
