@@ -109,7 +109,9 @@ def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacitie
     rasterizer-input gradients (views of `bucket` when one is given)."""
     leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
     m3, sh, op, sc, rot = leaves
-    m2 = torch.zeros_like(m3, requires_grad=True)
+    # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
+    # not zero-filled here (the reference's render() does: gaussian_renderer/__init__.py:60-69)
+    m2 = torch.empty_like(m3).requires_grad_(True)
     color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
     ctx = bucket.capture() if bucket is not None else contextlib.nullcontext()
     with ctx:
