@@ -59,6 +59,8 @@ SIGNATURES = {
     "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_export_binning": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "gsr_debug_blend_backward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                 c_int64, POINTER(c_int64)]),
     "gsr_debug_blend_forward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                                 POINTER(c_int64)]),
     "gsr_debug_export_image": (c_int, [_P, c_int, c_int, _P, _P, _P, _P]),

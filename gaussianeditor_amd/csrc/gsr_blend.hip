@@ -613,12 +613,29 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
   const uint32_t nwork = a.work_meta[0];
   const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
   uint32_t* head = a.queue + x * QUEUE_STRIDE;
+  // debug timing (gsr_debug_blend_backward_profile): per workgroup start / end, tiles, longest and first tile
+  const bool prof = a.profile != nullptr;
+  uint64_t t_begin = 0, t_tile = 0, longest = 0, first = 0;
+  uint32_t ntiles = 0, west = 0;
+  if (prof) t_begin = __builtin_amdgcn_s_memtime();
+  auto run_tile = [&](uint32_t tile) {
+    if (prof) t_tile = __builtin_amdgcn_s_memtime();
+    backward_tile<ABLATE>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
+    if (prof) {
+      const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
+      if (ntiles == 0) first = d;
+      longest = d > longest ? d : longest;
+      ntiles++;
+      if (a.work_est != nullptr)
+        west += a.work_est[4u * tile] + a.work_est[4u * tile + 1] + a.work_est[4u * tile + 2] + a.work_est[4u * tile + 3];
+    }
+  };
   // first tile assigned by placement (see first_item_of_block), the rest popped
   uint32_t x0, base;
   const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   {
     const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
-    if (q0 < n0) backward_tile<ABLATE>(a, a.work_order[x0 + 8u * q0], s0, s1, s2, sid, sacc, s_maxc);
+    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);
   }
   for (;;) {
     __syncthreads();
@@ -627,7 +644,17 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
     const uint32_t q = s_item;
     __syncthreads();
     if (q >= n_x) break;
-    backward_tile<ABLATE>(a, a.work_order[x + 8u * q], s0, s1, s2, sid, sacc, s_maxc);
+    run_tile(a.work_order[x + 8u * q]);
+  }
+  if (prof && threadIdx.x == 0) {
+    uint64_t* rec = a.profile + (size_t)blockIdx.x * 8;
+    rec[0] = t_begin;
+    rec[1] = __builtin_amdgcn_s_memtime();
+    rec[2] = ((uint64_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 32) |
+             (uint64_t)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);
+    rec[3] = ((uint64_t)ntiles << 32) | (uint64_t)west;
+    rec[4] = longest;
+    rec[5] = first;
   }
   if (a.self_reset && threadIdx.x == 0) retire_queue(a.queue);
 }

@@ -284,6 +284,31 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   return GSR_OK;
 }
 
+int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                                     const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
+                                     float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
+                                     int64_t max_records, int64_t* n_records_host) {
+  if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
+  const int64_t n = (int64_t)blend_grid_size() / 4;
+  *n_records_host = n;
+  if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
+  if (P < 0 || R <= 0 || W <= 0 || H <= 0 || !bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
+  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors) return GSR_ERR_BAD_ARGUMENT;
+  const Geom g = carve_geom(const_cast<void*>(geom), P);
+  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Image im = carve_image(const_cast<void*>(image), W, H);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
+  a.dL_dpix = dL_dpix;
+  a.dL_dmean2D = dL_dmeans2D;
+  a.dL_dconic = dL_dconic;
+  a.dL_dopacity = dL_dopacity;
+  a.dL_dcolors = dL_dcolors;
+  a.profile = records;
+  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 8 * (size_t)n, (hipStream_t)stream));
+  GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
+  return GSR_OK;
+}
+
 int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,

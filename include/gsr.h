@@ -246,6 +246,12 @@ int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32
  * items<<32 | entries evaluated, cycles chunk start -> survivors staged, cycles in the group loops, chunks walked,
  * cycles chunk start -> cull ballot}; records of workgroups that exit before doing any work stay zero.  *n_records_host = number of workgroups (call with max_records = 0
  * to query; returns GSR_ERR_BAD_ARGUMENT in that case after setting it). */
+/* The same for K7: one record of 8 x u64 per 4-wave workgroup: {start, end, XCC_ID<<32 | HW_ID, tiles<<32 | forward work
+ * estimate of those tiles, longest tile (ticks), first tile (ticks), 0, 0}.  Arguments as gsr_blend_backward. */
+int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
+                                     const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
+                                     float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
+                                     int64_t max_records, int64_t* n_records_host);
 int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                                     const void* binning, void* image, float* out_color, float* out_depth,
                                     uint64_t* records, int64_t max_records, int64_t* n_records_host);
