@@ -312,8 +312,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint3
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
-                                                            uint32_t* __restrict__ queues) {
+                                                            uint32_t* __restrict__ queues, uint32_t* __restrict__ est) {
   __shared__ uint32_t hist[WORK_BUCKETS + 1], cursor[WORK_BUCKETS + 1];
+  // per-quadrant work counters of the forward blend (the items of a quadrant combine their counts with atomicMax)
+  for (int i = threadIdx.x; i < 4 * T; i += 1024) est[i] = 0u;
   // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
   // own zeroed again (gsr_blend.hip: retire_queue), so this is the only place that clears them
   for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) {
@@ -355,7 +357,7 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                       im.queue_heads);
+                       im.queue_heads, im.work_est);
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
@@ -365,7 +367,7 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
   const int64_t nbr = (R + 255) / 256;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.tkey[b.final_buf], im.ranges);
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                       im.queue_heads);
+                       im.queue_heads, im.work_est);
   return hipGetLastError();
 }
 

@@ -92,21 +92,29 @@ __device__ __forceinline__ uint32_t first_item_of_block(uint32_t units, uint32_t
   return (slot & 1u) ? (slot + 1u) * n - 1u - u : slot * n + u;
 }
 
-template <class F>
+template <int SPLIT, class F>
 __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
   const uint32_t nwork = a.work_meta[0];
   const uint32_t T = (uint32_t)(a.gx * a.gy);
   const uint32_t nempty = with_empty ? T - nwork : 0u;
   // queue x (one per XCD) owns entries x, x+8, ... of work_order: 4 quadrant items per non-empty tile, then one item
   // per empty tile
+  // Granularity: a quadrant is one item, unless that leaves fewer than two items per persistent wave (small images,
+  // e.g. the editor's 512x512 views: 1024 tiles for 4096 waves): then every quadrant is cut into 2 (8x4 pixels) or 4
+  // (4x4) items, which trades lane utilisation the chip is not using anyway for shorter serial chains and finer
+  // culling.  The item code passed on is quad | sub << 2, decoded by the item function.
+  constexpr uint32_t split = (uint32_t)SPLIT;  // chosen by the launcher from the number of tiles of the image
+  constexpr uint32_t per_tile = 4u * split;
   auto run_item = [&](uint32_t x, uint32_t q) -> bool {
     const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
     const uint32_t e_x = nempty > x ? (nempty - x + 7u) / 8u : 0u;
-    if (q >= 4u * n_x + e_x) return false;
-    if (q < 4u * n_x)
-      item(a.work_order[x + 8u * (q >> 2)], q & 3u, false);
-    else
-      item(a.work_order[nwork + x + 8u * (q - 4u * n_x)], 0u, true);
+    if (q >= per_tile * n_x + e_x) return false;
+    if (q < per_tile * n_x) {
+      const uint32_t t = q / per_tile, r = q - t * per_tile;  // r = quad * split + sub
+      item(a.work_order[x + 8u * t], split == 1u ? r : ((r / split) | ((r % split) << 2)), false);
+    } else {
+      item(a.work_order[nwork + x + 8u * (q - per_tile * n_x)], 0u, true);
+    }
     return true;
   };
   uint32_t x0, base;
@@ -164,7 +172,8 @@ struct Entry {
   float4 r0, r1, r2;
 };
 
-__device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r1, float qx0, float qy0) {
+__device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r1, float qx0, float qy0,
+                                               float qw = (float)(QUAD - 1), float qh = (float)(QUAD - 1)) {
   // r0 = conic.x, conic.y, conic.z, opacity; r1 = mean.x, mean.y, depth, radius
   const float o = r0.w;
   if (!(o >= 1.0f / 255.0f)) return !(o == o) ? true : false;  // o < 1/255: alpha < 1/255 everywhere (NaN: keep)
@@ -175,8 +184,7 @@ __device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r
   const float hx = __builtin_sqrtf(tau2 * r0.z * inv) + 0.01f;
   const float hy = __builtin_sqrtf(tau2 * r0.x * inv) + 0.01f;
   if (!(hx == hx) || !(hy == hy)) return true;
-  const bool out = (r1.x + hx < qx0) || (r1.x - hx > qx0 + (float)(QUAD - 1)) || (r1.y + hy < qy0) ||
-                   (r1.y - hy > qy0 + (float)(QUAD - 1));
+  const bool out = (r1.x + hx < qx0) || (r1.x - hx > qx0 + qw) || (r1.y + hy < qy0) || (r1.y - hy > qy0 + qh);
   return !out;
 }
 
@@ -239,18 +247,30 @@ struct ChunkWalker {
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-template <bool PROFILE, bool AUX>
+template <bool PROFILE, bool AUX, int SPLIT>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
                                              uint64_t* prof_cyc) {
   PixelWave pw;
-  if (!setup_wave(a, tile, quad, pw)) {
-    if (a.work_est != nullptr && lane_id() == 0) a.work_est[4u * tile + quad] = 0u;
-    return;
-  }
+  // item code: quad | sub << 2 (SPLIT = 1: the whole quadrant)
+  constexpr uint32_t split = (uint32_t)SPLIT;
+  const uint32_t sub = (quad >> 2) & 3u;
+  quad &= 3u;
+  if (!setup_wave(a, tile, quad, pw)) return;  // (work_est was cleared by tile_worklist_kernel)
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
+  float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
+  float qw = (float)(QUAD - 1), qh = (float)(QUAD - 1);
+  if (split == 2u) {  // rows [4 sub, 4 sub + 4)
+    pw.inside = pw.inside && ((uint32_t)(lane >> 5) == sub);
+    qy0 += 4.0f * (float)sub;
+    qh = 3.0f;
+  } else if (split == 4u) {  // the 4x4 block (sub & 1, sub >> 1)
+    pw.inside = pw.inside && ((uint32_t)((lane >> 2) & 1) == (sub & 1u)) && ((uint32_t)(lane >> 5) == (sub >> 1));
+    qx0 += 4.0f * (float)(sub & 1u);
+    qy0 += 4.0f * (float)(sub >> 1);
+    qw = qh = 3.0f;
+  }
   bool done = !pw.inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last_contributor = 0;
@@ -267,7 +287,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
         tc0 = __builtin_amdgcn_s_memtime();
         prof_cyc[2]++;  // chunks walked
       }
-      const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+      const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0, qw, qh);
       const uint64_t m = __ballot(keep);
       if (PROFILE) prof_cyc[3] += __builtin_amdgcn_s_memtime() - tc0;  // wait for the chunk's records + cull
       if (m == 0) continue;
@@ -332,7 +352,8 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       if (PROFILE) prof_cyc[1] += __builtin_amdgcn_s_memtime() - tc1;  // group loop
     }
   }
-  if (a.work_est != nullptr && lane == 0) a.work_est[4u * tile + quad] = evaluated;
+  // (the sub-items of a cut quadrant report the largest of their counts: they walk the same list)
+  if (a.work_est != nullptr && lane == 0) atomicMax(&a.work_est[4u * tile + quad], evaluated);
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
     if (a.final_T != nullptr) {  // (null in an auxiliary render: the state the backward needs stays that of the main one)
@@ -346,19 +367,18 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   }
 }
 
-template <bool PROFILE, bool AUX>
+template <bool PROFILE, bool AUX, int SPLIT>
 __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
   uint64_t prof_cyc[4] = {0, 0, 0, 0};
   if (PROFILE) t_start = __builtin_amdgcn_s_memtime();
-  run_work_queue(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
+  run_work_queue<SPLIT>(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE, AUX>(a, tile, quad, prof_visited, prof_cyc);
+      forward_item<PROFILE, AUX, SPLIT>(a, tile, quad, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
-      if (a.work_est != nullptr && lane_id() < 4) a.work_est[4u * tile + (uint32_t)lane_id()] = 0u;
       for (uint32_t q = 0; q < 4; ++q) {
         PixelWave pw;
         if (!setup_wave(a, tile, q, pw)) continue;
@@ -743,7 +763,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
 
 template <int C>
 __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
-  run_work_queue(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C>(a, tile, quad); });
+  run_work_queue<1>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C>(a, tile, quad); });
 }
 
 // Work list of the backward blend: tiles ordered by the work the FORWARD blend measured for them (entries evaluated,
@@ -826,12 +846,23 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(1);
+  static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
+  a.allow_split = split_ok ? 1 : 0;
+  // fewer than two quadrant items per persistent wave (bounded by the tile count of the image): cut the quadrants
+  const unsigned grid = blend_grid_size(), quads = 4u * (unsigned)(a.gx * a.gy);
+  const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
+  const dim3 g(grid), b(WAVE);
   if (a.profile)
-    hipLaunchKernelGGL((blend_forward_kernel<true, false>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
-  else if (a.colors3 != nullptr)
-    hipLaunchKernelGGL((blend_forward_kernel<false, true>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
-  else
-    hipLaunchKernelGGL((blend_forward_kernel<false, false>), dim3(blend_grid_size()), dim3(WAVE), 0, s, a);
+    hipLaunchKernelGGL((blend_forward_kernel<true, false, 1>), g, b, 0, s, a);
+  else if (a.colors3 != nullptr) {
+    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, true, 1>), g, b, 0, s, a);
+    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, true, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((blend_forward_kernel<false, true, 4>), g, b, 0, s, a);
+  } else {
+    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, false, 1>), g, b, 0, s, a);
+    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, false, 2>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((blend_forward_kernel<false, false, 4>), g, b, 0, s, a);
+  }
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {

@@ -86,6 +86,7 @@ struct BlendArgs {
   float* weights;
   int32_t* cnt;
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
+  int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile;
