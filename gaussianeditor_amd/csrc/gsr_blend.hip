@@ -431,7 +431,11 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile
+constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile (or two quadrants of a heavy one)
+constexpr uint32_t BWD_ITEM_HALF = 0x80000000u;   // item code: the workgroup handles one half of the tile ...
+constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead of {0,1}
+constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
+
 
 // One tile, processed by a 4-wave workgroup (wave w = quadrant w).  The four waves walk the tile's list
 // back to front in the SAME 64-entry chunks; each wave culls / compacts / evaluates the chunk for its own
@@ -444,11 +448,22 @@ template <int ABLATE>  // 0 = product; 1..4 = timing experiments only (wrong res
 __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
                                               float4 (*s2)[WAVE], uint32_t* sid, float (*sacc)[WAVE], uint32_t* s_maxc) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
+  // item code (backward_worklist_kernel): a whole tile, wave w = quadrant w; or half a tile, waves (0,1) and (2,3) =
+  // the upper / lower 8x4 pixels of its two quadrants
+  const bool half_item = (tile & BWD_ITEM_HALF) != 0u;
+  const uint32_t part = (tile & BWD_ITEM_PART) ? 1u : 0u;
+  tile &= BWD_ITEM_TILE;
   PixelWave pw;
-  const bool has_pixels = setup_wave(a, tile, (uint32_t)w, pw);
+  const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
   const uint2 range = a.ranges[tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
+  const float qx0 = (float)(pw.px - (lane & 7));
+  float qy0 = (float)(pw.py - (lane >> 3)), qh = (float)(QUAD - 1);
+  if (half_item) {
+    pw.inside = pw.inside && ((lane >> 5) == (w & 1));
+    qy0 += 4.0f * (float)(w & 1);
+    qh = 3.0f;
+  }
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   const bool live = has_pixels && pw.inside;
 
@@ -484,7 +499,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
     const uint32_t csize = walk.chunk_size();
     if (w == 0 && (uint32_t)lane < csize) sid[lane] = walk.cur.id;
     const uint32_t pos = walk.lane_pos();
-    const bool keep = ((uint32_t)lane < csize) && (pos < maxc) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+    const bool keep = ((uint32_t)lane < csize) && (pos < maxc) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0, (float)(QUAD - 1), qh);
     const uint64_t m = __ballot(keep);
     const uint32_t cnt = (uint32_t)__popcll(m);
     const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
@@ -646,8 +661,15 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
       if (ntiles == 0) first = d;
       longest = d > longest ? d : longest;
       ntiles++;
-      if (a.work_est != nullptr)
-        west += a.work_est[4u * tile] + a.work_est[4u * tile + 1] + a.work_est[4u * tile + 2] + a.work_est[4u * tile + 3];
+      if (a.work_est != nullptr) {
+        const uint32_t tt = tile & BWD_ITEM_TILE;
+        if (tile & BWD_ITEM_HALF) {
+          const uint32_t q0 = (tile & BWD_ITEM_PART) ? 2u : 0u;
+          west += a.work_est[4u * tt + q0] + a.work_est[4u * tt + q0 + 1];
+        } else {
+          west += a.work_est[4u * tt] + a.work_est[4u * tt + 1] + a.work_est[4u * tt + 2] + a.work_est[4u * tt + 3];
+        }
+      }
     }
   };
   // first tile assigned by placement (see first_item_of_block), the rest popped
@@ -773,17 +795,43 @@ __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) 
 // One 1024-thread block (T is a few thousand); the order inside a bucket depends on LDS-atomic timing: scheduling
 // only, never results.
 constexpr int BWD_BUCKETS = 256;
+// A tile whose work comes close to a workgroup's fair share of the whole launch would decide the run time on its own
+// (the kernel ends with its longest tile: measured 505 K of 509 K cycles).  Such tiles are cut into two items, each
+// a workgroup that covers TWO quadrants with two waves per quadrant (8x4 pixels per wave): half the tile per
+// workgroup, and the finer culling shortens the waves' lists as well.  `workgroups` = size of the launch.
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
-                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta) {
+                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
+                                                                uint32_t workgroups, int allow_halves) {  // allow_halves: 0, or the threshold in 1/8 of a fair share
   __shared__ uint32_t hist[BWD_BUCKETS + 1], cursor[BWD_BUCKETS + 1];
+  __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint32_t s_threshold;
   for (int i = threadIdx.x; i <= BWD_BUCKETS; i += 1024) hist[i] = 0;
+  // total work -> the weight above which a tile is cut
+  uint32_t mine = 0;
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+    mine += e.x + e.y + e.z + e.w;
+  }
+  uint32_t total;
+  (void)block_excl_scan_u32<1024>(mine, &total, smem);
+  if (threadIdx.x == 0)
+    s_threshold = allow_halves ? max(64u, (uint32_t)((uint64_t)total * (uint32_t)allow_halves / (8u * max(workgroups, 1u)))) : 0xffffffffu;
   __syncthreads();
-  auto bucket_of = [](uint4 e) -> uint32_t {
-    const uint32_t w = e.x + e.y + e.z + e.w;
+  const uint32_t threshold = s_threshold;
+  auto bucket_of = [](uint32_t w) -> uint32_t {
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
   };
-  for (int t = threadIdx.x; t < T; t += 1024) atomicAdd(&hist[bucket_of(reinterpret_cast<const uint4*>(est)[t])], 1u);
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+    const uint32_t w = e.x + e.y + e.z + e.w;
+    if (w >= threshold) {
+      atomicAdd(&hist[bucket_of(e.x + e.y)], 1u);
+      atomicAdd(&hist[bucket_of(e.z + e.w)], 1u);
+    } else {
+      atomicAdd(&hist[bucket_of(w)], 1u);
+    }
+  }
   __syncthreads();
   if (threadIdx.x < 64) {  // exclusive scan of the bucket sizes by one wave
     uint32_t run = 0;
@@ -796,11 +844,17 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) meta[0] = cursor[BWD_BUCKETS];  // number of tiles with work
+  if (threadIdx.x == 0) meta[0] = cursor[BWD_BUCKETS];  // number of items with work
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint32_t pos = atomicAdd(&cursor[bucket_of(reinterpret_cast<const uint4*>(est)[t])], 1u);
-    order[pos] = (uint32_t)t;
+    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+    const uint32_t w = e.x + e.y + e.z + e.w;
+    if (w >= threshold) {
+      order[atomicAdd(&cursor[bucket_of(e.x + e.y)], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
+      order[atomicAdd(&cursor[bucket_of(e.z + e.w)], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
+    } else {
+      order[atomicAdd(&cursor[bucket_of(w)], 1u)] = (uint32_t)t;
+    }
   }
 }
 
@@ -872,7 +926,9 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
   static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
   if (own_list && a.work_est != nullptr) {
-    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta);
+    static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
+    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta,
+                       blend_grid_size() / BWD_WAVES, halves);
     a.work_order = a.bwd_order;
     a.work_meta = a.bwd_meta;
   } else {

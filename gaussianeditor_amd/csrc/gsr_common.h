@@ -91,7 +91,8 @@ struct Image {
   uint32_t* work_order; // (T)  tile ids: non-empty tiles, longest list first (bucketed), then the empty tiles
   uint32_t* work_meta;  // [0] = number of non-empty tiles
   uint32_t* work_est;   // (T,4) entries the forward blend evaluated per (tile, quadrant): the backward's work estimate
-  uint32_t* bwd_order;  // (T)  tile ids for the backward blend: most forward work first, tiles without any work dropped
+  uint32_t* bwd_order;  // (2T) items of the backward blend (a tile, or half of a heavy tile): most forward work first,
+                        //      tiles without any work dropped
   uint32_t* bwd_meta;   // [0] = number of tiles in bwd_order
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
   size_t bytes;
@@ -108,7 +109,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * T);
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 4 * T);
-  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
+  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * 2 * T);
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
   im.bytes = off;
