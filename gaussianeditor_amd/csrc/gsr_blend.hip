@@ -707,15 +707,30 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
 // mask value(s) to weights[id] and C to cnt[id] (the reference increments cnt inside its
 // channel loop, apply_weights.cu:331-339).
 // ----------------------------------------------------------------------------------
-template <int C>
+template <int C, int SPLIT>
 __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
+  // item code as in forward_item: quad | sub << 2 (SPLIT = 1: the whole quadrant)
+  constexpr uint32_t split = (uint32_t)SPLIT;
+  const uint32_t sub = (quad >> 2) & 3u;
+  quad &= 3u;
   if (!setup_wave(a, tile, quad, pw)) return;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
+  float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
+  float qw = (float)(QUAD - 1), qh = (float)(QUAD - 1);
+  if (split == 2u) {
+    pw.inside = pw.inside && ((uint32_t)(lane >> 5) == sub);
+    qy0 += 4.0f * (float)sub;
+    qh = 3.0f;
+  } else if (split == 4u) {
+    pw.inside = pw.inside && ((uint32_t)((lane >> 2) & 1) == (sub & 1u)) && ((uint32_t)(lane >> 5) == (sub >> 1));
+    qx0 += 4.0f * (float)(sub & 1u);
+    qy0 += 4.0f * (float)(sub >> 1);
+    qw = qh = 3.0f;
+  }
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   float Cw[C];
 #pragma unroll
@@ -731,7 +746,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   ChunkWalker<true> walk(a, range.x, range.y - range.x);
   for (; walk.valid(); walk.advance()) {
     if (__all(done)) break;
-    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0);
+    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0, qw, qh);
     const uint64_t km = __ballot(keep);
     if (km == 0) continue;
     const uint32_t n = (uint32_t)__popcll(km);
@@ -783,9 +798,9 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   }
 }
 
-template <int C>
+template <int C, int SPLIT>
 __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
-  run_work_queue<1>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C>(a, tile, quad); });
+  run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C, SPLIT>(a, tile, quad); });
 }
 
 // Work list of the backward blend: tiles ordered by the work the FORWARD blend measured for them (entries evaluated,
@@ -951,13 +966,23 @@ hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size());
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(1);
-  const unsigned grid = blend_grid_size();
+  const unsigned grid = blend_grid_size(), quads = 4u * (unsigned)(a.gx * a.gy);
+  static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
+  const int split = !split_ok || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);  // as the forward
+  const dim3 g(grid), b(WAVE);
+#define GSR_TRACE_LAUNCH(CC)                                                                     \
+  do {                                                                                           \
+    if (split == 1) hipLaunchKernelGGL((trace_weights_kernel<CC, 1>), g, b, 0, s, a);             \
+    else if (split == 2) hipLaunchKernelGGL((trace_weights_kernel<CC, 2>), g, b, 0, s, a);        \
+    else hipLaunchKernelGGL((trace_weights_kernel<CC, 4>), g, b, 0, s, a);                        \
+  } while (0)
   switch (a.C) {
-    case 1: hipLaunchKernelGGL(trace_weights_kernel<1>, dim3(grid), dim3(WAVE), 0, s, a); break;
-    case 2: hipLaunchKernelGGL(trace_weights_kernel<2>, dim3(grid), dim3(WAVE), 0, s, a); break;
-    case 3: hipLaunchKernelGGL(trace_weights_kernel<3>, dim3(grid), dim3(WAVE), 0, s, a); break;
+    case 1: GSR_TRACE_LAUNCH(1); break;
+    case 2: GSR_TRACE_LAUNCH(2); break;
+    case 3: GSR_TRACE_LAUNCH(3); break;
     default: return hipErrorInvalidValue;
   }
+#undef GSR_TRACE_LAUNCH
   return hipGetLastError();
 }
 
