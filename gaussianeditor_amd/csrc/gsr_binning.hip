@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
   // own zeroed again (gsr_blend.hip: retire_queue), so this is the only place that clears them
   for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) {
     queues[(size_t)i * QUEUE_STRIDE] = 0u;      // taken from the front / counter
-    queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // taken from the back (two-ended cursors)
+    queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // (second word of the line: spare)
   }
   for (int i = threadIdx.x; i <= WORK_BUCKETS; i += 1024) hist[i] = 0;
   __syncthreads();
