@@ -127,3 +127,31 @@ class Reference:
                                          ctypes.c_float(tanfovy), _p(iw), _p(radii), _p(cnt), int(iw.shape[0]))
         if rc != 0:
             raise RuntimeError("reference apply_weights failed")
+
+
+# ---- the reference's simple-knn (oracle/_ref/libknn_ref*.so) ----
+_knn_libs: Dict[str, ctypes.CDLL] = {}
+
+
+def knn_lib_path(variant: str = "nofma") -> str:
+    return os.path.join(_HERE, "_ref", "libknn_ref_nofma.so" if variant == "nofma" else "libknn_ref.so")
+
+
+def knn_available(variant: str = "nofma") -> bool:
+    return os.path.exists(knn_lib_path(variant))
+
+
+def knn_mean_dist2(points: torch.Tensor, variant: str = "nofma") -> torch.Tensor:
+    """SimpleKNN::knn of the reference (simple_knn.cu:185-221) on a (P,3) float32 CUDA tensor -> (P,) float32."""
+    if variant not in _knn_libs:
+        L = ctypes.CDLL(knn_lib_path(variant))
+        L.gsrref_knn.restype = ctypes.c_int
+        L.gsrref_knn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _knn_libs[variant] = L
+    pts = points.contiguous()
+    out = torch.zeros(pts.shape[0], dtype=torch.float32, device=pts.device)
+    torch.cuda.synchronize()
+    rc = _knn_libs[variant].gsrref_knn(int(pts.shape[0]), pts.data_ptr(), out.data_ptr())
+    if rc != 0:
+        raise RuntimeError(f"reference SimpleKNN::knn failed ({rc})")
+    return out

@@ -151,3 +151,26 @@ def test_apply_weights_vs_reference():
     print("cnt mismatch fraction vs reference", mism, "total", int(c_ref.sum()))
     assert mism < 2e-3 and abs(int(cnt.sum()) - int(c_ref.sum())) <= 1e-4 * int(c_ref.sum()) + 8
     assert float((w - w_ref).abs().max()) <= 2.0
+
+
+@pytest.mark.parametrize("P,kind", [(5000, "uniform"), (200000, "uniform"), (100000, "clustered")])
+def test_knn_vs_reference_simple_knn(P, kind):
+    """distCUDA2 against the reference's own simple_knn.cu compiled for gfx950: bit-identical to the contraction-free
+    build (both round dx*dx + dy*dy + dz*dz operation by operation), within one rounding of the default (FMA) build."""
+    from gaussianeditor_amd.simple_knn._C import distCUDA2
+    from oracle import ref as R
+
+    if not R.knn_available("nofma"):
+        pytest.skip("oracle/_ref/libknn_ref_nofma.so not built (needs /root/reference at build time)")
+    g = torch.Generator().manual_seed(P)
+    pts = torch.rand(P, 3, generator=g) * 2 - 1
+    if kind == "clustered":
+        pts = pts * 0.01 + torch.randint(0, 5, (P, 3), generator=g).float()
+    pts = pts.to(DEV)
+    mine = distCUDA2(pts)
+    ref_nofma = R.knn_mean_dist2(pts, "nofma")
+    assert torch.equal(mine, ref_nofma)
+    if R.knn_available("fma"):
+        ref_fma = R.knn_mean_dist2(pts, "fma")
+        rel = ((mine - ref_fma).abs() / ref_fma.abs().clamp_min(1e-30)).max()
+        assert float(rel) <= 1e-6
