@@ -112,9 +112,21 @@ def main():
         allreduce_view_grads(bucket, radii)
         return radii
 
-    for _ in range(args.warmup):
-        train_step()
-    sync_all()
+    exchange = bucket.sh_exchange
+    try:
+        for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+            train_step()
+        sync_all()
+    except Exception as e:  # the colour-gradient exchange has only ever run on gloo: keep the run alive if RCCL objects
+        if world == 1 or bucket.sh_exchange != "rgb":
+            raise
+        print(f"[bench] rank {rank}: 'rgb' gradient exchange failed ({type(e).__name__}: {e}); falling back to the dense "
+              "all-reduce of the SH gradient", file=sys.stderr, flush=True)
+        bucket = GradBucket(P, M, dev, sh_exchange="direct")
+        exchange = "direct(fallback)"
+        for _ in range(max(args.warmup, 1)):
+            train_step()
+        sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         radii = train_step()
@@ -244,6 +256,7 @@ def main():
             "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16), {W}x{H}, ring-v1 8 views, one view per GPU "
                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
+                       "grad_exchange": exchange,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
             "forward_renders_per_s": renders_per_s,
             "forward_mpixels_per_s": renders_per_s * N / 1e6,
