@@ -168,6 +168,10 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
     if radii is not None:
         dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
     mode = "dense"
+    if sparse == "auto":
+        # worth its extra collective, host sync and pack / unpack kernels only for the 248 MB bucket that carries the SH
+        # gradient; the 56 MB bucket of the colour-gradient exchange is reduced densely
+        sparse = bucket.sh_exchange == "direct"
     if sparse:
         P = bucket.P
         mask = _touched_rows(bucket).to(torch.uint8)
