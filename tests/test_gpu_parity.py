@@ -726,3 +726,39 @@ def test_prune_optimizer_like_reference():
     for p in (g["params"][0] for g in a.param_groups):
         p.grad = torch.ones_like(p)
     a.step()  # the pruned optimizer keeps working
+
+
+def test_c_abi_host_without_torch(tmp_path):
+    """examples/c_abi_render.cpp links libgsr_hip.so from plain C++ (hipMalloc'd buffers, no torch, no Python) and must
+    produce the very image the drop-in binding renders -- the boundary carries no hidden torch state."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_abi_render")
+    if not os.path.exists(exe):
+        pytest.fail("examples/c_abi_render is not built (run __graft_entry__.build())")
+    case = make_case(20000, 320, 200, seed=11, s0=0.03)
+    sc, cam = case["sc"], case["cam"]
+    P, M = sc["features"].shape[0], sc["features"].shape[1]
+    scene = tmp_path / "scene.bin"
+    with open(scene, "wb") as f:
+        np.array([P, case["D"], M, case["W"], case["H"]], np.int32).tofile(f)
+        np.array([case["tfx"], case["tfy"], 1.0], np.float32).tofile(f)
+        for t in (case["bg"], sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"],
+                  cam.world_view_transform, cam.full_proj_transform, cam.camera_center):
+            t.contiguous().numpy().astype(np.float32).tofile(f)
+    out = tmp_path / "out.bin"
+    r = subprocess.run([exe, str(scene), str(out)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    R, color, depth, radii, *_ = _run_hip_forward(case)
+    W, H = case["W"], case["H"]
+    with open(out, "rb") as f:
+        R_c = int(np.fromfile(f, np.int64, 1)[0])
+        color_c = np.fromfile(f, np.float32, 3 * H * W).reshape(3, H, W)
+        depth_c = np.fromfile(f, np.float32, H * W).reshape(1, H, W)
+        radii_c = np.fromfile(f, np.int32, P)
+    assert R_c == R and R > 0
+    assert np.array_equal(radii_c, radii.cpu().numpy())
+    assert np.array_equal(color_c, color.cpu().numpy())
+    assert np.array_equal(depth_c, depth.cpu().numpy())
