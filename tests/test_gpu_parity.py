@@ -104,11 +104,11 @@ def test_forward_scale_modifier_and_culling(oracle):
     assert (f["radii"] == 0).any() and (f["radii"] > 0).any()
 
 
-def _grads_hip(case, G, colors_precomp=None, cov3D_precomp=None, D=None):
+def _grads_hip(case, G, colors_precomp=None, cov3D_precomp=None, D=None, scale_modifier=1.0):
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
 
     sc = case["sc"]
-    rs = settings(case, DEV, D=D)
+    rs = settings(case, DEV, D=D, scale_modifier=scale_modifier)
     leaf = lambda t: t.to(DEV).clone().requires_grad_(True)  # noqa: E731
     xyz, op = leaf(sc["xyz"]), leaf(sc["opacity"])
     m2d = torch.zeros_like(xyz, requires_grad=True)
@@ -300,6 +300,26 @@ def test_edge_geometries(oracle, P, W, H, s0, scale_xyz):
     h = _grads_hip(case, G)
     for k, v in h.items():
         assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_sweep(oracle, seed):
+    """Seeded random shapes: odd image sizes down to one pixel, any SH degree, P from 1 to a few thousand, random
+    splat size / scene scale / scale_modifier / view.  Forward stage by stage and all six gradients against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    P = int([1, 2, 63, 65, 255, 256][seed] if seed < 6 else rng.integers(300, 6000))
+    W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 3 == 0 else rng.integers(1, 400))
+    H = int(rng.choice([1, 3, 16, 47]) if seed % 4 == 1 else rng.integers(1, 300))
+    D = int(rng.integers(0, 4))
+    case = make_case(P, W, H, seed=100 + seed, s0=float(rng.choice([0.01, 0.05, 0.3])), view=int(rng.integers(0, 4)),
+                     sh_degree=D, scale_xyz=float(rng.choice([0.2, 1.0, 2.5])))
+    sm = float(rng.choice([0.5, 1.0, 1.7]))
+    f, _ = _compare_forward(oracle, case, scale_modifier=sm)
+    G = seed_gradient(H, W, seed) * (H * W)
+    g = oracle_backward(oracle, case, f, G, scale_modifier=sm)
+    h = _grads_hip(case, G, scale_modifier=sm)
+    for k, v in h.items():
+        assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, (k, P, W, H, D, sm)
 
 
 def test_degenerate_inputs(oracle):
