@@ -106,10 +106,15 @@ def main():
         return float(t.item())
 
     # ---------------- train step: fwd + bwd + all-reduce ----------------
+    route = {"last": "local"}
+    # GSR_BENCH_ROWS=0|1 (testing): force the dense / the touched-rows form of the exchange instead of choosing by bytes
+    rows_env = os.environ.get("GSR_BENCH_ROWS")
+    rows_mode = "auto" if rows_env is None else (rows_env == "1")
+
     def train_step():
         color, radii, depth, grads = render_view_grads(rs, params["xyz"], params["opacity"], params["features"],
                                                        params["scaling"], params["rotation"], G, bucket)
-        allreduce_view_grads(bucket, radii)
+        route["last"] = allreduce_view_grads(bucket, radii, rows=rows_mode)
         return radii
 
     exchange = bucket.sh_exchange
@@ -256,7 +261,8 @@ def main():
             "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16), {W}x{H}, ring-v1 8 views, one view per GPU "
                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
-                       "grad_exchange": exchange,
+                       "grad_exchange": exchange, "grad_exchange_route": route["last"],
+                       "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
             "forward_renders_per_s": renders_per_s,
             "forward_mpixels_per_s": renders_per_s * N / 1e6,

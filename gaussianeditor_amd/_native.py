@@ -23,6 +23,11 @@ class AdamTensor(ctypes.Structure):
                 ("row_len", ctypes.c_int32), ("masked", ctypes.c_int32), ("lr", ctypes.c_double), ("anchor_scale", c_float)]
 
 
+class DenseGrads(ctypes.Structure):
+    """gsr_dense_grads (include/gsr.h)."""
+    _fields_ = [("means3D", _P), ("scales", _P), ("rotations", _P), ("means2D", _P), ("opacities", _P), ("sh", _P)]
+
+
 class CompactTensor(ctypes.Structure):
     """gsr_compact_tensor (include/gsr.h)."""
     _fields_ = [("src", _P), ("dst", _P), ("row_bytes", c_int64)]
@@ -48,6 +53,10 @@ SIGNATURES = {
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                             c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "gsr_view_message_words": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
+    "gsr_view_message_plan": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, POINTER(c_int64)]),
+    "gsr_view_message_pack": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, _P, c_int64, _P]),
+    "gsr_view_messages_accumulate": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads)]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "gsr_compact_workspace_size": (c_int, [c_int64, POINTER(c_size_t)]),

@@ -344,6 +344,69 @@ int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const 
   return GSR_OK;
 }
 
+int gsr_view_message_words(int64_t P, int64_t cap, int64_t* words) {
+  if (P < 0 || cap < 0 || !words) return GSR_ERR_BAD_ARGUMENT;
+  *words = view_message_words_host(P, cap);
+  return GSR_OK;
+}
+
+static bool dense_grads_complete(const gsr_dense_grads* g) {
+  return g && g->means3D && g->scales && g->rotations && g->means2D && g->opacities;
+}
+
+int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
+                          void* workspace, int64_t* count_host) {
+  if (!count_host) return GSR_ERR_BAD_ARGUMENT;
+  *count_host = 0;
+  if (P == 0) return GSR_OK;
+  if (P < 0 || !dense_grads_complete(local) || !rgb || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const float* data[6] = {local->means3D, local->scales, local->rotations, local->means2D, local->opacities, rgb};
+  const int row_len[6] = {3, 3, 4, 3, 1, 3};
+  GSR_HIP(launch_touched_rows(s, P, 6, data, row_len, mask));
+  GSR_HIP(launch_compact_plan(s, P, mask, workspace));
+  uint64_t total = 0;
+  GSR_HIP(hipMemcpyAsync(&total, compact_total_ptr(workspace, P), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+  GSR_HIP(hipStreamSynchronize(s));
+  *count_host = (int64_t)total;
+  return GSR_OK;
+}
+
+int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
+                          const uint8_t* mask, void* workspace, int64_t cap, float* message) {
+  if (P < 0 || cap < 0 || !message || !campos) return GSR_ERR_BAD_ARGUMENT;
+  if (P > 0 && (!dense_grads_complete(local) || !rgb || !mask || !workspace)) return GSR_ERR_BAD_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  if (P == 0) {  // header only: camera centre, count 0
+    GSR_HIP(hipMemcpyAsync(message, campos, 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    GSR_HIP(hipMemsetAsync(message + 3, 0, sizeof(float), s));
+    return GSR_OK;
+  }
+  const int64_t nb = (P + VIEW_MSG_ROWS - 1) / VIEW_MSG_ROWS;
+  float* rows = message + 4 + nb;
+  const gsr_compact_tensor t[7] = {{nullptr, rows, 4},  // the row numbers themselves
+                                   {local->means3D, rows + cap, 12},
+                                   {local->scales, rows + 4 * cap, 12},
+                                   {local->rotations, rows + 7 * cap, 16},
+                                   {local->means2D, rows + 11 * cap, 12},
+                                   {local->opacities, rows + 14 * cap, 4},
+                                   {rgb, rows + 15 * cap, 12}};
+  GSR_HIP(launch_compact_apply(s, P, mask, workspace, 7, t));
+  GSR_HIP(launch_view_message_header(s, P, campos, compact_block_off_ptr(workspace, P), compact_total_ptr(workspace, P), message));
+  return GSR_OK;
+}
+
+int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
+                                 int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out) {
+  if (P == 0) return GSR_OK;
+  if (P < 0 || num_views < 1 || !messages || cap < 0 || stride_words < view_message_words_host(P, cap)) return GSR_ERR_BAD_ARGUMENT;
+  if (!dense_grads_complete(out)) return GSR_ERR_BAD_ARGUMENT;
+  if (out->sh && (!means3D || D < 0 || D > 3 || M < (D + 1) * (D + 1))) return GSR_ERR_BAD_ARGUMENT;
+  float* const d[6] = {out->means3D, out->scales, out->rotations, out->means2D, out->opacities, out->sh};
+  GSR_HIP(launch_view_messages_accumulate((hipStream_t)stream, P, D, M, num_views, messages, stride_words, cap, means3D, d));
+  return GSR_OK;
+}
+
 int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,

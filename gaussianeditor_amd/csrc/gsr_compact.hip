@@ -12,7 +12,7 @@
 
 namespace gsr {
 
-constexpr int CMP_ROWS = 1024;  // rows per block
+constexpr int CMP_ROWS = VIEW_MSG_ROWS;  // rows per block (1024; the view messages of the multi-GPU exchange carry block_off)
 constexpr int CMP_MAX_TENSORS = 32;
 
 struct CompactWork {
@@ -85,6 +85,11 @@ __global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactAr
   if (total == 0) return;
   const CompactTensorDev t = a.t[blockIdx.y];
   const uint32_t nrows = (uint32_t)min((int64_t)CMP_ROWS, a.P - row0);
+  if (t.src == nullptr) {  // "iota" source: the surviving row numbers themselves (int32), internal callers only
+    const uint32_t p = pos[threadIdx.x];
+    if (p != 0xffffffffu) reinterpret_cast<int32_t*>(t.dst)[p] = (int32_t)r;
+    return;
+  }
   if ((t.row_bytes & 3u) == 0 && (((uintptr_t)t.src | (uintptr_t)t.dst) & 3u) == 0) {
     const uint32_t W = t.row_bytes >> 2;
     const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(t.src) + (size_t)row0 * W;
@@ -115,6 +120,7 @@ hipError_t launch_compact_plan(hipStream_t s, int64_t P, const uint8_t* keep, vo
   return hipGetLastError();
 }
 const uint64_t* compact_total_ptr(void* workspace, int64_t P) { return carve_compact(workspace, P).total; }
+const uint32_t* compact_block_off_ptr(void* workspace, int64_t P) { return carve_compact(workspace, P).block_off; }
 
 hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace, int nt,
                                 const gsr_compact_tensor* tensors) {

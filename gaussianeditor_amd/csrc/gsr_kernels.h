@@ -97,6 +97,17 @@ hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a);
 hipError_t launch_sh_grad_compose(hipStream_t s, int P, int D, int M, int N, const float* means3D, const float* campos,
                                   const float* dL_drgb, float* dL_dsh);
+// "touched rows" exchange (gsr_preprocess.hip): mask of rows with a non-zero entry in any of up to 8 row-major tensors;
+// a view's message = header (camera centre, count, compaction block offsets) + packed rows; all views' messages added
+// per Gaussian in view order into the dense gradients (dense: means3D, scales, rotations, means2D, opacities, sh | null)
+constexpr int VIEW_MSG_ROWS = 1024;  // rows per block of the message's offset table == the compaction's block (gsr_compact.hip)
+hipError_t launch_touched_rows(hipStream_t s, int64_t P, int nt, const float* const* data, const int* row_len, uint8_t* mask);
+int64_t view_message_words_host(int64_t P, int64_t cap);
+hipError_t launch_view_message_header(hipStream_t s, int64_t P, const float* campos, const uint32_t* block_off,
+                                      const uint64_t* total, float* msg);
+hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int M, int n_views, const float* messages,
+                                           int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6]);
+const uint32_t* compact_block_off_ptr(void* workspace, int64_t P);
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
                               float* conic_opacity, uint8_t* clamped);
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1);

@@ -243,6 +243,59 @@ def sh_grad_compose(means3D, campos_all, rgb_all, degree, M):
     return out
 
 
+# --- "touched rows" form of the multi-GPU exchange (gaussianeditor_amd/multiview.py; include/gsr.h: view messages) -----
+def _dense_grads(tensors):
+    """gsr_dense_grads from [means3D, scales, rotations, means2D, opacities, sh | None] (contiguous float32)."""
+    return _native.DenseGrads(*[0 if t is None else t.data_ptr() for t in tensors])
+
+
+def view_message_words(P, cap):
+    n = ctypes.c_int64(0)
+    _native.check("gsr_view_message_words", _native.lib().gsr_view_message_words(int(P), int(cap), ctypes.byref(n)))
+    return int(n.value)
+
+
+def view_message_plan(grads5, rgb):
+    """Marks the rows of this view's gradients (means3D, scales, rotations, means2D, opacities + colour gradient) that are
+    not entirely zero.  Returns (plan, count); `count` costs one host readback."""
+    _require_cuda(rgb, "rgb")
+    dev, P = rgb.device, int(rgb.size(0))
+    if P == 0:
+        return (None, None, 0, dev), 0
+    L = _native.lib()
+    mask = torch.empty(P, dtype=torch.uint8, device=dev)
+    nbytes = ctypes.c_size_t(0)
+    _native.check("gsr_compact_workspace_size", L.gsr_compact_workspace_size(P, ctypes.byref(nbytes)))
+    work = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
+    count = ctypes.c_int64(0)
+    dg = _dense_grads(list(grads5) + [None])
+    with torch.cuda.device(dev):
+        _native.check("gsr_view_message_plan", L.gsr_view_message_plan(_stream(dev), P, ctypes.byref(dg), rgb.data_ptr(),
+                                                                        mask.data_ptr(), work.data_ptr(), ctypes.byref(count)))
+    return (mask, work, P, dev), int(count.value)
+
+
+def view_message_pack(plan, grads5, rgb, campos, cap, message):
+    """Writes this view's message (gsr_view_message_words(P, cap) float32 words) into `message`."""
+    mask, work, P, dev = plan
+    dg = _dense_grads(list(grads5) + [None])
+    ptr = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    with torch.cuda.device(dev):
+        _native.check("gsr_view_message_pack", _native.lib().gsr_view_message_pack(
+            _stream(dev), P, ctypes.byref(dg), ptr(rgb), campos.data_ptr(), ptr(mask), ptr(work), int(cap), message.data_ptr()))
+
+
+def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
+    """dense = the sum of the views' messages (rows of `messages`, (n, words)), view 0 first; dense[5] (SH gradient,
+    (P,M,3) or None) rebuilt from the colour gradients -- gsr_view_messages_accumulate."""
+    dev = messages.device
+    dg = _dense_grads(dense)
+    with torch.cuda.device(dev):
+        _native.check("gsr_view_messages_accumulate", _native.lib().gsr_view_messages_accumulate(
+            _stream(dev), int(P), int(degree), int(M), int(messages.size(0)), messages.data_ptr(), int(messages.stride(0)),
+            int(cap), means3D.data_ptr(), ctypes.byref(dg)))
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """markVisible, rasterize_points.cu:159-175 -> bool (P)."""
     P = int(means3D.size(0))

@@ -19,6 +19,16 @@ the 3-float colour gradient instead, the ranks ALL-GATHER those (12 B per Gaussi
 camera centres, and every rank rebuilds the sum over views with one kernel (`gsr_sh_grad_compose`), views in
 ascending rank order -- bit for bit what one process accumulating the views gives, identical on every replica.  The
 SUM all-reduce then carries 14 floats per Gaussian: 56 MB + 12 MB per rank instead of 248 MB at 1 M Gaussians.
+
+"Touched rows" (default on top of the "rgb" mode): a view only produces gradients for the Gaussians it blends (the
+front layers, ~10 % of the benchmark scene per view), so most of those dense buffers are zeros.  Each rank packs the rows
+that are not entirely zero -- index + 14 floats + the 3-float colour gradient = 72 B -- with one stable compaction, the
+ranks all-gather the packed rows (padded to the largest count) and every rank adds them per Gaussian, view 0 first
+(`gsr_view_messages_accumulate`: one kernel that writes the dense gradients, SH gradient rebuilt from the colour
+gradients).  The sums are those of one process accumulating the views one after the other, bit for bit, on every replica
+(a ring all-reduce gives no such order), and a rank receives 72 B x (touched rows of all views) instead of
+12 B x N x P + the all-reduce's 2 x 56 B x P.  If the views together touch too many rows for that to pay, all ranks
+take the dense route (the decision is made from the gathered counts, so it is the same everywhere).
 """
 from __future__ import annotations
 
@@ -58,6 +68,8 @@ class GradBucket:
         #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
         self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
         self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
+        self.last_route = None  # what the last multiview_step's exchange did: "local" | "rows" | "sparse" | "dense"
+        self.last_counts = None  # touched rows per view, as gathered by the last touched-rows exchange
         off = 0
         for name in slots:
             cnt = int(torch.Size(shapes[name]).numel())
@@ -140,8 +152,43 @@ def _touched_rows(bucket: GradBucket) -> torch.Tensor:
     return t
 
 
+#: bytes a touched row costs in a message: the row number + means3D 3, scales 3, rotations 4, means2D 3, opacities 1, rgb 3
+_ROW_BYTES = 4 * 18
+_ROW_SEGS = ("means3D", "scales", "rotations", "means2D", "opacities")
+
+
+def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Optional[str]:
+    """The touched-rows exchange of the "rgb" mode (module docstring).  Returns "rows", or None when the dense route is
+    cheaper (nothing has been modified then)."""
+    P, dev = bucket.P, bucket.flat.device
+    grads5 = [bucket.views[name] for name in _ROW_SEGS]
+    plan, count = _C.view_message_plan(grads5, bucket.rgb)
+    mine = torch.tensor([count], dtype=torch.int64, device=dev)
+    gathered = [torch.empty_like(mine) for _ in range(n)]
+    dist.all_gather(gathered, mine, group=group)
+    counts = [int(c) for c in torch.cat(gathered).tolist()]  # host sync; identical on every rank
+    bucket.last_counts = counts
+    dense_bytes = 12 * n * P + 2 * 56 * P  # what a rank receives on the dense route (rgb all-gather + ring all-reduce)
+    if not force and _ROW_BYTES * sum(counts) > 0.6 * dense_bytes:
+        return None
+    cap = max(max(counts), 1)
+    words = _C.view_message_words(P, cap)
+    send = torch.empty(words, dtype=torch.float32, device=dev)
+    _C.view_message_pack(plan, grads5, bucket.rgb, bucket.campos, cap, send)
+    recv = torch.empty((n, words), dtype=torch.float32, device=dev)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(recv, send, group=group)  # straight into the rows of recv
+    else:
+        dist.all_gather(list(recv.unbind(0)), send, group=group)
+    sh = torch.empty((P, bucket.M, 3), dtype=torch.float32, device=dev)
+    # one kernel: per Gaussian, the views' rows added in ascending view order (zeros where no view touched it)
+    _C.view_messages_accumulate(recv, P, cap, bucket.sh_degree, bucket.M, bucket.means3D_ref, grads5 + [sh])
+    bucket.views["sh"] = sh
+    return "rows"
+
+
 def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = None, group=None, sparse="auto",
-                         sparse_threshold: float = 0.5):
+                         sparse_threshold: float = 0.5, rows="auto"):
     """The exchange step of an iteration: SUM over ranks of the gradient bucket, MAX over ranks of the screen
     radii.  No-op in a single-process run.
 
@@ -151,12 +198,21 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
     MAX-all-reduce a one-byte-per-Gaussian "touched" mask (P bytes), and if the union is at most
     `sparse_threshold` of the scene only the union rows are packed, summed with ONE all-reduce and scattered
     back; otherwise the dense bucket is reduced.  Every rank takes the same branch (the mask is reduced), and
-    rows outside the union are zero on every rank, so the result equals the dense all-reduce."""
+    rows outside the union are zero on every rank, so the result equals the dense all-reduce.
+
+    In the "rgb" mode of the bucket `rows` ("auto" | True | False) selects the touched-rows exchange described in the
+    module docstring; "auto" uses it unless the gathered row counts say the dense route moves fewer bytes.  Returns the
+    route taken: "local", "rows", "sparse" or "dense"."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         if bucket.sh_exchange == "rgb":  # a single view: the "sum" has one term
             bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
                                                      bucket.sh_degree, bucket.M)
         return "local"
+    if bucket.sh_exchange == "rgb" and rows in ("auto", True):
+        if _exchange_touched_rows(bucket, group, dist.get_world_size(group), force=rows is True) is not None:
+            if radii is not None:
+                dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
+            return "rows"
     if bucket.sh_exchange == "rgb":
         # colour gradients + camera centres of all views, then the SH gradient of the batch, rebuilt locally
         n = dist.get_world_size(group)
@@ -200,5 +256,5 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
     `radii` the batch-max radii."""
     color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
                                                    params["scaling"], params["rotation"], dL_dcolor, bucket)
-    allreduce_view_grads(bucket, radii, group)
+    bucket.last_route = allreduce_view_grads(bucket, radii, group)
     return color, radii, depth, grads

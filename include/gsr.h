@@ -209,6 +209,42 @@ typedef struct gsr_adam_tensor {
 int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
                   double eps, const uint8_t* row_mask, const float* row_weight);
 
+/* ---- multi-GPU exchange in "touched rows" form (new; SURVEY.md section 8(e), gaussianeditor_amd/multiview.py) ----
+ * A view only produces gradients for the Gaussians it blends.  Instead of all-reducing dense (P, 14 + 3M) buffers a
+ * rank packs the rows that are not entirely zero into a MESSAGE, the ranks all-gather the messages, and each rank adds
+ * them per Gaussian, view 0 first: the operations and the order of one process accumulating the views one after the
+ * other, bit for bit and identical on every replica (a ring all-reduce guarantees no order).
+ * Message layout, 32-bit words, nb = ceil(P / 1024):
+ *   [0..2] camera centre  [3] count (int32)  [4 .. 4+nb) touched rows before row block b
+ *   then idx (cap x int32, ascending), means3D (cap x 3), scales (cap x 3), rotations (cap x 4), means2D (cap x 3),
+ *   opacities (cap), rgb (cap x 3: the clamp-masked colour gradient gsr_preprocess_backward_rgb emits); rows >= count
+ *   are padding.  All ranks use one `cap` >= every rank's count (they exchange the counts first).
+ *   gsr_view_message_words        number of words of a message;
+ *   gsr_view_message_plan         marks the touched rows of this view's gradients (mask: P bytes of scratch; workspace:
+ *                                 gsr_compact_workspace_size(P) bytes) and returns their number in *count_host
+ *                                 (one blocking readback);
+ *   gsr_view_message_pack         writes the message (same mask / workspace);
+ *   gsr_view_messages_accumulate  num_views messages, `stride_words` apart, -> the dense sums in `out` (every row of
+ *                                 every array is written: Gaussians no view touched get zeros); out->sh, if not NULL,
+ *                                 is rebuilt from the colour gradients exactly as gsr_sh_grad_compose does (means3D,
+ *                                 active degree D, M coefficients).
+ * local->sh is ignored by plan / pack. */
+typedef struct gsr_dense_grads {
+  float* means3D;   /* (P,3) */
+  float* scales;    /* (P,3) */
+  float* rotations; /* (P,4) */
+  float* means2D;   /* (P,3) */
+  float* opacities; /* (P,1) */
+  float* sh;        /* (P,M,3) or NULL */
+} gsr_dense_grads;
+int gsr_view_message_words(int64_t P, int64_t cap, int64_t* words);
+int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
+                          void* workspace, int64_t* count_host);
+int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
+                          const uint8_t* mask, void* workspace, int64_t cap, float* message);
+int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
+                                 int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out);
+
 /* ---- prune = stable compaction of the rows of many tensors by one mask ----
  * Replaces the per-tensor boolean-mask indexing of GaussianModel.prune_points / _prune_optimizer
  * (gaussiansplatting/scene/gaussian_model.py:568-609: parameters, Adam moments, bookkeeping tensors).

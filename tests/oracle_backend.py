@@ -73,6 +73,58 @@ def sh_grad_compose(means3D, campos_all, rgb_all, degree, M):
                                               int(degree), int(M)))
 
 
+# --- view messages of the touched-rows exchange (include/gsr.h), same word layout as the library's -----------------------
+def view_message_words(P, cap):
+    return 4 + (int(P) + 1023) // 1024 + 18 * int(cap)
+
+
+def view_message_plan(grads5, rgb):
+    P = int(rgb.size(0))
+    rows = torch.cat([t.reshape(P, -1) for t in grads5] + [rgb.reshape(P, 3)], dim=1)
+    idx = (rows != 0).any(dim=1).nonzero().view(-1)
+    return idx, int(idx.numel())
+
+
+def view_message_pack(plan, grads5, rgb, campos, cap, message):
+    P, n, nb = int(rgb.size(0)), int(plan.numel()), (int(rgb.size(0)) + 1023) // 1024
+    w = message.view(torch.int32)
+    message[0:3] = campos.reshape(3)
+    w[3] = n
+    w[4:4 + nb] = torch.searchsorted(plan, torch.arange(nb, dtype=plan.dtype) * 1024).to(torch.int32)
+    off = 4 + nb
+    w[off:off + n] = plan.to(torch.int32)
+    off += cap
+    for t, k in zip(list(grads5) + [rgb], (3, 3, 4, 3, 1, 3)):
+        message[off:off + k * cap].view(cap, k)[:n] = t.reshape(P, k)[plan]
+        off += k * cap
+
+
+def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
+    nb = (int(P) + 1023) // 1024
+    for d in dense:
+        if d is not None:
+            d.zero_()
+    for v in range(messages.size(0)):  # ascending view order
+        msg = messages[v]
+        n = int(msg.view(torch.int32)[3])
+        if n == 0:
+            continue
+        off = 4 + nb
+        i = msg.view(torch.int32)[off:off + n].to(torch.int64)
+        off += cap
+        rows = []
+        for k in (3, 3, 4, 3, 1, 3):
+            rows.append(msg[off:off + k * cap].view(cap, k)[:n])
+            off += k * cap
+        for k in range(5):
+            dense[k].reshape(int(P), -1)[i] += rows[k]
+        if dense[5] is not None:
+            # one view's SH gradient of the packed rows, rebuilt exactly as gsr_sh_grad_compose does for N = 1
+            t = O.sh_grad_compose(means3D.detach()[i].numpy(), msg[0:3].reshape(1, 3).numpy(),
+                                  rows[5].reshape(1, n, 3).numpy(), int(degree), int(M))
+            dense[5][i] += torch.from_numpy(t)
+
+
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
                             image_width, debug=False):
     f = _registry[int(geomBuffer.view(torch.int64)[0])]
@@ -103,5 +155,5 @@ def install(monkeypatch):
     import gaussianeditor_amd.diff_gaussian_rasterization as dgr
 
     for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_aux", "sh_grad_compose",
-                 "mark_visible", "apply_weights"):
+                 "view_message_words", "view_message_plan", "view_message_pack", "view_messages_accumulate", "mark_visible", "apply_weights"):
         monkeypatch.setattr(dgr._C, name, globals()[name])

@@ -23,8 +23,8 @@ def _free_port():
     return p
 
 
-def _worker_rgb(rank, world, port, out_dir):
-    """The "rgb" exchange: colour gradients all-gathered, SH gradient rebuilt on every rank."""
+def _worker_rgb(rank, world, port, out_dir, rows, s0):
+    """The "rgb" exchange: colour gradients all-gathered (dense, or as packed touched rows), SH gradient rebuilt on every rank."""
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +38,7 @@ def _worker_rgb(rank, world, port, out_dir):
     mpatch = _pt.MonkeyPatch()
     oracle_backend.install(mpatch)
     try:
-        case = make_case(P, W, H, seed=5, s0=0.07, view=rank, nviews=world)
+        case = make_case(P, W, H, seed=5, s0=s0, view=rank, nviews=world)
         sc = case["sc"]
         bucket = GradBucket(P, 16, "cpu")  # "auto" -> "rgb" because two ranks run
         assert bucket.sh_exchange == "rgb" and bucket.flat.numel() == P * 14
@@ -46,9 +46,11 @@ def _worker_rgb(rank, world, port, out_dir):
         color, radii, depth, grads = render_view_grads(settings(case, "cpu"), sc["xyz"], sc["opacity"], sc["features"],
                                                        sc["scaling"], sc["rotation"], G, bucket)
         assert grads["sh"] is None
-        mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0))
+        rows_of = torch.cat([v.reshape(P, -1) for v in bucket.flat_views().values()] + [bucket.rgb], dim=1)
+        touched = float((rows_of != 0).any(dim=1).float().mean())
+        mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0), rows=rows)
         np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=bucket.flat.numpy(), sh=bucket.views["sh"].numpy(),
-                 radii=radii.numpy(), mode=np.array([mode == "sparse"]))
+                 radii=radii.numpy(), touched=np.array([touched]), rows_route=np.array([mode == "rows"]))
     finally:
         mpatch.undo()
         dist.destroy_process_group()
@@ -118,16 +120,17 @@ def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
     assert np.array_equal(r0["radii"], rad)
 
 
-def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path):
+@pytest.mark.parametrize("rows,s0", [(False, 0.07), (True, 0.07), ("auto", 0.07), ("auto", 0.004)])
+def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path, rows, s0):
     world = 2
-    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path), rows, s0), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rgb_rank0.npz"), np.load(tmp_path / "rgb_rank1.npz")
     # replicas agree bit for bit, including the SH gradient each of them rebuilt on its own
     for k in ("flat", "sh", "radii"):
         assert np.array_equal(r0[k], r1[k]), k
     tot, sh = None, None
     for v in range(world):
-        case = make_case(P, W, H, seed=5, s0=0.07, view=v, nviews=world)
+        case = make_case(P, W, H, seed=5, s0=s0, view=v, nviews=world)
         f = oracle_forward(oracle, case)
         g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
         flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dmeans2D",
@@ -135,6 +138,12 @@ def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path):
         tot = flat if tot is None else tot + flat
         sh = g["dL_dsh"] if sh is None else sh + g["dL_dsh"]  # a single process accumulates view after view
     assert rel_err(r0["flat"], tot) < 1e-6
+    # the route: forced, or chosen from the gathered counts (72 B per touched row against the dense route's bytes)
+    t = float(r0["touched"][0]) + float(r1["touched"][0])
+    want_rows = rows is True or (rows == "auto" and 72 * t <= 0.6 * (12 * world + 112))
+    assert bool(r0["rows_route"][0]) == bool(r1["rows_route"][0]) == want_rows, (t, rows)
+    if want_rows:  # packed rows are added view after view to zeros: the single process's sums, bit for bit
+        assert np.array_equal(r0["flat"], tot)
     # rebuilt from 3 floats per view = the accumulated per-view SH gradients, bit for bit
     assert np.array_equal(r0["sh"], sh.reshape(r0["sh"].shape))
 

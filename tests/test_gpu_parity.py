@@ -693,6 +693,68 @@ def test_sh_grad_rebuilt_from_colour_gradients(oracle, D):
     assert np.array_equal(rebuilt.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("D,s0,P", [(3, 0.01, 20000), (1, 0.05, 20000), (2, 0.02, 1023), (3, 0.02, 5121)])
+def test_touched_rows_exchange_kernels(oracle, D, s0, P):
+    """The multi-GPU exchange in its touched-rows form, run for three views in ONE process: every view packs its
+    non-zero rows into a message (gsr_view_message_plan / _pack), gsr_view_messages_accumulate adds the messages per
+    Gaussian in view order.  The sums equal torch's sequential accumulation of the dense per-view gradients bit for
+    bit, the rebuilt SH gradient equals gsr_sh_grad_compose over the same views bit for bit (and the oracle's)."""
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+    from gaussianeditor_amd.multiview import _ROW_SEGS, GradBucket, render_view_grads
+
+    W, H, views, M = 200, 150, 3, 16
+    buckets, plans, dense_sum, rgbs, cams, m3 = [], [], None, [], [], None
+    for v in range(views):
+        case = make_case(P, W, H, seed=70, s0=s0, view=v, nviews=views)
+        sc = case["sc"]
+        rs = settings(case, DEV, D=D)
+        G = (seed_gradient(H, W, 80 + v) * H * W).to(DEV)
+        args = [sc[k].to(DEV) for k in ("xyz", "opacity", "features", "scaling", "rotation")]
+        m3 = args[0]
+        b = GradBucket(P, M, DEV, sh_exchange="rgb")
+        render_view_grads(rs, *args, G, b)
+        grads5 = [b.views[name] for name in _ROW_SEGS]
+        plan, count = _C.view_message_plan(grads5, b.rgb)
+        any_nz = torch.cat([g.reshape(P, -1) for g in grads5] + [b.rgb], dim=1).ne(0).any(dim=1)
+        assert count == int(any_nz.sum()) and 0 < count <= P
+        buckets.append(b)
+        plans.append((plan, count, any_nz.nonzero().view(-1)))
+        cur = [g.clone() for g in grads5]
+        dense_sum = cur if dense_sum is None else [a + c for a, c in zip(dense_sum, cur)]  # (0 + g0) + g1 + g2
+        rgbs.append(b.rgb.clone())
+        cams.append(rs.campos.reshape(3).clone())
+    cap = max(c for _, c, _ in plans) + 5  # (padding rows beyond every count)
+    words, nb = _C.view_message_words(P, cap), (P + 1023) // 1024
+    assert words == 4 + nb + 18 * cap
+    messages = torch.full((views, words + 7), float("nan"), device=DEV)[:, :words]  # rows 'stride' apart, stride > words
+    for v, (b, (plan, count, want)) in enumerate(zip(buckets, plans)):
+        _C.view_message_pack(plan, [b.views[name] for name in _ROW_SEGS], b.rgb, cams[v], cap, messages[v])
+        msg = messages[v]
+        assert torch.equal(msg[:3], cams[v]) and int(msg.view(torch.int32)[3]) == count
+        boff = msg.view(torch.int32)[4:4 + nb].long()
+        assert torch.equal(boff, torch.searchsorted(want, torch.arange(nb, device=DEV) * 1024))
+        off = 4 + nb
+        assert torch.equal(msg.view(torch.int32)[off:off + count].long(), want)
+        off += cap
+        for name, k in zip(_ROW_SEGS + ("rgb",), (3, 3, 4, 3, 1, 3)):
+            src = b.rgb if name == "rgb" else b.views[name]
+            assert torch.equal(msg[off:off + k * cap].view(cap, k)[:count], src.reshape(P, k)[want]), name
+            off += k * cap
+    dense = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [torch.full((P, M, 3), float("nan"), device=DEV)]
+    _C.view_messages_accumulate(messages, P, cap, D, M, m3, dense)
+    for got, ref in zip(dense[:5], dense_sum):
+        assert torch.equal(got, ref.reshape(got.shape))
+    composed = _C.sh_grad_compose(m3, torch.stack(cams), torch.stack(rgbs), D, M)
+    assert torch.equal(dense[5], composed)
+    ref = oracle.sh_grad_compose(m3.cpu().numpy(), torch.stack(cams).cpu().numpy(), torch.stack(rgbs).cpu().numpy(), D, M)
+    assert np.array_equal(dense[5].cpu().numpy(), ref)
+    # without an SH target only the five dense segments are written; a single message is a valid batch
+    dense2 = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [None]
+    _C.view_messages_accumulate(messages[:1], P, cap, D, M, m3, dense2)
+    for got, name in zip(dense2[:5], _ROW_SEGS):
+        assert torch.equal(got, buckets[0].views[name].reshape(got.shape)), name
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # SURVEY.md section 8(f) rank 4: prune = one compaction for all tensors (gsr_compact_plan / gsr_compact_apply)
 @pytest.mark.parametrize("P,frac", [(1, 1.0), (5, 0.0), (1023, 0.5), (1025, 0.5), (100000, 0.9), (100000, 0.01)])
