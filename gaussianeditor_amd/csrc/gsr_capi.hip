@@ -356,8 +356,7 @@ static bool dense_grads_complete(const gsr_dense_grads* g) {
 
 int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
                           void* workspace, int64_t* count_host) {
-  if (!count_host) return GSR_ERR_BAD_ARGUMENT;
-  *count_host = 0;
+  if (count_host) *count_host = 0;
   if (P == 0) return GSR_OK;
   if (P < 0 || !dense_grads_complete(local) || !rgb || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
@@ -365,6 +364,7 @@ int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local,
   const int row_len[6] = {3, 3, 4, 3, 1, 3};
   GSR_HIP(launch_touched_rows(s, P, 6, data, row_len, mask));
   GSR_HIP(launch_compact_plan(s, P, mask, workspace));
+  if (!count_host) return GSR_OK;  // the caller reads the count from the workspace itself (first 8 bytes)
   uint64_t total = 0;
   GSR_HIP(hipMemcpyAsync(&total, compact_total_ptr(workspace, P), sizeof(uint64_t), hipMemcpyDeviceToHost, s));
   GSR_HIP(hipStreamSynchronize(s));

@@ -255,13 +255,14 @@ def view_message_words(P, cap):
     return int(n.value)
 
 
-def view_message_plan(grads5, rgb):
+def view_message_plan(grads5, rgb, readback=True):
     """Marks the rows of this view's gradients (means3D, scales, rotations, means2D, opacities + colour gradient) that are
-    not entirely zero.  Returns (plan, count); `count` costs one host readback."""
+    not entirely zero.  Returns (plan, count): an int (one host readback), or with readback=False a 1-element int64 device
+    tensor (no synchronisation; valid in stream order)."""
     _require_cuda(rgb, "rgb")
     dev, P = rgb.device, int(rgb.size(0))
     if P == 0:
-        return (None, None, 0, dev), 0
+        return (None, None, 0, dev), (0 if readback else torch.zeros(1, dtype=torch.int64, device=dev))
     L = _native.lib()
     mask = torch.empty(P, dtype=torch.uint8, device=dev)
     nbytes = ctypes.c_size_t(0)
@@ -271,8 +272,9 @@ def view_message_plan(grads5, rgb):
     dg = _dense_grads(list(grads5) + [None])
     with torch.cuda.device(dev):
         _native.check("gsr_view_message_plan", L.gsr_view_message_plan(_stream(dev), P, ctypes.byref(dg), rgb.data_ptr(),
-                                                                        mask.data_ptr(), work.data_ptr(), ctypes.byref(count)))
-    return (mask, work, P, dev), int(count.value)
+                                                                        mask.data_ptr(), work.data_ptr(),
+                                                                        ctypes.byref(count) if readback else None))
+    return (mask, work, P, dev), (int(count.value) if readback else work[:8].view(torch.int64))
 
 
 def view_message_pack(plan, grads5, rgb, campos, cap, message):

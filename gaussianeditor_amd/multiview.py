@@ -162,11 +162,10 @@ def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Op
     cheaper (nothing has been modified then)."""
     P, dev = bucket.P, bucket.flat.device
     grads5 = [bucket.views[name] for name in _ROW_SEGS]
-    plan, count = _C.view_message_plan(grads5, bucket.rgb)
-    mine = torch.tensor([count], dtype=torch.int64, device=dev)
+    plan, mine = _C.view_message_plan(grads5, bucket.rgb, readback=False)  # the count stays on the device ...
     gathered = [torch.empty_like(mine) for _ in range(n)]
     dist.all_gather(gathered, mine, group=group)
-    counts = [int(c) for c in torch.cat(gathered).tolist()]  # host sync; identical on every rank
+    counts = [int(c) for c in torch.cat(gathered).tolist()]  # ... this is the step's one host sync; identical on every rank
     bucket.last_counts = counts
     dense_bytes = 12 * n * P + 2 * 56 * P  # what a rank receives on the dense route (rgb all-gather + ring all-reduce)
     if not force and _ROW_BYTES * sum(counts) > 0.6 * dense_bytes:

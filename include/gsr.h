@@ -222,7 +222,10 @@ int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors,
  *   gsr_view_message_words        number of words of a message;
  *   gsr_view_message_plan         marks the touched rows of this view's gradients (mask: P bytes of scratch; workspace:
  *                                 gsr_compact_workspace_size(P) bytes) and returns their number in *count_host
- *                                 (one blocking readback);
+ *                                 (one blocking readback).  With count_host == NULL nothing is read back and the call
+ *                                 does not block: the count is then the uint64 at the start of `workspace`, in
+ *                                 stream order (multiview.py all-gathers it from there: one host sync for all ranks'
+ *                                 counts instead of two);
  *   gsr_view_message_pack         writes the message (same mask / workspace);
  *   gsr_view_messages_accumulate  num_views messages, `stride_words` apart, -> the dense sums in `out` (every row of
  *                                 every array is written: Gaussians no view touched get zeros); out->sh, if not NULL,

@@ -78,11 +78,11 @@ def view_message_words(P, cap):
     return 4 + (int(P) + 1023) // 1024 + 18 * int(cap)
 
 
-def view_message_plan(grads5, rgb):
+def view_message_plan(grads5, rgb, readback=True):
     P = int(rgb.size(0))
     rows = torch.cat([t.reshape(P, -1) for t in grads5] + [rgb.reshape(P, 3)], dim=1)
     idx = (rows != 0).any(dim=1).nonzero().view(-1)
-    return idx, int(idx.numel())
+    return idx, (int(idx.numel()) if readback else torch.tensor([idx.numel()], dtype=torch.int64))
 
 
 def view_message_pack(plan, grads5, rgb, campos, cap, message):
