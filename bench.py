@@ -78,7 +78,7 @@ def main():
 
     from gaussianeditor_amd import _native
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-    from gaussianeditor_amd.multiview import GradBucket, allreduce_view_grads, render_view_grads
+    from gaussianeditor_amd.multiview import GradBucket, multiview_step, render_view_grads
     from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
 
     P, W, H = args.gaussians, args.width, args.height
@@ -112,9 +112,9 @@ def main():
     rows_mode = "auto" if rows_env is None else (rows_env == "1")
 
     def train_step():
-        color, radii, depth, grads = render_view_grads(rs, params["xyz"], params["opacity"], params["features"],
-                                                       params["scaling"], params["rotation"], G, bucket)
-        route["last"] = allreduce_view_grads(bucket, radii, rows=rows_mode)
+        # forward, radii MAX all-reduce started, backward, gradient exchange (gaussianeditor_amd/multiview.py)
+        color, radii, depth, grads = multiview_step(rs, params, G, bucket, rows=rows_mode)
+        route["last"] = bucket.last_route
         return radii
 
     exchange = bucket.sh_exchange

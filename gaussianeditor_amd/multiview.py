@@ -115,16 +115,19 @@ class GradBucket:
 
 
 def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
-                      dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None):
+                      dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None, after_forward=None):
     """Forward + backward of ONE view through the drop-in L1 API with `dL_dcolor` as the
     pixel gradient.  Returns (color, radii, depth, grads) where grads has the six
-    rasterizer-input gradients (views of `bucket` when one is given)."""
+    rasterizer-input gradients (views of `bucket` when one is given).  `after_forward(radii)` is called between the
+    forward and the backward (multiview_step starts the radii's MAX all-reduce there, so that it overlaps the backward)."""
     leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
     m3, sh, op, sc, rot = leaves
     # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
     # not zero-filled here (the reference's render() does: gaussian_renderer/__init__.py:60-69)
     m2 = torch.empty_like(m3).requires_grad_(True)
     color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
+    if after_forward is not None:
+        after_forward(radii)
     ctx = bucket.capture() if bucket is not None else contextlib.nullcontext()
     with ctx:
         # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by allreduce_view_grads)
@@ -248,12 +251,23 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
 
 
 def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, torch.Tensor], dL_dcolor: torch.Tensor,
-                   bucket: GradBucket, group=None):
+                   bucket: GradBucket, group=None, rows="auto"):
     """One data-parallel iteration for this rank's view: forward, backward, gradient all-reduce.
     `params`: xyz, opacity, features, scaling, rotation (activated, as the rasterizer consumes them).
     After the call `bucket.views[...]` hold the batch-summed gradients on every rank and
     `radii` the batch-max radii."""
+    pending = []
+
+    def start_radii(radii):  # known after the forward: the collective runs while the backward computes
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            batch_max = radii.clone()  # (the backward still needs this view's own radii)
+            pending.append((batch_max, dist.all_reduce(batch_max, op=dist.ReduceOp.MAX, group=group, async_op=True)))
+
     color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
-                                                   params["scaling"], params["rotation"], dL_dcolor, bucket)
-    bucket.last_route = allreduce_view_grads(bucket, radii, group)
+                                                   params["scaling"], params["rotation"], dL_dcolor, bucket,
+                                                   after_forward=start_radii)
+    bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows)
+    for batch_max, work in pending:
+        work.wait()
+        radii = batch_max
     return color, radii, depth, grads

@@ -43,12 +43,29 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0):
         bucket = GradBucket(P, 16, "cpu")  # "auto" -> "rgb" because two ranks run
         assert bucket.sh_exchange == "rgb" and bucket.flat.numel() == P * 14
         G = seed_gradient(H, W, 100 + rank) * H * W
-        color, radii, depth, grads = render_view_grads(settings(case, "cpu"), sc["xyz"], sc["opacity"], sc["features"],
-                                                       sc["scaling"], sc["rotation"], G, bucket)
-        assert grads["sh"] is None
-        rows_of = torch.cat([v.reshape(P, -1) for v in bucket.flat_views().values()] + [bucket.rgb], dim=1)
-        touched = float((rows_of != 0).any(dim=1).float().mean())
-        mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0), rows=rows)
+        if rows == "auto":  # the whole step as bench.py runs it: the radii's MAX all-reduce overlaps the backward
+            from gaussianeditor_amd.multiview import multiview_step
+
+            touched_of = []
+            orig = allreduce_view_grads.__globals__["_C"].view_message_plan
+
+            def spy(grads5, rgb, readback=True):
+                rows_of = torch.cat([g.reshape(P, -1) for g in grads5] + [rgb], dim=1)
+                touched_of.append(float((rows_of != 0).any(dim=1).float().mean()))
+                return orig(grads5, rgb, readback)
+
+            mpatch.setattr(allreduce_view_grads.__globals__["_C"], "view_message_plan", spy)
+            params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+            color, radii, depth, grads = multiview_step(settings(case, "cpu"), params, G, bucket)
+            assert grads["sh"] is None
+            mode, touched = bucket.last_route, touched_of[0]
+        else:
+            color, radii, depth, grads = render_view_grads(settings(case, "cpu"), sc["xyz"], sc["opacity"], sc["features"],
+                                                           sc["scaling"], sc["rotation"], G, bucket)
+            assert grads["sh"] is None
+            rows_of = torch.cat([v.reshape(P, -1) for v in bucket.flat_views().values()] + [bucket.rgb], dim=1)
+            touched = float((rows_of != 0).any(dim=1).float().mean())
+            mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0), rows=rows)
         np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=bucket.flat.numpy(), sh=bucket.views["sh"].numpy(),
                  radii=radii.numpy(), touched=np.array([touched]), rows_route=np.array([mode == "rows"]))
     finally:
