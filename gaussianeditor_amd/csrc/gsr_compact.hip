@@ -66,12 +66,14 @@ struct CompactTensorDev {
 };
 struct CompactArgs {
   CompactTensorDev t[CMP_MAX_TENSORS];
+  int nt;
   int64_t P;
   const uint8_t* keep;
   const uint32_t* block_off;
 };
 
-// grid = (row blocks, tensors)
+constexpr int CMP_TENSORS_PER_BLOCK = 8;  // tensors a block moves after scanning its part of the mask once
+// grid = (row blocks, ceil(tensors / CMP_TENSORS_PER_BLOCK))
 __global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactArgs a) {
   __shared__ uint32_t smem[CMP_ROWS / 64 + 1];
   __shared__ uint32_t pos[CMP_ROWS];
@@ -83,14 +85,29 @@ __global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactAr
   pos[threadIdx.x] = k ? a.block_off[blockIdx.x] + ex : 0xffffffffu;
   __syncthreads();
   if (total == 0) return;
-  const CompactTensorDev t = a.t[blockIdx.y];
   const uint32_t nrows = (uint32_t)min((int64_t)CMP_ROWS, a.P - row0);
+  const int t_end = min(a.nt, ((int)blockIdx.y + 1) * CMP_TENSORS_PER_BLOCK);
+  for (int ti = (int)blockIdx.y * CMP_TENSORS_PER_BLOCK; ti < t_end; ++ti) {
+  const CompactTensorDev t = a.t[ti];
   if (t.src == nullptr) {  // "iota" source: the surviving row numbers themselves (int32), internal callers only
     const uint32_t p = pos[threadIdx.x];
     if (p != 0xffffffffu) reinterpret_cast<int32_t*>(t.dst)[p] = (int32_t)r;
-    return;
+    continue;
   }
-  if ((t.row_bytes & 3u) == 0 && (((uintptr_t)t.src | (uintptr_t)t.dst) & 3u) == 0) {
+  if ((t.row_bytes & 3u) == 0 && t.row_bytes <= 16u && (((uintptr_t)t.src | (uintptr_t)t.dst) & 3u) == 0) {
+    // short rows (1..4 words: positions, scales, quaternions, opacities, ...): each thread moves its own row
+    const uint32_t W = t.row_bytes >> 2, p = pos[threadIdx.x];
+    if (p != 0xffffffffu) {
+      const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(t.src) + (size_t)r * W;
+      uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(t.dst) + (size_t)p * W;
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c) v[c] = c < W ? s[c] : 0u;
+#pragma unroll
+      for (uint32_t c = 0; c < 4; ++c)
+        if (c < W) d[c] = v[c];
+    }
+  } else if ((t.row_bytes & 3u) == 0 && (((uintptr_t)t.src | (uintptr_t)t.dst) & 3u) == 0) {
     const uint32_t W = t.row_bytes >> 2;
     const uint32_t* __restrict__ s = reinterpret_cast<const uint32_t*>(t.src) + (size_t)row0 * W;
     uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(t.dst);
@@ -109,6 +126,7 @@ __global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactAr
       const uint32_t p = pos[rr];
       if (p != 0xffffffffu) t.dst[(size_t)p * W + c] = s[e];
     }
+  }
   }
 }
 
@@ -130,6 +148,7 @@ hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, v
   CompactArgs a;
   memset(&a, 0, sizeof(a));
   a.P = P;
+  a.nt = nt;
   a.keep = keep;
   a.block_off = w.block_off;
   for (int i = 0; i < nt; ++i) {
@@ -138,7 +157,8 @@ hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, v
     a.t[i].row_bytes = (uint32_t)tensors[i].row_bytes;
   }
   const int64_t nb = (P + CMP_ROWS - 1) / CMP_ROWS;
-  hipLaunchKernelGGL(compact_apply_kernel, dim3((unsigned)nb, (unsigned)nt), dim3(CMP_ROWS), 0, s, a);
+  hipLaunchKernelGGL(compact_apply_kernel, dim3((unsigned)nb, (unsigned)((nt + CMP_TENSORS_PER_BLOCK - 1) / CMP_TENSORS_PER_BLOCK)),
+                     dim3(CMP_ROWS), 0, s, a);
   return hipGetLastError();
 }
 
