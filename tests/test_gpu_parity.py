@@ -233,6 +233,22 @@ def test_empty_and_fully_culled():
     assert float(depth.abs().max()) == 0.0
 
 
+def test_too_many_instances_is_an_error_not_a_crash():
+    """70 000 splats that each cover all 32 400 tiles of a 4K image: 2.27e9 (tile, Gaussian) instances, beyond the
+    31-bit index space the reference's `int num_rendered` has too (rasterizer_impl.cu:247-250 would overflow silently).
+    The library reports GSR_ERR_TOO_MANY after the preprocessing kernel; nothing is allocated for the instances."""
+    from gaussianeditor_amd._native import GsrError
+
+    case = make_case(70000, 3840, 2160, seed=9, s0=40.0, scale_xyz=0.05)
+    case["sc"]["opacity"].fill_(0.9)
+    with pytest.raises(GsrError, match="31-bit"):
+        _run_hip_forward(case)
+    # the library is usable afterwards
+    small = make_case(500, 64, 64, seed=9, s0=0.1)
+    R, color, *_ = _run_hip_forward(small)
+    assert R > 0 and bool(torch.isfinite(color).all())
+
+
 def test_validation_errors():
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
 
