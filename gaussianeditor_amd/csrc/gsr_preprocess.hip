@@ -218,6 +218,10 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
       get_rect(pix, piy, radius_i, a.gx, a.gy, minx, miny, maxx, maxy);
       const uint32_t area = (maxx - minx) * (maxy - miny);
       if (area == 0) break;
+      // A NaN radius (non-finite scale / rotation / covariance) converts to 0 and still spans one tile.  The reference
+      // then counts that tile in num_rendered but never writes the instance (duplicateWithKeys skips radii <= 0,
+      // rasterizer_impl.cu:93), so its sort reads an uninitialised key.  Here such a Gaussian touches no tile.
+      if (radius_i <= 0) break;
 
       // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -252,9 +256,10 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
           }
           result = {result.x + 0.5f, result.y + 0.5f, result.z + 0.5f};
           a.g.clamped[idx] = (uint8_t)((result.x < 0 ? 1 : 0) | (result.y < 0 ? 2 : 0) | (result.z < 0 ? 4 : 0));
-          col.x = fmaxf(result.x, 0.0f);
-          col.y = fmaxf(result.y, 0.0f);
-          col.z = fmaxf(result.z, 0.0f);
+          // glm::max(result, 0.0f) is (x < y) ? y : x (forward.cu:70): a NaN colour stays NaN, unlike fmaxf
+          col.x = result.x < 0.0f ? 0.0f : result.x;
+          col.y = result.y < 0.0f ? 0.0f : result.y;
+          col.z = result.z < 0.0f ? 0.0f : result.z;
         }
       }
       // forward.cu:250-255

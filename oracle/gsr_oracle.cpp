@@ -291,6 +291,10 @@ int gsro_preprocess(int P, int D, int M, const float* means3D, const float* scal
     uint32_t minx, miny, maxx, maxy;
     getRect(pix, piy, f2i(my_radius), gx, gy, minx, miny, maxx, maxy);
     if ((maxx - minx) * (maxy - miny) == 0) continue;
+    // deliberate deviation: a NaN radius converts to 0 and still spans one tile; the reference counts
+    // the tile but never writes the instance (rasterizer_impl.cu:93 skips radii <= 0) and sorts an uninitialised key.
+    // Such a Gaussian touches no tile here and in the HIP path.
+    if (f2i(my_radius) <= 0) continue;
 
     // forward.cu:241-247 / computeColorFromSH forward.cu:20-71
     if (colors_precomp == nullptr) {

@@ -359,6 +359,47 @@ def test_degenerate_inputs(oracle):
         assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
 
 
+def test_nonfinite_inputs_match_oracle(oracle):
+    """NaN / Inf in every input array.  The reference has no guards: a NaN position, scale or rotation fails the
+    `det == 0` / rectangle tests and the Gaussian is dropped, a NaN opacity or colour flows into the pixels it covers.
+    The HIP path makes the same decisions (float -> int conversions saturate and send NaN to 0 on both sides)."""
+    case = make_case(3000, 96, 96, seed=31, s0=0.08)
+    sc = case["sc"]
+    nan, inf = float("nan"), float("inf")
+    sc["xyz"][0:20, 0] = nan
+    sc["xyz"][20:40] = inf
+    sc["scaling"][40:60] = inf
+    sc["scaling"][60:80, 1] = nan
+    sc["opacity"][80:100] = nan
+    sc["opacity"][100:110] = inf
+    sc["rotation"][110:130] = nan
+    sc["rotation"][130:140] = 0.0
+    sc["features"][140:160] = nan
+    sc["features"][160:170, 0] = inf
+    f = oracle_forward(oracle, case)
+    assert int((f["radii"][:80] > 0).sum()) == 0 and int((f["radii"][80:110] > 0).sum()) == 30  # (what the cases do)
+    R, color, depth, radii, geom, binning, img = _run_hip_forward(case)
+    st = hip_state(3000, R, 96, 96, geom, binning, img)
+    assert R == f["num_rendered"]
+    assert np.array_equal(radii.cpu().numpy(), f["radii"])
+    assert np.array_equal(st["keys"], f["keys"]) and np.array_equal(st["point_list"], f["point_list"])
+    assert np.array_equal(st["ranges"], f["ranges"]) and np.array_equal(st["n_contrib"], f["n_contrib"])
+    col = color.cpu().numpy()
+    assert np.array_equal(np.isnan(col), np.isnan(f["color"])) and 0 < int(np.isnan(col).sum()) < col.size
+    assert np.allclose(col, f["color"], rtol=0, atol=1e-5, equal_nan=True)
+    assert np.allclose(st["final_T"], f["final_T"], rtol=0, atol=1e-6, equal_nan=True)
+    # the backward runs to completion on the same scene; gradients of the untouched, finite Gaussians match
+    G = seed_gradient(96, 96, 31) * (96 * 96)
+    g = oracle_backward(oracle, case, f, G)
+    h = _grads_hip(case, G)
+    for k, v in h.items():
+        ref = g[k].reshape(v.shape)
+        assert np.array_equal(np.isnan(v), np.isnan(ref)), k
+        fin = np.isfinite(ref) & np.isfinite(v)
+        scale = max(1.0, float(np.abs(ref[fin]).max())) if fin.any() else 1.0
+        assert float(np.abs(v[fin] - ref[fin]).max()) <= 1e-5 * scale, k
+
+
 def test_non_contiguous_and_sliced_inputs(oracle):
     """The L1 API accepts whatever torch hands it: transposed / strided / sliced tensors are made contiguous
     (rasterize_points.cu:80-91 calls .contiguous() on every input)."""
