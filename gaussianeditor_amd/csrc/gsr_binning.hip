@@ -250,38 +250,64 @@ hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes) 
 }
 
 // ----------------------------------------------------------------------------------
-// K3: duplicateWithKeys, rasterizer_impl.cu:67-100, in depth order of the Gaussians.  Thread i
-// handles Gaussian order[i]; its write offset is block_offs[block] + in-block exclusive scan.
+// K3: duplicateWithKeys, rasterizer_impl.cu:67-100, in depth order of the Gaussians.  A block
+// takes 256 consecutive Gaussians of that order; their instances occupy one contiguous run of the
+// output (block_offs[block] + in-block exclusive scan).  The threads then walk the run SLOT BY SLOT
+// (thread t writes slots t, t + 256, ...: coalesced stores however uneven the rectangles are): a
+// binary search in the block's offset table finds the Gaussian a slot belongs to, the slot's position
+// inside its rectangle gives the tile, rows first as the reference's loops do.
 // Only the tile id is written as key (the depth is implied by the position).
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
                                                                const Geom g, uint32_t* __restrict__ tkeys,
                                                                uint32_t* __restrict__ vals, uint2* __restrict__ ranges) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_org[GAUSS_BLOCK], s_w[GAUSS_BLOCK];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   // the ranges of tiles no instance falls into stay (0,0) (reference: cudaMemset, rasterizer_impl.cu:263-265);
   // cleared here, two launches ahead of tile_ranges_kernel, instead of by a memset of its own
   if (i < gx * gy) ranges[i] = make_uint2(0u, 0u);
+  if ((int)blockIdx.x * GAUSS_BLOCK >= P) return;  // (extra blocks only clear ranges)
   const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
   const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
   const uint32_t n = i < P ? g.dkey[fin ^ 1u][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
   uint32_t total;
-  const uint32_t boff = (int)blockIdx.x * GAUSS_BLOCK < P ? g.block_offs[blockIdx.x] : 0u;  // (extra blocks only clear ranges)
-  uint32_t off = boff + block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
-  if (n == 0) return;
-  const float4 r1 = g.rec1[idx];   // the only gather: mean2D, depth, radius (K1 stores (float)radii[idx] in .w)
-  const float r = r1.w;
-  // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle)
-  const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
-  const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
-  const uint32_t maxx = (uint32_t)min(gx, max(0, f2i_sat((r1.x + r + (float)TILE - 1.0f) / (float)TILE)));
-  const uint32_t maxy = (uint32_t)min(gy, max(0, f2i_sat((r1.y + r + (float)TILE - 1.0f) / (float)TILE)));
-  for (uint32_t y = miny; y < maxy; y++)
-    for (uint32_t x = minx; x < maxx; x++) {
-      tkeys[off] = y * (uint32_t)gx + x;
-      vals[off] = idx;
-      off++;
+  const uint32_t boff = g.block_offs[blockIdx.x];
+  const uint32_t off = block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
+  uint32_t org = 0, w = 1;
+  if (n != 0) {
+    const float4 r1 = g.rec1[idx];  // the only gather: mean2D, depth, radius (K1 stores (float)radii[idx] in .w)
+    const float r = r1.w;
+    // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle, n == width * height)
+    const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
+    const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
+    const uint32_t maxx = (uint32_t)min(gx, max(0, f2i_sat((r1.x + r + (float)TILE - 1.0f) / (float)TILE)));
+    org = miny * (uint32_t)gx + minx;  // tile id of the rectangle's first tile
+    w = maxx - minx;
+  }
+  s_off[threadIdx.x] = off;
+  s_idx[threadIdx.x] = idx;
+  s_org[threadIdx.x] = org;
+  s_w[threadIdx.x] = w;
+  if (threadIdx.x == 0) s_off[GAUSS_BLOCK] = total;
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < total; s += GAUSS_BLOCK) {
+    // the last j with s_off[j] <= s: s_off[j + 1] > s, so Gaussian j owns at least one slot
+    uint32_t lo = 0, hi = GAUSS_BLOCK;
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {  // GAUSS_BLOCK == 256
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= s) lo = mid; else hi = mid;
     }
+    const uint32_t k = s - s_off[lo], wj = s_w[lo];
+    // row = k / wj without an integer division: k, wj < 2^24 (at most gx * gy tiles), one correction step each way
+    uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)wj));
+    if (row * wj > k) row--;
+    if ((row + 1u) * wj <= k) row++;
+    const uint32_t col = k - row * wj;
+    tkeys[boff + s] = s_org[lo] + row * (uint32_t)gx + col;
+    vals[boff + s] = s_idx[lo];
+  }
 }
 
 // ----------------------------------------------------------------------------------
