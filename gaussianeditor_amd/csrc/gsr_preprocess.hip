@@ -348,13 +348,42 @@ __device__ __forceinline__ void store_sh_grad(float* __restrict__ dst, int M, co
   }
 }
 
-// (amdgpu_waves_per_eu: 129 VGPRs unconstrained = 3 waves per SIMD; capped at 128 the kernel fits 4 without spilling:
-//  -8 us.  Moving the 192-byte SH rows through LDS with wave-coalesced global accesses was measured too: slower, both
-//  for the loads (two exposed latencies) and for the stores; the strided dwordx4 accesses are not the problem.)
-__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// Wave-cooperative store of 64 consecutive 192-byte SH-gradient rows (M = 16): every lane puts its row into a private
+// LDS tile whose rows are padded to 13 float4 (bank-conflict free both ways) and the wave's 12 KB block leaves as
+// twelve fully coalesced 1 KB stores (tools/microbench/rows192.hip: 5.55 TB/s against 4.55 TB/s for one thread per
+// row).  One wave owns a tile: no workgroup barrier.  K8+K9: 122 -> 110 us.  The same route for the SH LOADS changes
+// nothing (measured again with this tile: 110 us either way), so they stay one row per thread.
+constexpr int SH_TILE_F4 = 64 * 13;
+__device__ __forceinline__ void sh_tile_store_rows(float* __restrict__ dst_rows, int nrows, float4* __restrict__ tile, int lane,
+                                                   const V3* g, int ncoef) {
+  float f[48];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const bool on = k < ncoef;  // coefficients >= ncoef are zero
+    f[3 * k] = on ? g[k].x : 0.f;
+    f[3 * k + 1] = on ? g[k].y : 0.f;
+    f[3 * k + 2] = on ? g[k].z : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 12; ++i) tile[lane * 13 + i] = make_float4(f[4 * i], f[4 * i + 1], f[4 * i + 2], f[4 * i + 3]);
+  __builtin_amdgcn_wave_barrier();
+  float4* __restrict__ q = reinterpret_cast<float4*>(dst_rows);
+  const int nf4 = nrows * 12;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int e = k * 64 + lane, r = e / 12, c = e - 12 * r;
+    if (e < nf4) q[e] = tile[r * 13 + c];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// (Three waves per SIMD: the 52 KB of store tiles per workgroup allow three workgroups per CU, ~140 VGPRs.)
+__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 preprocess_backward_kernel(const PreBwdArgs a) {
-  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  if (idx >= a.P) return;
+  __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
+  const int idx_raw = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  const bool live = idx_raw < a.P;  // (no early return: the SH-gradient rows leave wave-cooperatively)
+  const int idx = live ? idx_raw : a.P - 1;
   const int ncoef = (a.D + 1) * (a.D + 1);
   V3 dmean = {0.f, 0.f, 0.f};
   float dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -365,7 +394,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
   V3 drgb = {0.f, 0.f, 0.f};  // dL_dRGB with the clamped channels zeroed (output of the "rgb" mode)
 
-  if (a.radii[idx] > 0) {
+  if (live && a.radii[idx] > 0) {
     Cam cam;
     load_cam(cam, a.viewmatrix, a.projmatrix, a.shs ? a.campos : nullptr);
     const float* view = cam.view;
@@ -565,12 +594,21 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     }
   }
 
+  if (a.dL_dsh != nullptr) {
+    if (a.M == 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0) {
+      const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+      const int row0 = idx_raw - lane;  // first row of this wave
+      if (row0 < a.P) sh_tile_store_rows(a.dL_dsh + (size_t)row0 * 48, min(64, a.P - row0), sh_tile[wv], lane, dsh, ncoef);
+    } else if (live) {
+      store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
+    }
+  }
+  if (!live) return;
   a.dL_dmeans3D[3 * (size_t)idx] = dmean.x;
   a.dL_dmeans3D[3 * (size_t)idx + 1] = dmean.y;
   a.dL_dmeans3D[3 * (size_t)idx + 2] = dmean.z;
 #pragma unroll
   for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
-  if (a.dL_dsh != nullptr) store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
   if (a.dL_drgb != nullptr) {
     a.dL_drgb[3 * (size_t)idx] = drgb.x;
     a.dL_drgb[3 * (size_t)idx + 1] = drgb.y;
