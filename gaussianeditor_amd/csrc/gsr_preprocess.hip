@@ -669,14 +669,16 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) sh_grad_compose_kernel(int P, int
                                                                      const float* __restrict__ campos,  // (N,3)
                                                                      const float* __restrict__ dL_drgb,  // (N,P,3)
                                                                      float* __restrict__ dL_dsh) {      // (P,M,3)
-  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  if (idx >= P) return;
+  __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
+  const int idx_raw = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  const bool live = idx_raw < P;  // (no early return: the rows leave wave-cooperatively)
+  const int idx = live ? idx_raw : P - 1;
   const int ncoef = (D + 1) * (D + 1);
   V3 dsh[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
   const V3 m = {means3D[3 * (size_t)idx], means3D[3 * (size_t)idx + 1], means3D[3 * (size_t)idx + 2]};
-  for (int v = 0; v < N; ++v) {
+  for (int v = 0; v < (live ? N : 0); ++v) {
     const float* g = dL_drgb + ((size_t)v * P + idx) * 3;
     const V3 dL_dRGB = {g[0], g[1], g[2]};
     // a view that does not see the Gaussian (or whose colour was clamped in all channels) contributes exact zeros
@@ -686,7 +688,12 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) sh_grad_compose_kernel(int P, int
 #pragma unroll
     for (int k = 0; k < 16; ++k) dsh[k] = dsh[k] + t[k];
   }
-  store_sh_grad(dL_dsh + (size_t)idx * M * 3, M, dsh, ncoef);
+  if (M == 16 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15u) == 0) {
+    const int lane = (int)(threadIdx.x & 63u), row0 = idx_raw - lane;
+    if (row0 < P) sh_tile_store_rows(dL_dsh + (size_t)row0 * 48, min(64, P - row0), sh_tile[threadIdx.x >> 6], lane, dsh, ncoef);
+  } else if (live) {
+    store_sh_grad(dL_dsh + (size_t)idx * M * 3, M, dsh, ncoef);
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -758,17 +765,24 @@ __global__ void __launch_bounds__(256) view_message_header_kernel(int64_t P, con
 
 // Adds the messages of all views, view 0 first, per Gaussian in registers (the operations and the order of one process
 // that accumulates the views one after the other; a Gaussian no view touched gets zeros) and writes the dense gradients.
-// One workgroup per 1024-row block: the rows a view sends for the block are the contiguous slice
-// [boff[b], boff[b+1]) of its packed rows, scattered into an LDS position map so that the thread of row g finds its entry.
+// The rows a view sends for the 1024-row message block b are the contiguous slice [boff[b], boff[b+1]) of its packed rows.
+// A workgroup of 256 threads owns 256 consecutive Gaussians, a quarter of a message block: it walks the slice of every
+// view, notes in an LDS position map where the rows of its quarter are, and the thread of Gaussian g then adds them in
+// view order.  The SH rows leave wave-cooperatively (sh_tile_store_rows).
 constexpr int VIEW_BATCH = 8;  // views whose position maps are resident in LDS at a time
-__global__ void __launch_bounds__(VIEW_MSG_ROWS) view_messages_accumulate_kernel(int64_t P, int D, int M, int n_views,
-                                                                                const float* __restrict__ messages,
-                                                                                int64_t stride_words, int64_t cap,
-                                                                                const float* __restrict__ means3D_param,
-                                                                                DenseGrads d) {
-  __shared__ uint16_t posmap[VIEW_BATCH][VIEW_MSG_ROWS];
+__global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(int64_t P, int D, int M, int n_views,
+                                                                              const float* __restrict__ messages,
+                                                                              int64_t stride_words, int64_t cap,
+                                                                              const float* __restrict__ means3D_param,
+                                                                              DenseGrads d) {
+  __shared__ uint16_t posmap[VIEW_BATCH][GAUSS_BLOCK];
+  __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
+  constexpr int QUARTERS = VIEW_MSG_ROWS / GAUSS_BLOCK;
   const int64_t nb = (P + VIEW_MSG_ROWS - 1) / VIEW_MSG_ROWS;
-  const int64_t b = blockIdx.x, g0 = b * VIEW_MSG_ROWS, g = g0 + threadIdx.x;
+  const int64_t b = blockIdx.x / QUARTERS;                       // message block
+  const int64_t g0 = (int64_t)blockIdx.x * GAUSS_BLOCK, g_raw = g0 + threadIdx.x;
+  const bool live = g_raw < P;
+  const int64_t g = live ? g_raw : P - 1;
   const int ncoef = (D + 1) * (D + 1);
   V3 am = {0.f, 0.f, 0.f}, as = {0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f};
   float4 ar = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -777,7 +791,7 @@ __global__ void __launch_bounds__(VIEW_MSG_ROWS) view_messages_accumulate_kernel
 #pragma unroll
   for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
   V3 m = {0.f, 0.f, 0.f};
-  if (g < P && d.sh != nullptr) m = {means3D_param[3 * g], means3D_param[3 * g + 1], means3D_param[3 * g + 2]};
+  if (d.sh != nullptr) m = {means3D_param[3 * g], means3D_param[3 * g + 1], means3D_param[3 * g + 2]};
   for (int vb = 0; vb < n_views; vb += VIEW_BATCH) {
     const int nv = min(VIEW_BATCH, n_views - vb);
     for (int u = 0; u < nv; ++u) posmap[u][threadIdx.x] = 0xffffu;
@@ -785,12 +799,15 @@ __global__ void __launch_bounds__(VIEW_MSG_ROWS) view_messages_accumulate_kernel
     for (int u = 0; u < nv; ++u) {
       const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
       const uint32_t lo = v.boff[b], hi = b + 1 < nb ? v.boff[b + 1] : v.count;
-      for (uint32_t j = lo + threadIdx.x; j < hi; j += VIEW_MSG_ROWS) posmap[u][(int64_t)v.idx[j] - g0] = (uint16_t)(j - lo);
+      for (uint32_t j = lo + threadIdx.x; j < hi; j += GAUSS_BLOCK) {
+        const int64_t q = (int64_t)v.idx[j] - g0;
+        if (q >= 0 && q < GAUSS_BLOCK) posmap[u][q] = (uint16_t)(j - lo);
+      }
     }
     __syncthreads();
     for (int u = 0; u < nv; ++u) {
       const uint32_t o = posmap[u][threadIdx.x];
-      if (o == 0xffffu) continue;
+      if (o == 0xffffu || !live) continue;
       const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
       const size_t j = (size_t)v.boff[b] + o;
       am = am + V3{v.means3D[3 * j], v.means3D[3 * j + 1], v.means3D[3 * j + 2]};
@@ -811,13 +828,22 @@ __global__ void __launch_bounds__(VIEW_MSG_ROWS) view_messages_accumulate_kernel
     }
     __syncthreads();
   }
-  if (g >= P) return;
+  if (d.sh != nullptr) {
+    if (M == 16 && (reinterpret_cast<uintptr_t>(d.sh) & 15u) == 0) {
+      const int lane = (int)(threadIdx.x & 63u);
+      const int64_t row0 = g_raw - lane;
+      if (row0 < P)
+        sh_tile_store_rows(d.sh + (size_t)row0 * 48, (int)min((int64_t)64, P - row0), sh_tile[threadIdx.x >> 6], lane, dsh, ncoef);
+    } else if (live) {
+      store_sh_grad(d.sh + (size_t)g * M * 3, M, dsh, ncoef);
+    }
+  }
+  if (!live) return;
   d.means3D[3 * g] = am.x; d.means3D[3 * g + 1] = am.y; d.means3D[3 * g + 2] = am.z;
   d.scales[3 * g] = as.x; d.scales[3 * g + 1] = as.y; d.scales[3 * g + 2] = as.z;
   d.means2D[3 * g] = a2.x; d.means2D[3 * g + 1] = a2.y; d.means2D[3 * g + 2] = a2.z;
   d.rotations[4 * g] = ar.x; d.rotations[4 * g + 1] = ar.y; d.rotations[4 * g + 2] = ar.z; d.rotations[4 * g + 3] = ar.w;
   d.opacities[g] = ao;
-  if (d.sh != nullptr) store_sh_grad(d.sh + (size_t)g * M * 3, M, dsh, ncoef);
 }
 
 // ----------------------------------------------------------------------------------
@@ -887,8 +913,8 @@ hipError_t launch_view_message_header(hipStream_t s, int64_t P, const float* cam
 hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int M, int n_views, const float* messages,
                                            int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6]) {
   DenseGrads d = {dense[0], dense[1], dense[2], dense[3], dense[4], dense[5]};
-  const int64_t nb = (P + VIEW_MSG_ROWS - 1) / VIEW_MSG_ROWS;
-  hipLaunchKernelGGL(view_messages_accumulate_kernel, dim3((unsigned)nb), dim3(VIEW_MSG_ROWS), 0, s, P, D, M, n_views, messages,
+  const int64_t nblk = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  hipLaunchKernelGGL(view_messages_accumulate_kernel, dim3((unsigned)nblk), dim3(GAUSS_BLOCK), 0, s, P, D, M, n_views, messages,
                      stride_words, cap, means3D, d);
   return hipGetLastError();
 }
