@@ -66,7 +66,8 @@ SIGNATURES = {
                             _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
-    "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_debug_cov3d": (c_int, [_P, c_int, _P, c_float, _P, _P]),
     "gsr_debug_export_binning": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "gsr_debug_blend_backward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                                  c_int64, POINTER(c_int64)]),

@@ -263,12 +263,13 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   if (!dL_dmeans2D || !dL_dconic || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
   if (shs && ((!dL_dsh && !dL_drgb) || !campos)) return GSR_ERR_BAD_ARGUMENT;
   if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
+  if (!cov3D_precomp && !scales) return GSR_ERR_BAD_ARGUMENT;  // the 3D covariance is recomputed, not read from `geom`
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   PreBwdArgs pa;
   pa.P = P; pa.D = D; pa.M = shs ? M : 0;
   pa.means3D = means3D; pa.radii = radii; pa.shs = shs; pa.scales = scales; pa.rotations = rotations;
   pa.scale_modifier = scale_modifier;
-  pa.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
+  pa.cov3D_precomp = cov3D_precomp;
   pa.clamped = g.clamped;
   pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
   pa.h_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:308-309
@@ -510,14 +511,20 @@ int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* worksp
   return GSR_OK;
 }
 
-int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
-                          float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
+int gsr_debug_cov3d(void* stream, int P, const float* scales, float scale_modifier, const float* rotations, float* cov3D) {
+  if (P <= 0) return GSR_OK;
+  if (!scales || !rotations || !cov3D) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_export_cov3d((hipStream_t)stream, P, scales, scale_modifier, rotations, cov3D));
+  return GSR_OK;
+}
+
+int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* rgb,
+                          float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
   if (P <= 0) return GSR_OK;
   if (!geom) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   GSR_HIP(launch_export_geom((hipStream_t)stream, P, g, means2D, depths, rgb, conic_opacity, clamped));
   hipStream_t s = (hipStream_t)stream;
-  if (cov3D) GSR_HIP(hipMemcpyAsync(cov3D, g.cov3D, sizeof(float) * 6 * (size_t)P, hipMemcpyDeviceToDevice, s));
   if (tiles_touched)
     GSR_HIP(hipMemcpyAsync(tiles_touched, g.tiles, sizeof(uint32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
   return GSR_OK;

@@ -35,7 +35,7 @@ struct PreBwdArgs {
   const float* scales;
   const float* rotations;
   float scale_modifier;
-  const float* cov3D;  // computed (geom) or precomputed
+  const float* cov3D_precomp;  // (P,6) or null: then recomputed from scales / rotations as K1 did (never stored)
   const uint8_t* clamped;
   const float* viewmatrix;
   const float* projmatrix;
@@ -108,6 +108,8 @@ hipError_t launch_view_message_header(hipStream_t s, int64_t P, const float* cam
 hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int M, int n_views, const float* messages,
                                            int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6]);
 const uint32_t* compact_block_off_ptr(void* workspace, int64_t P);
+hipError_t launch_export_cov3d(hipStream_t s, int P, const float* scales, float scale_modifier, const float* rotations,
+                               float* cov3D);
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
                               float* conic_opacity, uint8_t* clamped);
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1);

@@ -132,6 +132,26 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t id
   }
 }
 
+// computeCov3D, forward.cu:118-152: Sigma = (S R)^T (S R), upper triangle.  Used by K1 and again by K8+K9 -- the reference
+// keeps the six floats in its geometry buffer between the passes (rasterizer_impl.cu:225, 388); recomputing them from
+// the 28 bytes of scale and rotation the backward reads anyway saves a 24-byte store and a 24-byte load per Gaussian.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales, float scale_modifier,
+                                                     const float* __restrict__ rotations, int idx, float (&c3)[6]) {
+  M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
+  S.m[0][0] = scale_modifier * scales[3 * idx + 0];
+  S.m[1][1] = scale_modifier * scales[3 * idx + 1];
+  S.m[2][2] = scale_modifier * scales[3 * idx + 2];
+  const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                  2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                  2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+  const M3 Mm = mul(S, R);
+  const M3 Sigma = mul(tr(Mm), Mm);
+  c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
+  c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+}
+
 // ----------------------------------------------------------------------------------
 // K1: preprocessCUDA, DGR/cuda_rasterizer/forward.cu:155-256 (+ apply_weights.cu:148-234).
 // Additionally produces the per-block sum of tiles_touched (first level of K2).
@@ -170,22 +190,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
 #pragma unroll
         for (int i = 0; i < 6; ++i) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
       } else {
-        M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
-        S.m[0][0] = a.scale_modifier * a.scales[3 * idx + 0];
-        S.m[1][1] = a.scale_modifier * a.scales[3 * idx + 1];
-        S.m[2][2] = a.scale_modifier * a.scales[3 * idx + 2];
-        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
-        const float r = q.x, x = q.y, y = q.z, z = q.w;
-        const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-        const M3 Mm = mul(S, R);
-        const M3 Sigma = mul(tr(Mm), Mm);
-        c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
-        c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+        cov3d_from_scale_rot(a.scales, a.scale_modifier, a.rotations, idx, c3);
       }
-#pragma unroll
-      for (int i = 0; i < 6; ++i) a.g.cov3D[6 * (size_t)idx + i] = c3[i];
+      // (not stored: the backward recomputes it from the same inputs, bit for bit, instead of reading 24 B back)
 
       // cov2D: forward.cu:74-113
       V3 t = p_view;
@@ -401,8 +408,12 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     const float* proj = cam.proj;
     const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
     float c3[6];
+    if (a.cov3D_precomp != nullptr) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) c3[i] = a.cov3D[6 * (size_t)idx + i];
+      for (int i = 0; i < 6; ++i) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+    } else {
+      cov3d_from_scale_rot(a.scales, a.scale_modifier, a.rotations, idx, c3);  // what K1 computed, bit for bit
+    }
     const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
     const V3 dL_dcon = {gc.x, gc.y, gc.w};
 
@@ -872,6 +883,21 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) export_geom_kernel(int P, const G
     const uint8_t c = live ? g.clamped[idx] : 0;
     clamped[3 * idx] = c & 1; clamped[3 * idx + 1] = (c >> 1) & 1; clamped[3 * idx + 2] = (c >> 2) & 1;
   }
+}
+__global__ void __launch_bounds__(GAUSS_BLOCK) export_cov3d_kernel(int P, const float* scales, float scale_modifier,
+                                                                  const float* rotations, float* cov3D) {
+  const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  if (idx >= P) return;
+  float c3[6];
+  cov3d_from_scale_rot(scales, scale_modifier, rotations, idx, c3);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) cov3D[6 * (size_t)idx + i] = c3[i];
+}
+hipError_t launch_export_cov3d(hipStream_t s, int P, const float* scales, float scale_modifier, const float* rotations,
+                               float* cov3D) {
+  hipLaunchKernelGGL(export_cov3d_kernel, dim3((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK), dim3(GAUSS_BLOCK), 0, s, P, scales, scale_modifier,
+                     rotations, cov3D);
+  return hipGetLastError();
 }
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
                               float* conic_opacity, uint8_t* clamped) {

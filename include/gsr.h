@@ -270,11 +270,15 @@ int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* worksp
 /* ---- introspection used by the parity tests (not needed by the drop-in) ----
  * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
  * scratch buffers into caller-provided DEVICE arrays (any may be NULL):
- *   means2D (P,2) f32, depths (P) f32, cov3D (P,6) f32, rgb (P,3) f32, conic_opacity (P,4) f32,
+ *   means2D (P,2) f32, depths (P) f32, rgb (P,3) f32, conic_opacity (P,4) f32,
  *   tiles_touched (P) u32, clamped (P,3) u8;
- *   keys (R) u64 sorted, point_list (R) u32 sorted; ranges (T,2) u32; final_T (N) f32; n_contrib (N) u32. */
-int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* cov3D,
-                          float* rgb, float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped);
+ *   keys (R) u64 sorted, point_list (R) u32 sorted; ranges (T,2) u32; final_T (N) f32; n_contrib (N) u32.
+ * The 3D covariance (reference: geomState.cov3D, rasterizer_impl.cu:225) is not kept in `geom`: forward and backward
+ * both compute it from scales / rotations with the same operations.  gsr_debug_cov3d evaluates that function for all
+ * P Gaussians into cov3D (P,6). */
+int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D, float* depths, float* rgb,
+                          float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped);
+int gsr_debug_cov3d(void* stream, int P, const float* scales, float scale_modifier, const float* rotations, float* cov3D);
 int gsr_debug_export_binning(void* stream, int P, int64_t R, int W, int H, const void* geom, const void* binning,
                              uint64_t* keys, uint32_t* point_list);
 int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32_t* ranges, float* final_T,

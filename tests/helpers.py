@@ -47,7 +47,7 @@ def settings(case, dev, D=None, scale_modifier=1.0, debug=False):
                                          cam.camera_center.to(dev), False, debug)
 
 
-def hip_state(P, R, W, H, geom, binning, img):
+def hip_state(P, R, W, H, geom, binning, img, cov_inputs=None):
     """Pull every intermediate out of the opaque scratch buffers (device -> numpy)."""
     from gaussianeditor_amd import _native
 
@@ -64,8 +64,16 @@ def hip_state(P, R, W, H, geom, binning, img):
                ranges=torch.zeros((T, 2), dtype=torch.int32, device=dev), final_T=f(H * W),
                n_contrib=torch.zeros(H * W, dtype=torch.int32, device=dev))
     p = lambda k: out[k].data_ptr()  # noqa: E731
-    _native.check("export_geom", L.gsr_debug_export_geom(s, P, geom.data_ptr(), p("means2D"), p("depths"), p("cov3D"),
+    _native.check("export_geom", L.gsr_debug_export_geom(s, P, geom.data_ptr(), p("means2D"), p("depths"),
                                                          p("rgb"), p("conic_opacity"), p("tiles_touched"), p("clamped")))
+    if cov_inputs is not None:  # (scales, rotations, scale_modifier): the 3D covariance both passes compute from them
+        import ctypes
+
+        sc_, rot_, mod_ = cov_inputs
+        sc_, rot_ = sc_.to(dev).contiguous(), rot_.to(dev).contiguous()
+        _native.check("debug_cov3d", L.gsr_debug_cov3d(s, P, sc_.data_ptr(), ctypes.c_float(mod_), rot_.data_ptr(), p("cov3D")))
+    else:
+        del out["cov3D"]
     if R > 0:
         _native.check("export_binning", L.gsr_debug_export_binning(s, P, R, W, H, geom.data_ptr(), binning.data_ptr(),
                                                                    p("keys"), p("point_list")))

@@ -39,7 +39,9 @@ def _compare_forward(O, case, **kw):
     f = oracle_forward(O, case, **kw)
     R, color, depth, radii, geom, binning, img = _run_hip_forward(case, **kw)
     P, W, H = case["sc"]["xyz"].shape[0], case["W"], case["H"]
-    st = hip_state(P, R, W, H, geom, binning, img)
+    cov_inputs = None if kw.get("cov3D_precomp") is not None else (case["sc"]["scaling"], case["sc"]["rotation"],
+                                                                   kw.get("scale_modifier", 1.0))
+    st = hip_state(P, R, W, H, geom, binning, img, cov_inputs)
     vis = f["radii"] > 0
     # --- integers / indices: bit exact
     assert R == f["num_rendered"]
@@ -54,6 +56,8 @@ def _compare_forward(O, case, **kw):
     # --- per-Gaussian floats
     exact = {}
     for k in ("means2D", "depths", "conic_opacity", "cov3D"):
+        if k not in st:  # (cov3D_precomp given: nothing is computed)
+            continue
         a, b = st[k][vis], f[k][vis]
         exact[k] = bool(np.array_equal(a, b))
         assert rel_err(a, b) <= 1e-6, k
