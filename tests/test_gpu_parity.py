@@ -809,6 +809,19 @@ def test_touched_rows_exchange_kernels(oracle, D, s0, P):
     assert torch.equal(dense[5], composed)
     ref = oracle.sh_grad_compose(m3.cpu().numpy(), torch.stack(cams).cpu().numpy(), torch.stack(rgbs).cpu().numpy(), D, M)
     assert np.array_equal(dense[5].cpu().numpy(), ref)
+    # more views than one LDS batch holds (8): the three messages repeated, eleven in all
+    reps = [v % views for v in range(11)]
+    many = messages[reps].contiguous()
+    dense11 = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [torch.full((P, M, 3), float("nan"), device=DEV)]
+    _C.view_messages_accumulate(many, P, cap, D, M, m3, dense11)
+    seq = None
+    for v in reps:
+        cur = [buckets[v].views[name].reshape(P, -1) for name in _ROW_SEGS]
+        seq = [c.clone() for c in cur] if seq is None else [a + c for a, c in zip(seq, cur)]
+    for got, ref11 in zip(dense11[:5], seq):
+        assert torch.equal(got, ref11.reshape(got.shape))
+    assert torch.equal(dense11[5], _C.sh_grad_compose(m3, torch.stack([cams[v] for v in reps]),
+                                                      torch.stack([rgbs[v] for v in reps]), D, M))
     # without an SH target only the five dense segments are written; a single message is a valid batch
     dense2 = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [None]
     _C.view_messages_accumulate(messages[:1], P, cap, D, M, m3, dense2)
