@@ -339,7 +339,12 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint3
 __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                             uint32_t* __restrict__ queues, uint32_t* __restrict__ est) {
-  __shared__ uint32_t hist[WORK_BUCKETS + 1], cursor[WORK_BUCKETS + 1];
+  // Counting sort of the tiles by bucket.  Most tiles of an image fall into a handful of buckets, and LDS atomics on one
+  // address serialise, so every bucket has WORK_SUB counters (chosen by the thread's lane): the order inside a bucket is
+  // free anyway, and the sort's time stops growing with the number of tiles per bucket.
+  constexpr int WORK_SUB = 16, NCNT = (WORK_BUCKETS + 1) * WORK_SUB;
+  __shared__ uint32_t cnt[NCNT];
+  __shared__ uint32_t smem[1024 / 64 + 1];
   // per-quadrant work counters of the forward blend (the items of a quadrant combine their counts with atomicMax)
   for (int i = threadIdx.x; i < 4 * T; i += 1024) est[i] = 0u;
   // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
@@ -348,8 +353,9 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
     queues[(size_t)i * QUEUE_STRIDE] = 0u;      // taken from the front / counter
     queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // (second word of the line: spare)
   }
-  for (int i = threadIdx.x; i <= WORK_BUCKETS; i += 1024) hist[i] = 0;
+  for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
   __syncthreads();
+  const uint32_t sub = threadIdx.x & (WORK_SUB - 1);
   auto bucket_of = [](uint32_t len) -> uint32_t {
     if (len == 0) return WORK_BUCKETS;  // empty tiles: last
     const uint32_t c = (len + 63u) / 64u;
@@ -357,21 +363,25 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
   };
   for (int t = threadIdx.x; t < T; t += 1024) {
     const uint2 r = ranges[t];
-    atomicAdd(&hist[bucket_of(r.y - r.x)], 1u);
+    atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i <= WORK_BUCKETS; ++i) {
-      cursor[i] = run;
-      run += hist[i];
+  {  // exclusive scan over the NCNT counters in (bucket, sub) order: counts -> cursors
+    uint32_t carry = 0;
+    for (int base = 0; base < NCNT; base += 1024) {
+      const int i = base + (int)threadIdx.x;
+      const uint32_t v = i < NCNT ? cnt[i] : 0u;
+      uint32_t chunk;
+      const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
+      if (i < NCNT) cnt[i] = carry + ex;
+      if (i == WORK_BUCKETS * WORK_SUB) meta[0] = carry + ex;  // number of non-empty tiles
+      carry += chunk;
     }
-    meta[0] = cursor[WORK_BUCKETS];  // number of non-empty tiles
   }
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 1024) {
     const uint2 r = ranges[t];
-    const uint32_t pos = atomicAdd(&cursor[bucket_of(r.y - r.x)], 1u);
+    const uint32_t pos = atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
     order[pos] = (uint32_t)t;
   }
 }

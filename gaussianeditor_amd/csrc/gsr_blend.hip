@@ -821,10 +821,13 @@ constexpr int BWD_BUCKETS = 256;
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
                                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                                 uint32_t workgroups, int allow_halves) {  // allow_halves: 0, or the threshold in 1/8 of a fair share
-  __shared__ uint32_t hist[BWD_BUCKETS + 1], cursor[BWD_BUCKETS + 1];
+  // (BWD_SUB counters per bucket, chosen by the lane: see tile_worklist_kernel in gsr_binning.hip)
+  constexpr int BWD_SUB = 16, NCNT = (BWD_BUCKETS + 1) * BWD_SUB;
+  __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];
   __shared__ uint32_t s_threshold;
-  for (int i = threadIdx.x; i <= BWD_BUCKETS; i += 1024) hist[i] = 0;
+  const uint32_t sub = threadIdx.x & (BWD_SUB - 1);
+  for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
   // total work -> the weight above which a tile is cut
   uint32_t mine = 0;
   for (int t = threadIdx.x; t < T; t += 1024) {
@@ -845,34 +848,34 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     const uint4 e = reinterpret_cast<const uint4*>(est)[t];
     const uint32_t w = e.x + e.y + e.z + e.w;
     if (w >= threshold) {
-      atomicAdd(&hist[bucket_of(e.x + e.y)], 1u);
-      atomicAdd(&hist[bucket_of(e.z + e.w)], 1u);
+      atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
+      atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u);
     } else {
-      atomicAdd(&hist[bucket_of(w)], 1u);
+      atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u);
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64) {  // exclusive scan of the bucket sizes by one wave
-    uint32_t run = 0;
-    for (int base = 0; base <= BWD_BUCKETS; base += 64) {
+  {  // exclusive scan over the counters in (bucket, sub) order: counts -> cursors
+    uint32_t carry = 0;
+    for (int base = 0; base < NCNT; base += 1024) {
       const int i = base + (int)threadIdx.x;
-      const uint32_t v = i <= BWD_BUCKETS ? hist[i] : 0u;
-      const uint32_t incl = wave_incl_scan_u32(v);
-      if (i <= BWD_BUCKETS) cursor[i] = run + incl - v;
-      run += (uint32_t)__shfl((int)incl, 63, 64);
+      const uint32_t v = i < NCNT ? cnt[i] : 0u;
+      uint32_t chunk;
+      const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
+      if (i < NCNT) cnt[i] = carry + ex;
+      if (i == BWD_BUCKETS * BWD_SUB) meta[0] = carry + ex;  // number of items with work
+      carry += chunk;
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) meta[0] = cursor[BWD_BUCKETS];  // number of items with work
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 1024) {
     const uint4 e = reinterpret_cast<const uint4*>(est)[t];
     const uint32_t w = e.x + e.y + e.z + e.w;
     if (w >= threshold) {
-      order[atomicAdd(&cursor[bucket_of(e.x + e.y)], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
-      order[atomicAdd(&cursor[bucket_of(e.z + e.w)], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
+      order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
+      order[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
     } else {
-      order[atomicAdd(&cursor[bucket_of(w)], 1u)] = (uint32_t)t;
+      order[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = (uint32_t)t;
     }
   }
 }
