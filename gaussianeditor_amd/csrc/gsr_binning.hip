@@ -44,10 +44,18 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t*
   h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
-#pragma unroll 4
+  // all 16 loads of a thread are issued back to back (unconditional, index clamped): the kernel runs one 4-wave block
+  // per CU and is bound by memory latency, not by bandwidth or the LDS atomics
+  uint32_t kv[SORT_ITEMS];
+#pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    if (k < n) atomicAdd(&h[(keys[k] >> shift) & mask], 1u);
+    kv[i] = keys[k < n ? k : n - 1];
+  }
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+    if (k < n) atomicAdd(&h[(kv[i] >> shift) & mask], 1u);
   }
   __syncthreads();
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
@@ -91,20 +99,13 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
   __shared__ uint32_t skey[SORT_KPB];
   __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
-#pragma unroll
-  for (int i = 0; i < NW; ++i) cnt[i][threadIdx.x] = 0;
-  {
-    uint32_t tot;
-    const uint32_t run = block_excl_scan_u32<SORT_THREADS>(bin_total[threadIdx.x], &tot, smem);
-    gbase[threadIdx.x] = run + hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
-  }
-  __syncthreads();
-
   const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
   const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
   uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
   uint16_t rank[SORT_ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
+  // the block's pairs are requested first, so that they travel while the digit bases below are loaded and scanned
+  // (no load crosses a barrier on its own)
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
@@ -112,6 +113,16 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
     key[i] = keys_in[kc];
     val[i] = IOTA ? (uint32_t)kc : vals_in[kc];
   }
+  const uint32_t my_hist = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < NW; ++i) cnt[i][threadIdx.x] = 0;
+  {
+    uint32_t tot;
+    const uint32_t run = block_excl_scan_u32<SORT_THREADS>(bin_total[threadIdx.x], &tot, smem);
+    gbase[threadIdx.x] = run + my_hist;
+  }
+  __syncthreads();
+
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
