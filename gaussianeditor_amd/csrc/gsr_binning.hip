@@ -37,10 +37,22 @@ __device__ __forceinline__ int f2i_sat(float v) {
 constexpr int RBITS = 8;
 constexpr int RBINS = 1 << RBITS;
 
+// `publish_dst` (first depth pass only): block 0 also copies the four live words of every header slot K1 filled
+// (partial num_rendered, depth-key range) into the caller's pinned, device-mapped host buffer -- the readback of
+// gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before).
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
-                                                                uint32_t nblocks) {
+                                                                uint32_t nblocks, const uint32_t* __restrict__ publish_src,
+                                                                uint32_t* __restrict__ publish_dst) {
   __shared__ uint32_t h[RBINS];
+  if (publish_dst != nullptr && blockIdx.x == 0) {
+    static_assert(SORT_THREADS >= GEOM_HDR_SLOTS * 4, "one thread per published word");
+    if (threadIdx.x < GEOM_HDR_SLOTS * 4) {
+      const uint32_t w = (threadIdx.x >> 2) * GEOM_HDR_SLOT_WORDS + (threadIdx.x & 3u);
+      publish_dst[w] = publish_src[w];
+    }
+    __threadfence_system();
+  }
   h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
@@ -184,13 +196,18 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
 // sequence are launched (pass p reads buffer p & 1), so a caller can enqueue a prefix of the passes, decide how
 // many more are needed and continue.
 static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
-                             const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0) {
+                             const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0,
+                             const uint32_t* publish_src = nullptr, uint32_t* publish_dst = nullptr,
+                             hipEvent_t published = nullptr) {
   const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
   int cur = p0 & 1, shift = 0;
   for (int p = 0; p < p0; ++p) shift += digit_bits[p];
   for (int p = p0; p < npass; ++p) {
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks);
+    const bool pub = p == p0 && publish_dst != nullptr;
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks,
+                       pub ? publish_src : nullptr, pub ? publish_dst : nullptr);
+    if (pub && published != nullptr) (void)hipEventRecord(published, s);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
       hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
@@ -245,8 +262,9 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
 // the smallest and the largest key differ need sorting (the rest is a common prefix), so the caller enqueues the
 // first passes, learns the key range from K1 and adds what is missing.
 static const int kDepthDigits[4] = {8, 8, 8, 8};
-hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1) {
-  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0);
+hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst, hipEvent_t published) {
+  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0,
+                   reinterpret_cast<const uint32_t*>(g.total), publish_dst, published);
   return hipGetLastError();
 }
 // After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).

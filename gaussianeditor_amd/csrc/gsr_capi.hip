@@ -23,7 +23,8 @@ inline int hip_fail(hipError_t e) {
 // Pinned landing slot + event of the num_rendered readback, one per (host thread, device).  This is the only
 // state the library keeps; it owns no device memory.
 struct HostSlot {
-  uint32_t* words = nullptr;  // GEOM_HDR_BYTES
+  uint32_t* words = nullptr;      // GEOM_HDR_BYTES, pinned and mapped into the device's address space
+  uint32_t* dev_words = nullptr;  // the same memory as the device sees it
   hipEvent_t ready = nullptr;
 };
 HostSlot* host_slot() {
@@ -34,12 +35,15 @@ HostSlot* host_slot() {
   HostSlot& h = slots[dev];
   if (h.words == nullptr) {
     void* p = nullptr;
-    if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&h.ready, hipEventDisableTiming) != hipSuccess) {
+    void* dp = nullptr;
+    if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&h.ready, hipEventDisableTiming) != hipSuccess) {
       (void)hipHostFree(p);
       return nullptr;
     }
     h.words = (uint32_t*)p;
+    h.dev_words = (uint32_t*)dp;
   }
   return &h;
 }
@@ -131,13 +135,12 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.g = carve_geom(geom, P);
   GSR_HIP(launch_preprocess(s, a));
   // The one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239).  K1 already holds
-  // num_rendered (and the range of the depth keys), so the copy goes to pinned memory right behind K1, followed by
-  // an event; the first two passes of the depth sort are enqueued behind it and run while the host wakes up.
+  // num_rendered (and the range of the depth keys); the first kernel behind it -- the histogram of the first depth-sort
+  // pass -- writes those words into pinned host memory and is followed by an event.  The first two passes of the
+  // depth sort are enqueued at once and run while the host wakes up.
   HostSlot* slot = host_slot();
   if (slot == nullptr) return hip_fail(hipErrorOutOfMemory);
-  GSR_HIP(hipMemcpyAsync(slot->words, a.g.total, GEOM_HDR_BYTES, hipMemcpyDeviceToHost, s));
-  GSR_HIP(hipEventRecord(slot->ready, s));
-  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2));
+  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, slot->ready));
   // busy-wait: hipEventSynchronize sleeps on an interrupt, which costs far more than the ~80 us being waited for
   for (;;) {
     const hipError_t q = hipEventQuery(slot->ready);
