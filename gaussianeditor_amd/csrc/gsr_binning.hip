@@ -37,21 +37,50 @@ __device__ __forceinline__ int f2i_sat(float v) {
 constexpr int RBITS = 8;
 constexpr int RBINS = 1 << RBITS;
 
-// `publish_dst` (first depth pass only): block 0 also copies the four live words of every header slot K1 filled
-// (partial num_rendered, depth-key range) into the caller's pinned, device-mapped host buffer -- the readback of
-// gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before).
+// `publish_dst` (first depth pass only): block 0 also reduces the per-block partials K1 left (num_rendered, range of the
+// depth keys) and writes the four words into the caller's pinned, device-mapped host buffer -- the readback of
+// gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before) and without a
+// header to clear in front of K1.
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
-                                                                uint32_t nblocks, const uint32_t* __restrict__ publish_src,
-                                                                uint32_t* __restrict__ publish_dst) {
+                                                                uint32_t nblocks, const uint4* __restrict__ publish_src,
+                                                                uint32_t publish_count, uint32_t* __restrict__ publish_dst) {
   __shared__ uint32_t h[RBINS];
   if (publish_dst != nullptr && blockIdx.x == 0) {
-    static_assert(SORT_THREADS >= GEOM_HDR_SLOTS * 4, "one thread per published word");
-    if (threadIdx.x < GEOM_HDR_SLOTS * 4) {
-      const uint32_t w = (threadIdx.x >> 2) * GEOM_HDR_SLOT_WORDS + (threadIdx.x & 3u);
-      publish_dst[w] = publish_src[w];
+    __shared__ unsigned long long psum[SORT_THREADS / 64];
+    __shared__ uint32_t pmax[SORT_THREADS / 64], pinv[SORT_THREADS / 64];
+    unsigned long long sum = 0;
+    uint32_t kmax = 0, kinv = 0;
+    for (uint32_t i = threadIdx.x; i < publish_count; i += SORT_THREADS) {
+      const uint4 v = publish_src[i];
+      sum += v.x;
+      kmax = max(kmax, v.y);
+      kinv = max(kinv, v.z);
     }
-    __threadfence_system();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      sum += __shfl_xor(sum, d, 64);
+      kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+      kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, d, 64));
+    }
+    if (lane_id() == 0) {
+      psum[threadIdx.x >> 6] = sum;
+      pmax[threadIdx.x >> 6] = kmax;
+      pinv[threadIdx.x >> 6] = kinv;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < SORT_THREADS / 64; ++w) {
+        sum += psum[w];
+        kmax = max(kmax, pmax[w]);
+        kinv = max(kinv, pinv[w]);
+      }
+      publish_dst[0] = (uint32_t)sum;
+      publish_dst[1] = (uint32_t)(sum >> 32);
+      publish_dst[GEOM_HDR_KEYMAX] = kmax;
+      publish_dst[GEOM_HDR_KEYINVMAX] = kinv;
+      __threadfence_system();
+    }
   }
   h[threadIdx.x] = 0;
   __syncthreads();
@@ -197,7 +226,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
 // many more are needed and continue.
 static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
                              const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0,
-                             const uint32_t* publish_src = nullptr, uint32_t* publish_dst = nullptr,
+                             const uint4* publish_src = nullptr, uint32_t publish_count = 0, uint32_t* publish_dst = nullptr,
                              hipEvent_t published = nullptr) {
   const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
   int cur = p0 & 1, shift = 0;
@@ -206,7 +235,7 @@ static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* c
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
     const bool pub = p == p0 && publish_dst != nullptr;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks,
-                       pub ? publish_src : nullptr, pub ? publish_dst : nullptr);
+                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr);
     if (pub && published != nullptr) (void)hipEventRecord(published, s);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
@@ -263,8 +292,8 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
 // first passes, learns the key range from K1 and adds what is missing.
 static const int kDepthDigits[4] = {8, 8, 8, 8};
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst, hipEvent_t published) {
-  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0,
-                   reinterpret_cast<const uint32_t*>(g.total), publish_dst, published);
+  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0, g.k1_partials,
+                   (uint32_t)((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK), publish_dst, published);
   return hipGetLastError();
 }
 // After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).

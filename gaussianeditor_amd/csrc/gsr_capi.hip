@@ -147,14 +147,9 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) return hip_fail(q);
   }
-  uint64_t total = 0;
-  uint32_t kmax = 0, kinv = 0;
-  for (int i = 0; i < GEOM_HDR_SLOTS; ++i) {
-    const uint32_t* w = slot->words + i * GEOM_HDR_SLOT_WORDS;
-    total += (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-    kmax = w[GEOM_HDR_KEYMAX] > kmax ? w[GEOM_HDR_KEYMAX] : kmax;
-    kinv = w[GEOM_HDR_KEYINVMAX] > kinv ? w[GEOM_HDR_KEYINVMAX] : kinv;
-  }
+  const uint32_t* w = slot->words;
+  const uint64_t total = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+  const uint32_t kmax = w[GEOM_HDR_KEYMAX], kinv = w[GEOM_HDR_KEYINVMAX];
   // bits above the highest one in which min and max key differ are a common prefix of every visible key
   const uint32_t kmin = ~kinv;
   int nbits = 0;

@@ -35,7 +35,8 @@ struct Geom {
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
   uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order
   uint32_t* block_offs;  // (nb)    exclusive prefix of block_sums
-  uint64_t* total;       // header (GEOM_HDR_BYTES, zeroed before K1), see GEOM_HDR_* below
+  uint64_t* total;       // header (GEOM_HDR_BYTES): word GEOM_HDR_FINAL only, written before it is read -- never cleared
+  uint4* k1_partials;    // (nb)    per K1 block: sum of tiles_touched, max depth key, max complemented key, 0
   // depth ordering of the Gaussians (stable LSD radix sort of (depth bits, index); culled Gaussians last)
   uint32_t* dkey[2];     // (P)     ping-pong depth keys
   uint32_t* dval[2];     // (P)     ping-pong Gaussian indices; dval[header FINAL] holds the final order
@@ -44,14 +45,14 @@ struct Geom {
   size_t bytes;
 };
 
-// Geom header: GEOM_HDR_SLOTS slots of one 128-byte line each.  K1's block b accumulates into slot b % SLOTS
-// (same-line memory-side atomics serialise at ~6 ns each: 3 atomics x 4096 blocks on ONE line cost 80 us, spread
-// over 64 lines they are free); the host sums / maxes the slots after the readback.  u32 word indices in a slot:
+// Geom header.  K1 leaves one partial per block in k1_partials (plain stores: nothing to clear beforehand, no atomics --
+// memory-side atomics on ONE line serialise at ~6 ns each, 3 x 4096 of them cost 80 us); block 0 of the first depth-sort
+// kernel reduces them and writes num_rendered and the key range into the host's pinned slot: u32 words there
 constexpr int GEOM_HDR_SLOTS = 64;
 constexpr int GEOM_HDR_SLOT_WORDS = 32;
-constexpr int GEOM_HDR_KEYMAX = 2;     // [0..1] partial num_rendered (u64); max depth key over the visible Gaussians
+constexpr int GEOM_HDR_KEYMAX = 2;     // [0..1] num_rendered (u64); max depth key over the visible Gaussians
 constexpr int GEOM_HDR_KEYINVMAX = 3;  // max of the complemented key (= ~min key)
-constexpr int GEOM_HDR_FINAL = 4;      // slot 0 only: which ping-pong side (dval[]) holds the depth order
+constexpr int GEOM_HDR_FINAL = 4;      // device header only: which ping-pong side (dval[]) holds the depth order
 constexpr int GEOM_HDR_BYTES = GEOM_HDR_SLOTS * GEOM_HDR_SLOT_WORDS * 4;
 
 __host__ __device__ inline Geom carve_geom(void* base, int P) {
@@ -60,6 +61,7 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   Geom g;
   size_t off = 0;
   g.total = (uint64_t*)(p + off);      off += align_up(GEOM_HDR_BYTES);
+  g.k1_partials = (uint4*)(p + off);   off += align_up(sizeof(uint4) * nb);
   g.rec0 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec1 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec2 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
     kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
     kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, d, 64));
   }
-  // num_rendered = sum of tiles_touched: one 64-bit atomic per block (the header is zeroed before the launch)
+  // num_rendered = sum of tiles_touched
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);  // (its barriers also order the skmax init)
   if (lane_id() == 0 && kinv) {
@@ -299,13 +299,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a
     atomicMax(&skmax[1], kinv);
   }
   __syncthreads();
-  if (threadIdx.x == 0 && total) {
-    uint32_t* hdr = reinterpret_cast<uint32_t*>(a.g.total) + (blockIdx.x % GEOM_HDR_SLOTS) * GEOM_HDR_SLOT_WORDS;
-    atomicAdd(reinterpret_cast<unsigned long long*>(hdr), (unsigned long long)total);
-    // range of the depth keys (max, and max of the complement = ~min): the host sizes the depth sort with it
-    atomicMax(hdr + GEOM_HDR_KEYMAX, skmax[0]);
-    atomicMax(hdr + GEOM_HDR_KEYINVMAX, skmax[1]);
-  }
+  // this block's share of num_rendered and of the range of the depth keys (max, and max of the complement = ~min:
+  // the host sizes the depth sort with it); reduced by the first depth-sort kernel (sort_hist_kernel, publish)
+  if (threadIdx.x == 0) a.g.k1_partials[blockIdx.x] = make_uint4(total, skmax[0], skmax[1], 0u);
 }
 
 // ----------------------------------------------------------------------------------
@@ -862,8 +858,6 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(i
 // ----------------------------------------------------------------------------------
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipError_t e = hipMemsetAsync(a.g.total, 0, GEOM_HDR_BYTES, s);
-  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(preprocess_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
