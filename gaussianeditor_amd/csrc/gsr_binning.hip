@@ -44,7 +44,8 @@ constexpr int RBINS = 1 << RBITS;
 __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t nblocks, const uint4* __restrict__ publish_src,
-                                                                uint32_t publish_count, uint32_t* __restrict__ publish_dst) {
+                                                                uint32_t publish_count, uint32_t* __restrict__ publish_dst,
+                                                                uint32_t publish_seq) {
   __shared__ uint32_t h[RBINS];
   if (publish_dst != nullptr && blockIdx.x == 0) {
     __shared__ unsigned long long psum[SORT_THREADS / 64];
@@ -80,6 +81,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t*
       publish_dst[GEOM_HDR_KEYMAX] = kmax;
       publish_dst[GEOM_HDR_KEYINVMAX] = kinv;
       __threadfence_system();
+      // the host spins on this word (fine-grained pinned memory): no event, hence no barrier packet in the stream
+      __hip_atomic_store(publish_dst + GEOM_HDR_FINAL, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   h[threadIdx.x] = 0;
@@ -227,7 +230,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
 static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
                              const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0,
                              const uint4* publish_src = nullptr, uint32_t publish_count = 0, uint32_t* publish_dst = nullptr,
-                             hipEvent_t published = nullptr) {
+                             uint32_t publish_seq = 0) {
   const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
   int cur = p0 & 1, shift = 0;
   for (int p = 0; p < p0; ++p) shift += digit_bits[p];
@@ -235,8 +238,7 @@ static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* c
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
     const bool pub = p == p0 && publish_dst != nullptr;
     hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks,
-                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr);
-    if (pub && published != nullptr) (void)hipEventRecord(published, s);
+                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
       hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
@@ -291,9 +293,9 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
 // the smallest and the largest key differ need sorting (the rest is a common prefix), so the caller enqueues the
 // first passes, learns the key range from K1 and adds what is missing.
 static const int kDepthDigits[4] = {8, 8, 8, 8};
-hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst, hipEvent_t published) {
+hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst, uint32_t publish_seq) {
   radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0, g.k1_partials,
-                   (uint32_t)((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK), publish_dst, published);
+                   (uint32_t)((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK), publish_dst, publish_seq);
   return hipGetLastError();
 }
 // After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).

@@ -23,9 +23,9 @@ inline int hip_fail(hipError_t e) {
 // Pinned landing slot + event of the num_rendered readback, one per (host thread, device).  This is the only
 // state the library keeps; it owns no device memory.
 struct HostSlot {
-  uint32_t* words = nullptr;      // GEOM_HDR_BYTES, pinned and mapped into the device's address space
+  uint32_t* words = nullptr;      // GEOM_HDR_BYTES, pinned (fine-grained) and mapped into the device's address space
   uint32_t* dev_words = nullptr;  // the same memory as the device sees it
-  hipEvent_t ready = nullptr;
+  uint32_t seq = 0;               // generation of the last readback; the device stores it behind the data
 };
 HostSlot* host_slot() {
   constexpr int MAX_DEV = 64;
@@ -37,11 +37,11 @@ HostSlot* host_slot() {
     void* p = nullptr;
     void* dp = nullptr;
     if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
-    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess ||
-        hipEventCreateWithFlags(&h.ready, hipEventDisableTiming) != hipSuccess) {
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
       (void)hipHostFree(p);
       return nullptr;
     }
+    memset(p, 0, GEOM_HDR_BYTES);
     h.words = (uint32_t*)p;
     h.dev_words = (uint32_t*)dp;
   }
@@ -140,12 +140,21 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   // depth sort are enqueued at once and run while the host wakes up.
   HostSlot* slot = host_slot();
   if (slot == nullptr) return hip_fail(hipErrorOutOfMemory);
-  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, slot->ready));
-  // busy-wait: hipEventSynchronize sleeps on an interrupt, which costs far more than the ~80 us being waited for
-  for (;;) {
-    const hipError_t q = hipEventQuery(slot->ready);
-    if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) return hip_fail(q);
+  const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
+  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
+  // Busy-wait on the generation word the device stores behind the data (an event would put a barrier packet into the
+  // stream -- a 6 us bubble -- and sleeping on an interrupt costs far more than the ~80 us being waited for).  Every
+  // now and then the stream is queried, so that a failed launch ends in an error instead of an endless spin.
+  {
+    volatile const uint32_t* flag = slot->words + GEOM_HDR_FINAL;
+    for (uint64_t spin = 1; *flag != seq; ++spin) {
+      if ((spin & 0x3ffffu) != 0) continue;
+      const hipError_t q = hipStreamQuery(s);
+      if (q == hipErrorNotReady) continue;
+      if (q != hipSuccess) return hip_fail(q);
+      if (*flag != seq) return hip_fail(hipErrorUnknown);  // the stream is idle and nothing was published
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
   }
   const uint32_t* w = slot->words;
   const uint64_t total = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
