@@ -22,7 +22,8 @@
  *     backward (the reference's geomBuffer / binningBuffer / imgBuffer,
  *     rasterize_points.cu:64-69, diff_gaussian_rasterization/__init__.py:122-133).
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it.
- *     The library keeps no global state and is re-entrant.
+ *     The library is re-entrant; the only state it keeps is, per host thread and device, an 8 KiB pinned host
+ *     buffer through which gsr_preprocess receives num_rendered (the device writes it, the host polls it).
  *   - an absent optional input is a NULL pointer (the reference uses empty
  *     tensors for the same purpose, diff_gaussian_rasterization/__init__.py:285-295).
  *   - return value: GSR_OK (0) or a negative gsr_status; never exit()/abort().
