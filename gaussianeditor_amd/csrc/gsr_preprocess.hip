@@ -157,7 +157,9 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s
 // Additionally produces the per-block sum of tiles_touched (first level of K2).
 // ----------------------------------------------------------------------------------
 
-__global__ void __launch_bounds__(GAUSS_BLOCK) preprocess_kernel(const PreArgs a) {
+// (70 VGPRs would allow 7 waves per SIMD; with one 192-byte SH row per thread that many waves thrash the caches --
+//  tools/microbench/rows192.hip: 4.55 TB/s at 2-4 waves per SIMD, 4.16 at 6, 3.24 at 8 -- so the kernel is held at 4: -3 us)
+__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_kernel(const PreArgs a) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   __shared__ uint32_t skmax[2];
   if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
