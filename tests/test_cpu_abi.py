@@ -44,6 +44,39 @@ def test_scratch_sizes_and_sort_bits():
         _native.scratch_sizes(-1, 0, 640, 480)
 
 
+def test_argument_validation_needs_no_gpu():
+    """Every entry point checks its arguments before it touches the device: size queries work and NULL / negative /
+    inconsistent arguments come back as GSR_ERR_BAD_ARGUMENT (-1) on a machine without a GPU."""
+    import ctypes
+
+    from gaussianeditor_amd import _native
+
+    L = _native.lib()
+    n = ctypes.c_int64(0)
+    assert L.gsr_view_message_words(1_000_000, 111_926, ctypes.byref(n)) == 0
+    assert n.value == 4 + 977 + 18 * 111_926  # header, block offsets of ceil(P / 1024) row blocks, 18 words per row
+    assert L.gsr_view_message_words(-1, 0, ctypes.byref(n)) == -1
+    sz = ctypes.c_size_t(0)
+    assert L.gsr_compact_workspace_size(1_000_000, ctypes.byref(sz)) == 0 and sz.value >= 2 * 4 * 977
+    assert L.gsr_knn_workspace_size(1000, ctypes.byref(sz)) == 0 and sz.value > 0
+    r = ctypes.c_int64(7)
+    # (P = 0 is a valid empty call everywhere; no pointer is dereferenced)
+    assert L.gsr_preprocess(None, 0, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
+                            0, 0, None, None, ctypes.byref(r)) == 0 and r.value == 0
+    assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
+                            0, 0, None, None, ctypes.byref(r)) == -1
+    assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
+                            0, 0, None, None, None) == -1
+    assert L.gsr_bin(None, 10, -1, 64, 64, None, None, None, None) == -1
+    assert L.gsr_bin(None, 10, 1 << 31, 64, 64, None, None, None, ctypes.c_void_p(16)) == -3  # GSR_ERR_TOO_MANY
+    assert L.gsr_debug_cov3d(None, 10, None, 1.0, None, None) == -1
+    assert L.gsr_sh_grad_compose(None, 10, 4, 16, 1, None, None, None, None) == -1  # degree > 3
+    assert L.gsr_view_message_plan(None, 10, None, None, None, None, None) == -1
+    assert L.gsr_view_messages_accumulate(None, 10, 3, 16, 0, None, 0, 0, None, None) == -1  # no views
+    assert L.gsr_adam_step(None, 0, None, 1, 0.9, 0.999, 1e-15, None, None) in (0, -1)
+    assert b"31-bit" in L.gsr_status_string(-3)
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly off-GPU, never route through a CPU implementation."""
     import torch
