@@ -76,7 +76,11 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
 
+    import gaussianeditor_amd
     from gaussianeditor_amd import _native
+
+    # GSR_TILE_BOUNDS=alpha (opt-in): bin by the alpha >= 1/255 box; default = the reference's rule
+    gaussianeditor_amd.set_tile_bounds(os.environ.get("GSR_TILE_BOUNDS", "reference"))
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     from gaussianeditor_amd.multiview import GradBucket, multiview_step, render_view_grads
     from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
@@ -261,6 +265,7 @@ def main():
             "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16), {W}x{H}, ring-v1 8 views, one view per GPU "
                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
+                       "tile_bounds": gaussianeditor_amd.get_tile_bounds(),
                        "grad_exchange": exchange, "grad_exchange_route": route["last"],
                        "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},

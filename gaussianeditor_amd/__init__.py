@@ -27,3 +27,28 @@ def install() -> None:
         from .compat import plyfile as _ply
 
         _sys.modules["plyfile"] = _ply
+
+
+def set_tile_bounds(mode: str) -> None:
+    """Opt-in binning rule (process-wide, include/gsr.h: GSR_OPT_TILE_BOUNDS).
+
+    "reference" (default): every Gaussian is binned into the reference's square of side 2 ceil(3 sigma_max); the
+    internal state (num_rendered, instance lists, n_contrib) equals the reference's bit for bit.
+    "alpha": only into the tiles its alpha >= 1/255 level set can reach.  Images, depths, radii, traced weights and
+    gradients are unchanged (every dropped instance would have been skipped at each pixel); fewer instances are
+    sorted and walked.  Scratch buffers of a view must be produced and consumed under one setting."""
+    from . import _native
+
+    if mode not in ("reference", "alpha"):
+        raise ValueError('tile bounds: "reference" or "alpha"')
+    _native.check("gsr_set_option", _native.lib().gsr_set_option(1, 1 if mode == "alpha" else 0))
+
+
+def get_tile_bounds() -> str:
+    import ctypes
+
+    from . import _native
+
+    v = ctypes.c_int(0)
+    _native.check("gsr_get_option", _native.lib().gsr_get_option(1, ctypes.byref(v)))
+    return "alpha" if v.value else "reference"

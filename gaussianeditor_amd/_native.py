@@ -38,6 +38,8 @@ SIGNATURES = {
     "gsr_abi_version": (c_int, []),
     "gsr_status_string": (ctypes.c_char_p, [c_int]),
     "gsr_last_hip_error": (c_int, []),
+    "gsr_set_option": (c_int, [c_int, c_int]),
+    "gsr_get_option": (c_int, [c_int, POINTER(c_int)]),
     "gsr_scratch_sizes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "gsr_sort_key_bits": (c_int, [c_int, c_int]),
     "gsr_preprocess": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,

@@ -336,14 +336,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
   const uint32_t off = block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   uint32_t org = 0, w = 1;
   if (n != 0) {
-    const float4 r1 = g.rec1[idx];  // the only gather: mean2D, depth, radius (K1 stores (float)radii[idx] in .w)
-    const float r = r1.w;
-    // getRect, auxiliary.h:46-56 (same inputs as in K1 => same rectangle, n == width * height)
-    const uint32_t minx = (uint32_t)min(gx, max(0, f2i_sat((r1.x - r) / (float)TILE)));
-    const uint32_t miny = (uint32_t)min(gy, max(0, f2i_sat((r1.y - r) / (float)TILE)));
-    const uint32_t maxx = (uint32_t)min(gx, max(0, f2i_sat((r1.x + r + (float)TILE - 1.0f) / (float)TILE)));
-    org = miny * (uint32_t)gx + minx;  // tile id of the rectangle's first tile
-    w = maxx - minx;
+    const uint2 rc = g.rect[idx];  // the only gather: the rectangle K1 binned the Gaussian into (n == width * height)
+    org = (rc.x >> 16) * (uint32_t)gx + (rc.x & 0xffffu);  // tile id of the rectangle's first tile
+    w = rc.y & 0xffffu;
   }
   s_off[threadIdx.x] = off;
   s_idx[threadIdx.x] = idx;

@@ -94,6 +94,18 @@ int gsr_last_hip_error(void) { return g_last_hip_error; }
 
 int gsr_sort_key_bits(int W, int H) { return sort_key_bits(W, H); }
 
+static int g_opt_tile_bounds = 0;  // GSR_OPT_TILE_BOUNDS (read with relaxed atomics: a plain int shared by the host threads)
+int gsr_set_option(int option, int value) {
+  if (option != GSR_OPT_TILE_BOUNDS || (value != 0 && value != 1)) return GSR_ERR_BAD_ARGUMENT;
+  __atomic_store_n(&g_opt_tile_bounds, value, __ATOMIC_RELAXED);
+  return GSR_OK;
+}
+int gsr_get_option(int option, int* value) {
+  if (option != GSR_OPT_TILE_BOUNDS || !value) return GSR_ERR_BAD_ARGUMENT;
+  *value = __atomic_load_n(&g_opt_tile_bounds, __ATOMIC_RELAXED);
+  return GSR_OK;
+}
+
 int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]) {
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
   sizes[0] = carve_geom(nullptr, P).bytes;
@@ -131,6 +143,7 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.focal_x = W / (2.0f * tan_fovx);
   a.gx = (W + TILE - 1) / TILE; a.gy = (H + TILE - 1) / TILE;
   a.skip_color = skip_color;
+  a.tile_bounds = __atomic_load_n(&g_opt_tile_bounds, __ATOMIC_RELAXED);
   a.radii = radii;
   a.g = carve_geom(geom, P);
   GSR_HIP(launch_preprocess(s, a));

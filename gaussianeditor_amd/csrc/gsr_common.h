@@ -31,6 +31,7 @@ struct Geom {
   float4* rec0;
   float4* rec1;
   float4* rec2;
+  uint2* rect;           // (P)     tile rectangle of a binned Gaussian: x = minx | miny << 16, y = width | height << 16
   uint32_t* tiles;       // (P)     tiles_touched
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
   uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order
@@ -65,6 +66,7 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   g.rec0 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec1 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec2 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
+  g.rect = (uint2*)(p + off);          off += align_up(sizeof(uint2) * (size_t)P);
   g.tiles = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * (size_t)P);
   g.clamped = (uint8_t*)(p + off);     off += align_up((size_t)P);
   g.block_sums = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);

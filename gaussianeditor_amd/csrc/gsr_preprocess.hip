@@ -231,6 +231,41 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       // then counts that tile in num_rendered but never writes the instance (duplicateWithKeys skips radii <= 0,
       // rasterizer_impl.cu:93), so its sort reads an uninitialised key.  Here such a Gaussian touches no tile.
       if (radius_i <= 0) break;
+      uint32_t ntiles = area;
+      if (a.tile_bounds) {
+        // Opt-in (gsr_set_option GSR_OPT_TILE_BOUNDS): bin the Gaussian only into the tiles its alpha >= 1/255 level set
+        // can reach -- the axis-aligned bounding box of that ellipse, with the margins of the blend kernels' own cull test
+        // (gsr_blend.hip: can_touch_quad), intersected with the reference's square.  An instance dropped here passes
+        // `alpha < 1/255 -> continue` (forward.cu:340-344) at every pixel of its tile, so images, radii and gradients
+        // do not change; num_rendered, the lists and n_contrib do.  radii keeps the reference's value.
+        const float o = a.opacities[idx];
+        float hx = (float)radius_i, hy = (float)radius_i;
+        if (o < 1.0f / 255.0f) {
+          ntiles = 0;  // never reaches the threshold (a NaN opacity fails this test and keeps the reference rectangle)
+        } else if (o == o) {
+          const float detc = conx * conz - cony * cony;
+          if (detc > 0.0f) {
+            const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f);
+            const float inv = __builtin_amdgcn_rcpf(detc) * 1.0001f;
+            const float ex = __builtin_sqrtf(tau2 * conz * inv) + 0.01f, ey = __builtin_sqrtf(tau2 * conx * inv) + 0.01f;
+            if (ex == ex && ey == ey) {
+              hx = fminf(hx, ex);
+              hy = fminf(hy, ey);
+            }
+          }
+        }
+        if (ntiles != 0) {
+          // tile t (pixels 16 t .. 16 t + 15) can be reached iff 16 t <= p + h and 16 t + 15 >= p - h.  (The reference's
+          // own upper bound, floor((p + r + 15) / 16), stops one pixel short of p + r; hence "+ TILE" here and the
+          // intersection with the reference's rectangle, which keeps the result a subset of it.)
+          minx = max(minx, (uint32_t)min(a.gx, max(0, f2i_sat((pix - hx) / (float)TILE))));
+          miny = max(miny, (uint32_t)min(a.gy, max(0, f2i_sat((piy - hy) / (float)TILE))));
+          maxx = min(maxx, (uint32_t)min(a.gx, max(0, f2i_sat((pix + hx + (float)TILE) / (float)TILE))));
+          maxy = min(maxy, (uint32_t)min(a.gy, max(0, f2i_sat((piy + hy + (float)TILE) / (float)TILE))));
+          ntiles = (maxx > minx && maxy > miny) ? (maxx - minx) * (maxy - miny) : 0u;
+        }
+      }
+      if (ntiles != 0) a.g.rect[idx] = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
 
       // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -277,7 +312,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       a.g.rec2[idx] = col;
       my_radius_i = radius_i;
       my_depth = p_view.z;
-      my_tiles = area;
+      my_tiles = ntiles;
     } while (false);
     a.radii[idx] = my_radius_i;
     a.g.tiles[idx] = my_tiles;

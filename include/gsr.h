@@ -66,6 +66,20 @@ int gsr_last_hip_error(void);
  * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
 int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]);
 
+/* Process-wide options (the defaults reproduce the reference's internal state bit for bit).
+ *   GSR_OPT_TILE_BOUNDS  0 (default): a Gaussian is binned into every tile of the reference's square of side
+ *                        2 ceil(3 sigma_max) (auxiliary.h:46-56, forward.cu:226-230);
+ *                        1: only into the tiles its alpha >= 1/255 level set can reach (bounding box of that ellipse
+ *                        with conservative margins, intersected with the reference's square).  Every dropped
+ *                        (tile, Gaussian) instance would have been skipped at each pixel by forward.cu:340-344, so images,
+ *                        depths, radii, traced weights and gradients are unchanged -- but num_rendered, the instance
+ *                        lists in the binning scratch and n_contrib differ from the reference's.
+ * Returns GSR_ERR_BAD_ARGUMENT for an unknown option or value.  Applies to gsr_preprocess calls made afterwards; the
+ * scratch buffers of one view must be produced and consumed under the same setting. */
+enum { GSR_OPT_TILE_BOUNDS = 1 };
+int gsr_set_option(int option, int value);
+int gsr_get_option(int option, int* value);
+
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);
 

@@ -363,6 +363,61 @@ def test_degenerate_inputs(oracle):
         assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
 
 
+@pytest.mark.parametrize("P,W,H,s0,seed", [(10000, 256, 256, 0.03, 1), (5000, 640, 360, 0.4, 21), (20000, 512, 512, 0.02, 4),
+                                           (3000, 250, 131, 0.05, 2)])
+def test_alpha_tile_bounds_leave_results_unchanged(oracle, P, W, H, s0, seed):
+    """set_tile_bounds("alpha") (opt-in): a Gaussian is binned only into the tiles its alpha >= 1/255 level set can reach.
+    Images, depths, radii, final_T and traced weights must be bit-identical to the reference rule's (hence to the
+    oracle's), gradients within the usual 1e-5; the instance list of every tile must be a subsequence of the reference
+    rule's list, and on these scenes (faint and elongated splats included) strictly fewer instances are sorted."""
+    import gaussianeditor_amd
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    case = make_case(P, W, H, seed=seed, s0=s0)
+    sc = case["sc"]
+    sc["opacity"][: P // 10] = 0.003                      # below 1/255: never visible in either rule
+    sc["opacity"][P // 10: P // 5] *= 0.05                 # faint: a small level set
+    sc["scaling"][P // 5: P // 2, 0] *= 4.0                # elongated: the bounding box is far from the square
+    G = seed_gradient(H, W, seed) * (H * W)
+    f = oracle_forward(oracle, case)
+    out = {}
+    try:
+        for mode in ("reference", "alpha"):
+            gaussianeditor_amd.set_tile_bounds(mode)
+            R, color, depth, radii, geom, binning, img = _run_hip_forward(case)
+            st = hip_state(P, R, W, H, geom, binning, img)
+            grads = _grads_hip(case, G)
+            if mode == "reference":
+                out["again"] = _grads_hip(case, G)  # a second run under the same rule: the atomics' run-to-run spread
+            w = torch.zeros(P, 1, device=DEV)
+            cnt = torch.zeros(P, 1, dtype=torch.int32, device=DEV)
+            mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(seed)) > 0.5).float()  # 0/1: exact sums
+            GaussianRasterizer(settings(case, DEV, D=0)).apply_weights(
+                sc["xyz"].to(DEV), None, sc["opacity"].to(DEV), None, w, sc["scaling"].to(DEV), sc["rotation"].to(DEV), None,
+                cnt, mask.to(DEV))
+            out[mode] = dict(R=R, color=color.cpu().numpy(), depth=depth.cpu().numpy(), radii=radii.cpu().numpy(), st=st,
+                             grads=grads, w=w.cpu().numpy(), cnt=cnt.cpu().numpy())
+    finally:
+        gaussianeditor_amd.set_tile_bounds("reference")
+    a, b = out["reference"], out["alpha"]
+    assert a["R"] == f["num_rendered"] and 0 < b["R"] < a["R"]
+    print(f"instances {a['R']} -> {b['R']} ({b['R'] / a['R']:.3f})")
+    for k in ("color", "depth", "radii", "w", "cnt"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["st"]["final_T"], b["st"]["final_T"])
+    assert np.array_equal(b["color"], f["color"]) and np.array_equal(b["radii"], f["radii"])
+    for k, v in b["grads"].items():
+        spread = rel_err(out["again"][k], a["grads"][k])
+        print(k, "alpha vs reference", rel_err(v, a["grads"][k]), "reference run to run", spread)
+        assert rel_err(v, a["grads"][k]) <= max(1e-5, 4.0 * spread), k
+    # per tile: the alpha rule's list is the reference rule's list with some entries removed, order kept
+    ra, rb = a["st"]["ranges"], b["st"]["ranges"]
+    la, lb = a["st"]["point_list"], b["st"]["point_list"]
+    for t in range(ra.shape[0]):
+        xa, xb = la[ra[t, 0]:ra[t, 1]], lb[rb[t, 0]:rb[t, 1]]
+        assert xb.size <= xa.size and np.array_equal(xa[np.isin(xa, xb)], xb), t
+
+
 def test_nonfinite_inputs_match_oracle(oracle):
     """NaN / Inf in every input array.  The reference has no guards: a NaN position, scale or rotation fails the
     `det == 0` / rectangle tests and the Gaussian is dropped, a NaN opacity or colour flows into the pixels it covers.

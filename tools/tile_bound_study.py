@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """How many (tile, Gaussian) instances of the benchmark view could never reach alpha >= 1/255 anywhere in their tile?
 ("opacity-aware tile bounds".)  CPU only: runs the oracle's preprocessing on the benchmark scene and
-compares the reference's tile rectangle (square of side 2 ceil(3 sigma_max), auxiliary.h:46-56) with the rectangle of
-the axis-aligned bounding box of the alpha = 1/255 level set, computed with the conservative margins of
-gsr_blend.hip: can_touch_quad.  Usage: python tools/tile_bound_study.py [P W H]"""
+compares the reference's tile rectangle (square of side 2 ceil(3 sigma_max), auxiliary.h:46-56) with what
+gaussianeditor_amd.set_tile_bounds("alpha") bins (K1 in gsr_preprocess.hip): the tiles the axis-aligned bounding box of
+the alpha = 1/255 level set can reach, with the conservative margins of gsr_blend.hip: can_touch_quad.  Usage: python tools/tile_bound_study.py [P W H]"""
 import math
 import os
 import sys
@@ -28,15 +28,20 @@ m, r, co = f["means2D"][vis], f["radii"][vis].astype(np.float32), f["conic_opaci
 gx, gy = (W + 15) // 16, (H + 15) // 16
 
 
-def tiles(hx, hy):
+def rect(hx, hy, upper):
     minx = np.clip(((m[:, 0] - hx) / 16).astype(np.int64), 0, gx)
     miny = np.clip(((m[:, 1] - hy) / 16).astype(np.int64), 0, gy)
-    maxx = np.clip(((m[:, 0] + hx + 15) / 16).astype(np.int64), 0, gx)
-    maxy = np.clip(((m[:, 1] + hy + 15) / 16).astype(np.int64), 0, gy)
-    return (maxx - minx) * (maxy - miny)
+    maxx = np.clip(((m[:, 0] + hx + upper) / 16).astype(np.int64), 0, gx)
+    maxy = np.clip(((m[:, 1] + hy + upper) / 16).astype(np.int64), 0, gy)
+    return minx, miny, maxx, maxy
 
 
-ref = tiles(r, r)
+def area(rc):
+    return np.maximum(rc[2] - rc[0], 0) * np.maximum(rc[3] - rc[1], 0)
+
+
+r0 = rect(r, r, 15)  # the reference: floor((p + r + 15) / 16) stops one pixel short of p + r
+ref = area(r0)
 assert int(ref.sum()) == int(f["num_rendered"])
 A, B, C, o = co[:, 0], co[:, 1], co[:, 2], co[:, 3]
 det = A * C - B * B
@@ -44,6 +49,8 @@ ok = (o >= 1 / 255) & (det > 0)
 tau2 = 2 * (np.log(np.maximum(255 * o, 1e-30)) * 1.001 + 0.01)
 hx = np.where(ok, np.sqrt(np.maximum(tau2 * C / np.where(ok, det, 1) * 1.0001, 0)) + 0.01, r)
 hy = np.where(ok, np.sqrt(np.maximum(tau2 * A / np.where(ok, det, 1) * 1.0001, 0)) + 0.01, r)
-tight = np.where(o < 1 / 255, 0, tiles(np.minimum(hx, r), np.minimum(hy, r)))
+r1 = rect(np.minimum(hx, r), np.minimum(hy, r), 16)  # tile t is reachable iff 16 t <= p + h ...
+r1 = (np.maximum(r1[0], r0[0]), np.maximum(r1[1], r0[1]), np.minimum(r1[2], r0[2]), np.minimum(r1[3], r0[3]))  # ... inside the reference's
+tight = np.where(o < 1 / 255, 0, area(r1))
 print(f"{P} Gaussians, {W}x{H}: visible {int(vis.sum())}; instances {int(ref.sum())} (reference rectangle) -> "
       f"{int(tight.sum())} (alpha >= 1/255 bounding box) = {tight.sum() / ref.sum():.3f}")
