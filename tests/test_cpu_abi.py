@@ -75,6 +75,12 @@ def test_argument_validation_needs_no_gpu():
     assert L.gsr_view_messages_accumulate(None, 10, 3, 16, 0, None, 0, 0, None, None) == -1  # no views
     assert L.gsr_adam_step(None, 0, None, 1, 0.9, 0.999, 1e-15, None, None) in (0, -1)
     assert b"31-bit" in L.gsr_status_string(-3)
+    # process-wide option: only GSR_OPT_TILE_BOUNDS (1) with 0 / 1
+    v = ctypes.c_int(-1)
+    assert L.gsr_get_option(1, ctypes.byref(v)) == 0 and v.value == 0  # the default reproduces the reference's binning
+    assert L.gsr_set_option(1, 2) == -1 and L.gsr_set_option(7, 1) == -1 and L.gsr_get_option(1, None) == -1
+    assert L.gsr_set_option(1, 1) == 0 and L.gsr_get_option(1, ctypes.byref(v)) == 0 and v.value == 1
+    assert L.gsr_set_option(1, 0) == 0
 
 
 def test_no_cpu_fallback():
