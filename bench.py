@@ -2,7 +2,9 @@
 """bench.py -- headline benchmark of the rasterizer hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or started plainly:
+     without WORLD_SIZE in the environment `--gpus N` re-executes itself under torch.distributed.run with N ranks on
+     127.0.0.1, and refuses to run if fewer than N GPUs are visible -- it never reports n_gpus = 1 for --gpus N)
 
 Workload (BASELINE.json metric, config C4): synth-v1 scene, 1,000,000 Gaussians, SH degree 3
 (M = 16), 1920x1080, ring-v1 cameras; rank r renders view r (one view per GPU, weak scaling).
@@ -11,7 +13,8 @@ all-reduce (SUM over the flat bucket, MAX over radii); inputs are resident in HB
 
 One JSON line is printed by rank 0: the train rate is `value`; the forward-only rate
 (renders/s, Mpixels/s), the per-stage GPU times, the roofline of the dominant stage and
-the CPU-oracle baseline ride along in the same object.
+the CPU baselines (the C++/OpenMP oracle and the PyTorch-CPU restatement) ride along in the
+same object.
 """
 from __future__ import annotations
 
@@ -43,6 +46,31 @@ def algorithmic_bytes(P, V, R, N, T, M):
     }
 
 
+def self_launch(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run` with N ranks (one per GPU)."""
+    import socket
+
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n:
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to run a smaller job under that label")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def percentile(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = q * (len(xs) - 1)
+    lo, hi = int(math.floor(i)), int(math.ceil(i))
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,14 +79,19 @@ def main():
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--s0", type=float, default=0.01, help="synth-v1 median scale (0.01 = headline; 0.03-0.05 = deep tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=15, help="oracle train iterations timed for cpu_baseline")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the rasterizer has no CPU fallback)")
@@ -67,6 +100,8 @@ def main():
     shared = os.environ.get("GSR_BENCH_SHARED_GPU", "0") == "1"
     if shared:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world}: only {torch.cuda.device_count()} GPU(s) visible (one rank per GPU)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -81,13 +116,17 @@ def main():
 
     # GSR_TILE_BOUNDS=alpha (opt-in): bin by the alpha >= 1/255 box; default = the reference's rule
     gaussianeditor_amd.set_tile_bounds(os.environ.get("GSR_TILE_BOUNDS", "reference"))
+    # GSR_FAST_EXP=1 (opt-in): hardware 2^x in the blend loops instead of the specified polynomial
+    gaussianeditor_amd.set_fast_exp(os.environ.get("GSR_FAST_EXP", "0") == "1")
+    from gaussianeditor_amd import options
+    flags = options.current_flags()
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
     from gaussianeditor_amd.multiview import GradBucket, multiview_step, render_view_grads
     from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
 
     P, W, H = args.gaussians, args.width, args.height
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    sc = synth_scene(P, seed=0, s0=0.01, sh_degree=3)
+    sc = synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
     M = sc["features"].shape[1]
     cam = ring_cameras(8, W, H)[rank % 8]
     tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
@@ -136,11 +175,19 @@ def main():
         for _ in range(max(args.warmup, 1)):
             train_step()
         sync_all()
+    # Timed region: exactly `steps` steps between barrier + synchronize on both sides (the contract's number).  An event
+    # per step on the launch stream additionally gives the distribution of the GPU-side step time (median / p10 / p90,
+    # SURVEY.md section 8(d)) without adding any synchronisation.
+    cur = torch.cuda.current_stream(dev)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record(cur)
+    for i in range(args.steps):
         radii = train_step()
+        step_ev[i + 1].record(cur)
     sync_all()
     train_s = max_over_ranks(time.perf_counter() - t0)
+    step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
 
     # ---------------- forward only ----------------
     rast = GaussianRasterizer(rs)
@@ -154,11 +201,15 @@ def main():
     for _ in range(max(2, args.warmup // 2)):
         fwd_step()
     sync_all()
+    fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    fwd_ev[0].record(cur)
+    for i in range(args.steps):
         fwd_step()
+        fwd_ev[i + 1].record(cur)
     sync_all()
     fwd_s = max_over_ranks(time.perf_counter() - t0)
+    fwd_ms = [fwd_ev[i].elapsed_time(fwd_ev[i + 1]) for i in range(args.steps)]
 
     # ---------------- per-stage GPU time (HIP events on the launch stream), rank-local ----------------
     L = _native.lib()
@@ -188,17 +239,17 @@ def main():
         ev[0].record(s)
         _native.check("pre", L.gsr_preprocess(sp, P, 3, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
                                               p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
-                                              p(rs.campos), W, H, tfx, tfy, 0, 0, p(radii_t), p(geom), ctypes.byref(Rc)))
+                                              p(rs.campos), W, H, tfx, tfy, 0, 0, flags, p(radii_t), p(geom), ctypes.byref(Rc)))
         ev[1].record(s)
         R = int(Rc.value)
         _, bb, _ = _native.scratch_sizes(P, R, W, H)
         binning = torch.empty(bb, dtype=torch.uint8, device=dev)
         _native.check("bin", L.gsr_bin(sp, P, R, W, H, p(radii_t), p(geom), p(binning), p(img)))
         ev[2].record(s)
-        _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth)))
+        _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
         ev[3].record(s)
         _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
-                                                  p(d_con), p(d_op), p(d_col)))
+                                                  p(d_con), p(d_op), p(d_col), flags))
         ev[4].record(s)
         _native.check("pbw", L.gsr_preprocess_backward(sp, P, 3, M, W, H, p(params["xyz"]), p(params["features"]),
                                                        p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
@@ -232,9 +283,32 @@ def main():
                        1.0, 3)
         cpu_s = time.perf_counter() - t0
         cpu = {"value": args.cpu_iters / cpu_s, "unit": "train iters/s", "cores": O.num_threads(), "kind": "port",
-               "sample": f"{args.cpu_iters} train iterations (fwd+bwd, one 1920x1080 view of the same 1M-Gaussian scene) "
+               "sample": f"{args.cpu_iters} train iterations (fwd+bwd, one {W}x{H} view of the same {P}-Gaussian scene) "
                          f"in {cpu_s:.1f} s with OpenMP over {O.num_threads()} threads; host has {os.cpu_count()} logical cores",
                "pixel_instances_per_view": int(f["pixel_instances"])}
+        # second leg: the PyTorch-CPU restatement of the forward render, same view, all host cores
+        try:
+            from oracle import torch_cpu as TC
+
+            torch.set_num_threads(os.cpu_count() or 1)
+            t0 = time.perf_counter()
+            tc_color, _, _, tc_R = TC.render(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"],
+                                             cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"],
+                                             W, H, tfx, tfy, 1.0, 3)
+            tc_s = time.perf_counter() - t0
+            cpu["torch_cpu"] = {"value": 1.0 / tc_s, "unit": "forward renders/s", "cores": torch.get_num_threads(),
+                                "kind": "port", "sample": f"1 forward render of the same view with oracle/torch_cpu.py "
+                                f"(vectorised float32 torch ops, per-tile cumprod blending) in {tc_s:.1f} s",
+                                "max_abs_diff_vs_oracle_image": float((tc_color - torch.from_numpy(f["color"])).abs().max()),
+                                "oracle_forward_renders_per_s": None}
+            t0 = time.perf_counter()
+            for _ in range(3):
+                O.forward(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], None, None,
+                          cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"], W, H, tfx, tfy,
+                          1.0, 3)
+            cpu["torch_cpu"]["oracle_forward_renders_per_s"] = 3.0 / (time.perf_counter() - t0)
+        except Exception as ex:  # the second leg must never cost the bench line
+            cpu["torch_cpu"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself; it reports the per-launch value
     # measured with rocprofv3 on this same workload and committed under profiles/ (null for any other workload).
@@ -257,15 +331,19 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * train_s / args.steps,
+            "step_ms_gpu": {"median": percentile(step_ms, 0.5), "p10": percentile(step_ms, 0.1), "p90": percentile(step_ms, 0.9),
+                            "note": "HIP events around every timed step on the launch stream of rank 0"},
+            "forward_ms_gpu": {"median": percentile(fwd_ms, 0.5), "p10": percentile(fwd_ms, 0.1), "p90": percentile(fwd_ms, 0.9)},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16), {W}x{H}, ring-v1 8 views, one view per GPU "
+            "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, one view per GPU "
                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
-                       "tile_bounds": gaussianeditor_amd.get_tile_bounds(),
+                       "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
+                       "synth_s0": args.s0,
                        "grad_exchange": exchange, "grad_exchange_route": route["last"],
                        "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},

@@ -83,11 +83,11 @@ int main(int argc, char** argv) {
 
   int64_t R = 0;  // the one blocking readback: sizes the per-instance scratch
   GSR_OK_(gsr_preprocess(stream, P, D, M, d_means, d_scales, fl[2], d_rots, d_opac, d_shs, nullptr, nullptr, d_view, d_proj,
-                         d_campos, W, H, fl[0], fl[1], 0, 0, d_radii, geom, &R));
+                         d_campos, W, H, fl[0], fl[1], 0, 0, /*flags=*/0u, d_radii, geom, &R));
   GSR_OK_(gsr_scratch_sizes(P, R, W, H, sizes));
   if (sizes[1]) HIP_OK(hipMalloc(&binning, sizes[1]));
   GSR_OK_(gsr_bin(stream, P, R, W, H, d_radii, geom, binning, image));
-  GSR_OK_(gsr_blend_forward(stream, P, R, W, H, d_bg, geom, binning, image, d_color, d_depth));
+  GSR_OK_(gsr_blend_forward(stream, P, R, W, H, d_bg, geom, binning, image, d_color, d_depth, /*flags=*/0u));
   HIP_OK(hipStreamSynchronize(stream));
 
   std::vector<float> color(3 * (size_t)W * H), depth((size_t)W * H);

@@ -30,25 +30,39 @@ def install() -> None:
 
 
 def set_tile_bounds(mode: str) -> None:
-    """Opt-in binning rule (process-wide, include/gsr.h: GSR_OPT_TILE_BOUNDS).
+    """Opt-in binning rule: the default of the GSR_FLAG_TILE_BOUNDS_ALPHA flag (include/gsr.h) for renders started
+    from now on (a render's backward always reuses the flags of its forward; `options.override` is per thread).
 
     "reference" (default): every Gaussian is binned into the reference's square of side 2 ceil(3 sigma_max); the
     internal state (num_rendered, instance lists, n_contrib) equals the reference's bit for bit.
     "alpha": only into the tiles its alpha >= 1/255 level set can reach.  Images, depths, radii, traced weights and
     gradients are unchanged (every dropped instance would have been skipped at each pixel); fewer instances are
-    sorted and walked.  Scratch buffers of a view must be produced and consumed under one setting."""
-    from . import _native
+    sorted and walked."""
+    from . import options
 
     if mode not in ("reference", "alpha"):
         raise ValueError('tile bounds: "reference" or "alpha"')
-    _native.check("gsr_set_option", _native.lib().gsr_set_option(1, 1 if mode == "alpha" else 0))
+    f = options.current_flags() & ~options.FLAG_TILE_BOUNDS_ALPHA
+    options.set_default_flags(f | (options.FLAG_TILE_BOUNDS_ALPHA if mode == "alpha" else 0))
 
 
 def get_tile_bounds() -> str:
-    import ctypes
+    from . import options
 
-    from . import _native
+    return "alpha" if options.current_flags() & options.FLAG_TILE_BOUNDS_ALPHA else "reference"
 
-    v = ctypes.c_int(0)
-    _native.check("gsr_get_option", _native.lib().gsr_get_option(1, ctypes.byref(v)))
-    return "alpha" if v.value else "reference"
+
+def set_fast_exp(on: bool) -> None:
+    """Opt-in: the default of GSR_FLAG_FAST_EXP (include/gsr.h) -- exp() of the blend loops on the hardware's
+    v_exp_f32 instead of the exactly specified polynomial.  Results stay within the 1e-5 parity bar; n_contrib /
+    final_T are then no longer bit-identical to the CPU oracle."""
+    from . import options
+
+    f = options.current_flags() & ~options.FLAG_FAST_EXP
+    options.set_default_flags(f | (options.FLAG_FAST_EXP if on else 0))
+
+
+def get_fast_exp() -> bool:
+    from . import options
+
+    return bool(options.current_flags() & options.FLAG_FAST_EXP)

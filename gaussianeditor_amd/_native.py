@@ -8,11 +8,13 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+from ctypes import c_float, c_int, c_int64, c_size_t, c_uint, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
-GSR_ABI_VERSION = 1
+#: GSR_LIBRARY_PATH (development only: A/B timing of differently built libraries, tools/ab_variants.py) replaces the
+#: in-tree library; it must export the same ABI and is loaded under the same "no fallback" rule.
+LIB_PATH = os.environ.get("GSR_LIBRARY_PATH") or os.path.join(_HERE, "libgsr_hip.so")
+GSR_ABI_VERSION = 2
 
 _P = c_void_p
 
@@ -38,18 +40,16 @@ SIGNATURES = {
     "gsr_abi_version": (c_int, []),
     "gsr_status_string": (ctypes.c_char_p, [c_int]),
     "gsr_last_hip_error": (c_int, []),
-    "gsr_set_option": (c_int, [c_int, c_int]),
-    "gsr_get_option": (c_int, [c_int, POINTER(c_int)]),
     "gsr_scratch_sizes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "gsr_sort_key_bits": (c_int, [c_int, c_int]),
     "gsr_preprocess": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
-                               c_float, c_float, c_int, c_int, _P, _P, POINTER(c_int64)]),
+                               c_float, c_float, c_int, c_int, c_uint, _P, _P, POINTER(c_int64)]),
     "gsr_bin": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
-    "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
-    "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
+    "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
-                             _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                             _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
+    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
@@ -67,7 +67,7 @@ SIGNATURES = {
     "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
                             _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
-    "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_cov3d": (c_int, [_P, c_int, _P, c_float, _P, _P]),
     "gsr_debug_export_binning": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),

@@ -172,20 +172,39 @@ struct Entry {
   float4 r0, r1, r2;
 };
 
+// Can the alpha >= 1/255 level set of an entry reach the pixel box [qx0, qx0 + qw] x [qy0, qy0 + qh]?  Conservative:
+// `false` only if every pixel of the box would take `alpha < 1/255 -> continue` (forward.cu:340-344) anyway.
+// The test bounds the level set {d : d^T Q d <= tau2}, tau2 = 2 ln(255 o), by its axis-aligned box with half extents
+// sqrt(tau2 Q_zz / det Q), sqrt(tau2 Q_xx / det Q).  det Q = Q_xx Q_zz - Q_xy^2 cancels for a needle that is not axis
+// aligned: its binary32 value is off by up to ~2e-7 Q_xx Q_zz, and the blend loops' own evaluation of the quadratic form
+// then carries rounding errors of the same relative size against terms that are 1/rho times larger than the result
+// (rho = det Q / (Q_xx Q_zz)).  So the box is trusted only for rho >= 1e-3, where both effects stay below the margins
+// applied here (extents^2 x 1.001 for det, tau2 x 1.001 + 0.02 for the evaluated exponent); worse-conditioned entries
+// are never culled (tools/cull_replay.py replays this arithmetic against the reference's per-pixel evaluation).
 __device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r1, float qx0, float qy0,
                                                float qw = (float)(QUAD - 1), float qh = (float)(QUAD - 1)) {
   // r0 = conic.x, conic.y, conic.z, opacity; r1 = mean.x, mean.y, depth, radius
   const float o = r0.w;
   if (!(o >= 1.0f / 255.0f)) return !(o == o) ? true : false;  // o < 1/255: alpha < 1/255 everywhere (NaN: keep)
-  const float det = r0.x * r0.z - r0.y * r0.y;
-  if (!(det > 0.0f)) return true;  // degenerate / NaN conic: never cull
+  const float xz = r0.x * r0.z;
+  const float det = xz - r0.y * r0.y;
+  if (!(det >= 1e-3f * xz) || !(det > 0.0f)) return true;  // ill-conditioned / degenerate / NaN conic: never cull
   const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f);
-  const float inv = __builtin_amdgcn_rcpf(det) * 1.0001f;
+  const float inv = __builtin_amdgcn_rcpf(det) * 1.001f;
   const float hx = __builtin_sqrtf(tau2 * r0.z * inv) + 0.01f;
   const float hy = __builtin_sqrtf(tau2 * r0.x * inv) + 0.01f;
   if (!(hx == hx) || !(hy == hy)) return true;
   const bool out = (r1.x + hx < qx0) || (r1.x - hx > qx0 + qw) || (r1.y + hy < qy0) || (r1.y - hy > qy0 + qh);
   return !out;
+}
+
+// exp(power) of the blend loops: the exactly specified polynomial (bit-identical to the CPU oracle), or -- per-call
+// opt-in GSR_FLAG_FAST_EXP -- the hardware's 2^x on power * log2(e) (one multiply + one quarter-rate v_exp_f32 instead
+// of 12 full-rate instructions).
+template <bool FAST>
+__device__ __forceinline__ float blend_exp(float power) {
+  if (FAST) return __builtin_amdgcn_exp2f(power * 0x1.715476p+0f);
+  return gsr_expf_noclamp(power);
 }
 
 // Walks list positions in chunks.  FORWARD: positions [0,len) ascending, lane l of chunk c holds
@@ -247,7 +266,7 @@ struct ChunkWalker {
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-template <bool PROFILE, bool AUX, int SPLIT>
+template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
                                              uint64_t* prof_cyc) {
   PixelWave pw;
@@ -329,7 +348,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
           cc[u] = s2[j + u];
           const float dx = gg[u].x - pfx, dy = gg[u].y - pfy;
           const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
-          al[u] = fminf(0.99f, co.w * gsr_expf_noclamp(power));
+          al[u] = fminf(0.99f, co.w * blend_exp<FAST>(power));
           ok[u] = !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
         }
         // pin the four footprints ahead of the serial part: otherwise the optimiser sinks each one into the masked
@@ -371,7 +390,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   }
 }
 
-template <bool PROFILE, bool AUX, int SPLIT>
+template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
 __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
@@ -380,7 +399,7 @@ __global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) 
   run_work_queue<SPLIT>(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE, AUX, SPLIT>(a, tile, quad, prof_visited, prof_cyc);
+      forward_item<PROFILE, AUX, SPLIT, FAST>(a, tile, quad, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
       for (uint32_t q = 0; q < 4; ++q) {
@@ -448,7 +467,7 @@ constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
 // the CU.  The global float atomics execute at the memory side on this chip and were the largest single
 // cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
 // 2-3 of a tile's 4 quadrants.
-template <int ABLATE>  // 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
+template <int ABLATE, bool FAST>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
 __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
                                               float4 (*s2)[WAVE], uint32_t* sid, float (*sacc)[WAVE], uint32_t* s_maxc) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -536,7 +555,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
         dxs[u] = g.x - pfx;
         dys[u] = g.y - pfy;
         const float power = blend_power_prescaled(cos_[u].x, cos_[u].y, cos_[u].z, dxs[u], dys[u]);
-        G[u] = gsr_expf_noclamp(power);  // only used where alpha >= 1/255, i.e. far above the clamp
+        G[u] = blend_exp<FAST>(power);  // only used where alpha >= 1/255, i.e. far above the clamp
         al[u] = fminf(0.99f, cos_[u].w * G[u]);
         contrib[u] = (c < last_contributor) && !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
         any = any || contrib[u];
@@ -639,7 +658,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   }
 }
 
-template <int ABLATE>
+template <int ABLATE, bool FAST>
 __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[WAVE];
@@ -659,7 +678,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    backward_tile<ABLATE>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
+    backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
     if (prof) {
       const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
       if (ntiles == 0) first = d;
@@ -711,7 +730,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
 // mask value(s) to weights[id] and C to cnt[id] (the reference increments cnt inside its
 // channel loop, apply_weights.cu:331-339).
 // ----------------------------------------------------------------------------------
-template <int C, int SPLIT>
+template <int C, int SPLIT, bool FAST>
 __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
   // item code as in forward_item: quad | sub << 2 (SPLIT = 1: the whole quadrant)
@@ -771,7 +790,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
       const float4 co = s0[j];
       const float dx = g.x - pfx, dy = g.y - pfy;
       const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
-      const float alpha = fminf(0.99f, co.w * gsr_expf_noclamp(power));
+      const float alpha = fminf(0.99f, co.w * blend_exp<FAST>(power));
       bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.0f - alpha);
       const bool term = hit && (test_T < 0.0001f);
@@ -802,9 +821,9 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   }
 }
 
-template <int C, int SPLIT>
+template <int C, int SPLIT, bool FAST>
 __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
-  run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C, SPLIT>(a, tile, quad); });
+  run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C, SPLIT, FAST>(a, tile, quad); });
 }
 
 // Work list of the backward blend: tiles ordered by the work the FORWARD blend measured for them (entries evaluated,
@@ -928,17 +947,20 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   const unsigned grid = blend_grid_size(), quads = 4u * (unsigned)(a.gx * a.gy);
   const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
   const dim3 g(grid), b(WAVE);
+#define GSR_FWD_LAUNCH(AUXV, FASTV)                                                                        \
+  do {                                                                                                     \
+    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 1, FASTV>), g, b, 0, s, a);       \
+    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 2, FASTV>), g, b, 0, s, a);  \
+    else hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 4, FASTV>), g, b, 0, s, a);                  \
+  } while (0)
   if (a.profile)
-    hipLaunchKernelGGL((blend_forward_kernel<true, false, 1>), g, b, 0, s, a);
+    hipLaunchKernelGGL((blend_forward_kernel<true, false, 1, false>), g, b, 0, s, a);
   else if (a.colors3 != nullptr) {
-    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, true, 1>), g, b, 0, s, a);
-    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, true, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((blend_forward_kernel<false, true, 4>), g, b, 0, s, a);
+    if (a.fast_exp) GSR_FWD_LAUNCH(true, true); else GSR_FWD_LAUNCH(true, false);
   } else {
-    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, false, 1>), g, b, 0, s, a);
-    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, false, 2>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((blend_forward_kernel<false, false, 4>), g, b, 0, s, a);
+    if (a.fast_exp) GSR_FWD_LAUNCH(false, true); else GSR_FWD_LAUNCH(false, false);
   }
+#undef GSR_FWD_LAUNCH
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
@@ -961,11 +983,14 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size() / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
-    case 1: hipLaunchKernelGGL(blend_backward_kernel<1>, g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(blend_backward_kernel<2>, g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(blend_backward_kernel<3>, g, b, 0, s, a); break;
-    case 4: hipLaunchKernelGGL(blend_backward_kernel<4>, g, b, 0, s, a); break;
-    default: hipLaunchKernelGGL(blend_backward_kernel<0>, g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((blend_backward_kernel<3, false>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((blend_backward_kernel<4, false>), g, b, 0, s, a); break;
+    default:
+      if (a.fast_exp) hipLaunchKernelGGL((blend_backward_kernel<0, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((blend_backward_kernel<0, false>), g, b, 0, s, a);
+      break;
   }
   return hipGetLastError();
 }
@@ -977,11 +1002,15 @@ hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
   static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
   const int split = !split_ok || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);  // as the forward
   const dim3 g(grid), b(WAVE);
-#define GSR_TRACE_LAUNCH(CC)                                                                     \
-  do {                                                                                           \
-    if (split == 1) hipLaunchKernelGGL((trace_weights_kernel<CC, 1>), g, b, 0, s, a);             \
-    else if (split == 2) hipLaunchKernelGGL((trace_weights_kernel<CC, 2>), g, b, 0, s, a);        \
-    else hipLaunchKernelGGL((trace_weights_kernel<CC, 4>), g, b, 0, s, a);                        \
+#define GSR_TRACE_LAUNCH2(CC, FASTV)                                                                    \
+  do {                                                                                                  \
+    if (split == 1) hipLaunchKernelGGL((trace_weights_kernel<CC, 1, FASTV>), g, b, 0, s, a);             \
+    else if (split == 2) hipLaunchKernelGGL((trace_weights_kernel<CC, 2, FASTV>), g, b, 0, s, a);        \
+    else hipLaunchKernelGGL((trace_weights_kernel<CC, 4, FASTV>), g, b, 0, s, a);                        \
+  } while (0)
+#define GSR_TRACE_LAUNCH(CC)                                                         \
+  do {                                                                               \
+    if (a.fast_exp) GSR_TRACE_LAUNCH2(CC, true); else GSR_TRACE_LAUNCH2(CC, false);  \
   } while (0)
   switch (a.C) {
     case 1: GSR_TRACE_LAUNCH(1); break;
@@ -989,6 +1018,7 @@ hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
     case 3: GSR_TRACE_LAUNCH(3); break;
     default: return hipErrorInvalidValue;
   }
+#undef GSR_TRACE_LAUNCH2
 #undef GSR_TRACE_LAUNCH
   return hipGetLastError();
 }

@@ -1,7 +1,10 @@
 // gsr_capi.hip -- the C ABI declared in include/gsr.h: argument checking, scratch carving and
-// kernel sequencing.  No device memory is allocated here; the only state is the pinned readback slot (host_slot).
+// kernel sequencing.  No device memory is allocated here and no option state is kept (behaviour flags arrive with every
+// call); the only state is the pool of pinned readback slots (host_slot).
 #include <math.h>
 #include <string.h>
+
+#include <mutex>
 
 
 #include "gsr_kernels.h"
@@ -20,32 +23,75 @@ inline int hip_fail(hipError_t e) {
     if (_e != hipSuccess) return hip_fail(_e); \
   } while (0)
 
-// Pinned landing slot + event of the num_rendered readback, one per (host thread, device).  This is the only
-// state the library keeps; it owns no device memory.
+// Pinned landing slots of the num_rendered readback.  A host thread checks one slot per device out of a process-wide
+// pool on its first gsr_preprocess for that device and hands it back when the thread exits (no HIP call is made in a
+// thread destructor: the runtime may already be gone); slots are reused by later threads and never freed, so the
+// pool is bounded by the largest number of threads that were inside the library at once.  This is the only state the
+// library keeps; it owns no device memory.
 struct HostSlot {
   uint32_t* words = nullptr;      // GEOM_HDR_BYTES, pinned (fine-grained) and mapped into the device's address space
   uint32_t* dev_words = nullptr;  // the same memory as the device sees it
   uint32_t seq = 0;               // generation of the last readback; the device stores it behind the data
+  int device = -1;
+  HostSlot* next_free = nullptr;
 };
-HostSlot* host_slot() {
-  constexpr int MAX_DEV = 64;
-  static thread_local HostSlot slots[MAX_DEV];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  HostSlot& h = slots[dev];
-  if (h.words == nullptr) {
-    void* p = nullptr;
-    void* dp = nullptr;
-    if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) return nullptr;
-    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess) {
-      (void)hipHostFree(p);
-      return nullptr;
-    }
-    memset(p, 0, GEOM_HDR_BYTES);
-    h.words = (uint32_t*)p;
-    h.dev_words = (uint32_t*)dp;
+constexpr int MAX_DEV = 64;
+std::mutex g_pool_mutex;
+HostSlot* g_pool_free[MAX_DEV] = {};  // per device: slots no thread holds at the moment
+
+struct ThreadSlots {
+  HostSlot* held[MAX_DEV] = {};
+  ~ThreadSlots() {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (int d = 0; d < MAX_DEV; ++d)
+      if (held[d] != nullptr) {
+        held[d]->next_free = g_pool_free[d];
+        g_pool_free[d] = held[d];
+      }
   }
-  return &h;
+};
+
+// The slot of the calling thread for the device `stream` belongs to (NOT the thread's current device: a C-ABI caller
+// may hand over a stream of another device).
+HostSlot* host_slot(hipStream_t stream) {
+  static thread_local ThreadSlots mine;
+  int dev = 0;
+  hipDevice_t sdev = 0;
+  if (stream != nullptr && hipStreamGetDevice(stream, &sdev) == hipSuccess)
+    dev = (int)sdev;  // (hipDevice_t is the ordinal)
+  else if (hipGetDevice(&dev) != hipSuccess)
+    return nullptr;
+  if (dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (mine.held[dev] != nullptr) return mine.held[dev];
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool_free[dev] != nullptr) {
+      HostSlot* h = g_pool_free[dev];
+      g_pool_free[dev] = h->next_free;
+      h->next_free = nullptr;
+      mine.held[dev] = h;
+      return h;
+    }
+  }
+  int cur = -1;
+  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+  void* p = nullptr;
+  void* dp = nullptr;
+  HostSlot* h = nullptr;
+  if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
+    if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) {
+      memset(p, 0, GEOM_HDR_BYTES);
+      h = new HostSlot();
+      h->words = (uint32_t*)p;
+      h->dev_words = (uint32_t*)dp;
+      h->device = dev;
+      mine.held[dev] = h;
+    } else {
+      (void)hipHostFree(p);
+    }
+  }
+  if (switched) (void)hipSetDevice(cur);
+  return h;
 }
 
 inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
@@ -94,18 +140,6 @@ int gsr_last_hip_error(void) { return g_last_hip_error; }
 
 int gsr_sort_key_bits(int W, int H) { return sort_key_bits(W, H); }
 
-static int g_opt_tile_bounds = 0;  // GSR_OPT_TILE_BOUNDS (read with relaxed atomics: a plain int shared by the host threads)
-int gsr_set_option(int option, int value) {
-  if (option != GSR_OPT_TILE_BOUNDS || (value != 0 && value != 1)) return GSR_ERR_BAD_ARGUMENT;
-  __atomic_store_n(&g_opt_tile_bounds, value, __ATOMIC_RELAXED);
-  return GSR_OK;
-}
-int gsr_get_option(int option, int* value) {
-  if (option != GSR_OPT_TILE_BOUNDS || !value) return GSR_ERR_BAD_ARGUMENT;
-  *value = __atomic_load_n(&g_opt_tile_bounds, __ATOMIC_RELAXED);
-  return GSR_OK;
-}
-
 int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]) {
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
   sizes[0] = carve_geom(nullptr, P).bytes;
@@ -117,13 +151,13 @@ int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]) {
 int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
                    const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                    const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
-                   int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, int32_t* radii,
-                   void* geom, int64_t* num_rendered_host) {
+                   int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, unsigned flags,
+                   int32_t* radii, void* geom, int64_t* num_rendered_host) {
   (void)prefiltered;  // the reference only uses it to trap on an impossible condition (auxiliary.h:156-160)
   if (num_rendered_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
   *num_rendered_host = 0;
   if (P == 0) return GSR_OK;
-  if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
+  if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3 || (flags & ~GSR_FLAG_ALL)) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
   if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr)) return GSR_ERR_BAD_ARGUMENT;
   if (!skip_color) {
@@ -143,28 +177,34 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.focal_x = W / (2.0f * tan_fovx);
   a.gx = (W + TILE - 1) / TILE; a.gy = (H + TILE - 1) / TILE;
   a.skip_color = skip_color;
-  a.tile_bounds = __atomic_load_n(&g_opt_tile_bounds, __ATOMIC_RELAXED);
+  a.tile_bounds = (flags & GSR_FLAG_TILE_BOUNDS_ALPHA) ? 1 : 0;
   a.radii = radii;
   a.g = carve_geom(geom, P);
   GSR_HIP(launch_preprocess(s, a));
   // The one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239).  K1 already holds
   // num_rendered (and the range of the depth keys); the first kernel behind it -- the histogram of the first depth-sort
-  // pass -- writes those words into pinned host memory and is followed by an event.  The first two passes of the
-  // depth sort are enqueued at once and run while the host wakes up.
-  HostSlot* slot = host_slot();
+  // pass -- writes those words into pinned, device-mapped host memory, a generation word last.  The first two passes of
+  // the depth sort are enqueued at once and run while the host waits.
+  HostSlot* slot = host_slot(s);
   if (slot == nullptr) return hip_fail(hipErrorOutOfMemory);
   const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
   GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
-  // Busy-wait on the generation word the device stores behind the data (an event would put a barrier packet into the
-  // stream -- a 6 us bubble -- and sleeping on an interrupt costs far more than the ~80 us being waited for).  Every
-  // now and then the stream is queried, so that a failed launch ends in an error instead of an endless spin.
+  // Poll the generation word (an event would put a barrier packet into the stream -- a 6 us bubble -- and sleeping on
+  // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED: after ~2 ms (earlier work
+  // is still queued on the stream, or a launch failed) the thread stops burning a core and blocks in
+  // hipStreamSynchronize, which also surfaces any launch error; the word is then either there or the call fails.
   {
     volatile const uint32_t* flag = slot->words + GEOM_HDR_FINAL;
-    for (uint64_t spin = 1; *flag != seq; ++spin) {
-      if ((spin & 0x3ffffu) != 0) continue;
-      const hipError_t q = hipStreamQuery(s);
-      if (q == hipErrorNotReady) continue;
-      if (q != hipSuccess) return hip_fail(q);
+    bool seen = false;
+    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+      if (*flag == seq) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+    }
+    if (!seen) {
+      GSR_HIP(hipStreamSynchronize(s));
       if (*flag != seq) return hip_fail(hipErrorUnknown);  // the stream is idle and nothing was published
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
@@ -197,8 +237,9 @@ int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, 
 }
 
 int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                      const void* binning, void* image, float* out_color, float* out_depth) {
-  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth) return GSR_ERR_BAD_ARGUMENT;
+                      const void* binning, void* image, float* out_color, float* out_depth, unsigned flags) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth || (flags & ~GSR_FLAG_ALL))
+    return GSR_ERR_BAD_ARGUMENT;
   if (R > 0 && (!geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
@@ -206,13 +247,15 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
   a.out_color = out_color;
   a.out_depth = out_depth;
+  a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }
 
 int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth) {
-  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color) return GSR_ERR_BAD_ARGUMENT;
+                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth,
+                          unsigned flags) {
+  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || (flags & ~GSR_FLAG_ALL)) return GSR_ERR_BAD_ARGUMENT;
   if (R > 0 && (!geom || !binning || !colors)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
@@ -225,6 +268,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   a.final_T = nullptr;
   a.n_contrib = nullptr;
   a.work_est = nullptr;
+  a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }
@@ -252,7 +296,8 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                        const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors) {
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags) {
+  if (flags & ~GSR_FLAG_ALL) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0 || R == 0) return GSR_OK;
   if (P < 0 || R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
   if (!bg || !geom || !binning || !image || !dL_dpix || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors)
@@ -266,6 +311,7 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   a.dL_dconic = dL_dconic;
   a.dL_dopacity = dL_dopacity;
   a.dL_dcolors = dL_dcolors;
+  a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
   return GSR_OK;
 }
@@ -434,12 +480,12 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
                  const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii, const void* geom,
                  const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
                  float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                 float* dL_dscales, float* dL_drots) {
+                 float* dL_dscales, float* dL_drots, unsigned flags) {
   (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
   if (P == 0) return GSR_OK;
   if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
   int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, dL_dmeans2D, dL_dconic,
-                              dL_dopacity, dL_dcolors);
+                              dL_dopacity, dL_dcolors, flags);
   if (st != GSR_OK) return st;
   return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
@@ -456,8 +502,9 @@ int gsr_mark_visible(void* stream, int P, const float* means3D, const float* vie
 }
 
 int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const void* geom, const void* binning,
-                      const void* image, const float* image_weights, float* weights, int32_t* cnt) {
+                      const void* image, const float* image_weights, float* weights, int32_t* cnt, unsigned flags) {
   if (C < 1 || C > 3) return GSR_ERR_BAD_CHANNELS;
+  if (flags & ~GSR_FLAG_ALL) return GSR_ERR_BAD_ARGUMENT;
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || !image || !image_weights || !weights || !cnt) return GSR_ERR_BAD_ARGUMENT;
   if (R == 0) return GSR_OK;
   if (!geom || !binning) return GSR_ERR_BAD_ARGUMENT;
@@ -469,6 +516,7 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   a.image_weights = image_weights;
   a.weights = weights;
   a.cnt = cnt;
+  a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_trace_weights((hipStream_t)stream, a));
   return GSR_OK;
 }

@@ -86,6 +86,7 @@ struct BlendArgs {
   const float* image_weights;
   float* weights;
   int32_t* cnt;
+  int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block

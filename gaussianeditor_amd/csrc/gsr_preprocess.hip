@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       if (radius_i <= 0) break;
       uint32_t ntiles = area;
       if (a.tile_bounds) {
-        // Opt-in (gsr_set_option GSR_OPT_TILE_BOUNDS): bin the Gaussian only into the tiles its alpha >= 1/255 level set
+        // Opt-in (GSR_FLAG_TILE_BOUNDS_ALPHA): bin the Gaussian only into the tiles its alpha >= 1/255 level set
         // can reach -- the axis-aligned bounding box of that ellipse, with the margins of the blend kernels' own cull test
         // (gsr_blend.hip: can_touch_quad), intersected with the reference's square.  An instance dropped here passes
         // `alpha < 1/255 -> continue` (forward.cu:340-344) at every pixel of its tile, so images, radii and gradients
@@ -243,10 +243,11 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
         if (o < 1.0f / 255.0f) {
           ntiles = 0;  // never reaches the threshold (a NaN opacity fails this test and keeps the reference rectangle)
         } else if (o == o) {
-          const float detc = conx * conz - cony * cony;
-          if (detc > 0.0f) {
+          const float xz = conx * conz;
+          const float detc = xz - cony * cony;
+          if (detc > 0.0f && detc >= 1e-3f * xz) {  // (an ill-conditioned conic keeps the reference rectangle: can_touch_quad)
             const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f);
-            const float inv = __builtin_amdgcn_rcpf(detc) * 1.0001f;
+            const float inv = __builtin_amdgcn_rcpf(detc) * 1.001f;
             const float ex = __builtin_sqrtf(tau2 * conz * inv) + 0.01f, ey = __builtin_sqrtf(tau2 * conx * inv) + 0.01f;
             if (ex == ex && ey == ey) {
               hx = fminf(hx, ex);

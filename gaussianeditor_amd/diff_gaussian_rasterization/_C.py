@@ -9,24 +9,35 @@ fails if the HIP library is not built.
 from __future__ import annotations
 
 import ctypes
-from typing import Callable, Optional, Tuple
+import threading
+from typing import Optional
 
 import torch
 
-from .. import _native
+from .. import _native, options
 
 _native.lib()  # fail loudly at import time if the extension is missing
 
 NUM_CHANNELS = 3  # config.h:15
 
-#: optional allocator for the backward's gradient outputs: fn(name, shape, zero) -> tensor.
-#: Used by gaussianeditor_amd.multiview to make the gradients views of one flat all-reduce bucket.
-_grad_allocator: Optional[Callable[[str, Tuple[int, ...], bool], torch.Tensor]] = None
+#: optional allocator for the backward's gradient outputs: fn(name, shape, zero) -> tensor | None.
+#: Used by gaussianeditor_amd.multiview to make the gradients views of one flat all-reduce bucket.  PER THREAD: the
+#: web UI's render thread and a training thread must not see each other's allocator, and
+#: autograd runs a backward on the thread that called it when invoked through torch.autograd.grad / .backward().
+_tls = threading.local()
 
 
 def set_grad_allocator(fn) -> None:
-    global _grad_allocator
-    _grad_allocator = fn
+    """Install (or with None remove) the gradient allocator of the CALLING thread."""
+    _tls.grad_allocator = fn
+
+
+def _allocator():
+    return getattr(_tls, "grad_allocator", None)
+
+
+def _flags(flags) -> int:
+    return options.current_flags() if flags is None else int(flags)
 
 
 def _require_cuda(t: torch.Tensor, name: str) -> None:
@@ -63,7 +74,7 @@ def _check_means(means3D: torch.Tensor) -> None:
 
 
 def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations, opacity, sh, cov3D_precomp, colors,
-                        viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, skip_color, radii):
+                        viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, skip_color, radii, flags):
     L = _native.lib()
     s = _stream(dev)
     gbytes, _, ibytes = _native.scratch_sizes(P, 0, W, H)
@@ -73,7 +84,7 @@ def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations
     _native.check("gsr_preprocess", L.gsr_preprocess(
         s, P, D, M, _ptr(means3D), _ptr(scales), scale_modifier, _ptr(rotations), _ptr(opacity), _ptr(sh),
         _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H, tan_fovx, tan_fovy,
-        int(bool(prefiltered)), int(skip_color), radii.data_ptr(), geom.data_ptr(), ctypes.byref(R)))
+        int(bool(prefiltered)), int(skip_color), flags, radii.data_ptr(), geom.data_ptr(), ctypes.byref(R)))
     R = int(R.value)
     _, bbytes, _ = _native.scratch_sizes(P, R, W, H)
     binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
@@ -83,9 +94,11 @@ def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, flags=None):
     """RasterizeGaussiansCUDA, rasterize_points.cu:35-95 ->
-    (num_rendered, color(3,H,W), depth(1,H,W), radii(P) i32, geomBuffer, binningBuffer, imgBuffer)."""
+    (num_rendered, color(3,H,W), depth(1,H,W), radii(P) i32, geomBuffer, binningBuffer, imgBuffer).
+    `flags` (extension, keyword): GSR_FLAG_* of include/gsr.h; None = options.current_flags()."""
+    flags = _flags(flags)
     _check_means(means3D)
     _require_cuda(means3D, "means3D")
     dev = means3D.device
@@ -109,21 +122,22 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         R, geom, binning, img = _preprocess_and_bin(dev, P, int(degree), M, means3D, scales, float(scale_modifier),
                                                     rotations, opacity, sh, cov3D_precomp, colors, viewmatrix,
                                                     projmatrix, campos, W, H, float(tan_fovx), float(tan_fovy),
-                                                    prefiltered, 0, radii)
+                                                    prefiltered, 0, radii, flags)
         _native.check("gsr_blend_forward", _native.lib().gsr_blend_forward(
             _stream(dev), P, R, W, H, background.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr(),
-            out_color.data_ptr(), out_depth.data_ptr()))
+            out_color.data_ptr(), out_depth.data_ptr(), flags))
         if debug:
             torch.cuda.synchronize(dev)  # CHECK_CUDA, auxiliary.h:166-173
     return R, out_color, out_depth, radii, geom, binning, img
 
 
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
-                            image_width, debug=False):
+                            image_width, debug=False, flags=None):
     """Extension (no reference counterpart): a second image of the view whose state
     (`geomBuffer`, `binningBuffer`, `imgBuffer`, `num_rendered`) an earlier rasterize_gaussians() call returned,
     blended with the per-Gaussian `colors` (P,3) instead -- K6 only, what the reference obtains by running the whole
     forward again with override_color.  Forward only; the saved state of the first render is left intact."""
+    flags = _flags(flags)
     _require_cuda(colors, "colors")
     dev = colors.device
     P, H, W = int(colors.size(0)), int(image_height), int(image_width)
@@ -136,15 +150,16 @@ def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binnin
     with torch.cuda.device(dev):
         _native.check("gsr_blend_forward_aux", _native.lib().gsr_blend_forward_aux(
             _stream(dev), P, int(num_rendered), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-            imgBuffer.data_ptr(), colors.data_ptr(), out.data_ptr(), None))
+            imgBuffer.data_ptr(), colors.data_ptr(), out.data_ptr(), None, flags))
         if debug:
             torch.cuda.synchronize(dev)
     return out
 
 
 def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
-    if _grad_allocator is not None:
-        t = _grad_allocator(name, tuple(shape), zero)
+    fn = _allocator()
+    if fn is not None:
+        t = fn(name, tuple(shape), zero)
         if t is not None:
             return t
     return (torch.zeros if zero else torch.empty)(shape, dtype=torch.float32, device=dev)
@@ -152,9 +167,11 @@ def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:97-157 ->
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    `flags` (extension, keyword): the flags the forward of this view ran with; None = options.current_flags()."""
+    flags = _flags(flags)
     dev = means3D.device
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
@@ -174,12 +191,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     has_scales = scales.numel() != 0
     # accumulated with atomics -> zero-filled (with as few fill launches as possible: one block, or two when a
     # gradient allocator owns means2D + opacities); the rest is fully written by the kernels
-    joint = _grad_allocator("means2D+opacities", (4 * P,), True) if _grad_allocator is not None else None
+    grad_alloc = _allocator()
+    # "means2D+opacities": an allocator may hand back BOTH accumulators, already zeroed by ONE fill of the span that
+    # holds them, as a pair (dL_dmeans2D (P,3), dL_dopacity (P,1))
+    joint = grad_alloc("means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
     if joint is not None:
-        dL_dmeans2D, dL_dopacity = joint[:3 * P].view(P, 3), joint[3 * P:].view(P, 1)
+        dL_dmeans2D, dL_dopacity = joint
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
-    elif _grad_allocator is not None:
+    elif grad_alloc is not None:
         dL_dmeans2D = _alloc("means2D", (P, 3), True, dev)
         dL_dopacity = _alloc("opacities", (P, 1), True, dev)
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
@@ -192,7 +212,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dcov3D = _alloc("cov3Ds_precomp", (P, 6), False, dev)
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
     # colour gradient INSTEAD of the (P,M,3) SH gradient; dL_dsh is then returned as None and rebuilt after the exchange
-    dL_drgb = _grad_allocator("sh_rgb", (P, 3), False) if (_grad_allocator is not None and M != 0) else None
+    dL_drgb = grad_alloc("sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
     dL_dsh = None if dL_drgb is not None else _alloc("sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc("scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc("rotations", (P, 4), not has_scales, dev)
@@ -206,13 +226,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
-                dL_drotations.data_ptr() if has_scales else None))
+                dL_drotations.data_ptr() if has_scales else None, flags))
         else:
             if int(R) > 0:
                 _native.check("gsr_blend_backward", L.gsr_blend_backward(
                     _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
                     imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
-                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr()))
+                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), flags))
             _native.check("gsr_preprocess_backward_rgb", L.gsr_preprocess_backward_rgb(
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
@@ -314,9 +334,10 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def apply_weights(background, means3D, weights, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                   projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-                  image_weights, cnt, debug):
+                  image_weights, cnt, debug, flags=None):
     """applyWeightsGaussiansCUDA, rasterize_points.cu:177-234.  `weights` (P,C) float32 and
     `cnt` (P[,1]) int32 are updated in place; returns None."""
+    flags = _flags(flags)
     _check_means(means3D)
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     C = int(image_weights.size(0))
@@ -343,10 +364,10 @@ def apply_weights(background, means3D, weights, opacity, scales, rotations, scal
         # (rasterizer_impl.cu:384, apply_weights.cu:219): no colour is needed at all here.
         R, geom, binning, img = _preprocess_and_bin(dev, P, 0, 0, means3D, scales, float(scale_modifier), rotations,
                                                     opacity, None, cov3D_precomp, None, viewmatrix, projmatrix, None,
-                                                    W, H, float(tan_fovx), float(tan_fovy), prefiltered, 1, radii)
+                                                    W, H, float(tan_fovx), float(tan_fovy), prefiltered, 1, radii, flags)
         _native.check("gsr_trace_weights", _native.lib().gsr_trace_weights(
             _stream(dev), P, R, W, H, C, geom.data_ptr(), _ptr(binning), img.data_ptr(), image_weights.data_ptr(),
-            w_work.data_ptr(), c_work.data_ptr()))
+            w_work.data_ptr(), c_work.data_ptr(), flags))
         if debug:
             torch.cuda.synchronize(dev)
     if w_work is not weights:

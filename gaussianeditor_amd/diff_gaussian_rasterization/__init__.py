@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _C
+from .. import options as _options
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_RasterizeGaussians"]
 
@@ -63,14 +64,18 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings, aux_colors=None):
         rs = raster_settings
+        # behaviour flags (include/gsr.h: GSR_FLAG_*) are fixed per render: read once here, reused by the backward
+        flags = _options.current_flags()
+        run = lambda fn: (lambda *a: fn(*a, flags=flags))  # noqa: E731
         # argument order of _C.rasterize_gaussians (rasterize_points.h:17-36)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
         num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_native(
-            _C.rasterize_gaussians, args, rs.debug, "snapshot_fw.dump",
+            run(_C.rasterize_gaussians), args, rs.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = rs
+        ctx.gsr_flags = flags
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
@@ -80,7 +85,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         if aux_colors is None:
             return color, radii, depth
         # extension: a second, gradient-free image of the same view with other colours (K6 only)
-        aux = _call_native(_C.rasterize_gaussians_aux,
+        aux = _call_native(run(_C.rasterize_gaussians_aux),
                            (rs.bg, aux_colors.detach(), num_rendered, geomBuffer, binningBuffer, imgBuffer, rs.image_height,
                             rs.image_width, rs.debug), rs.debug, "snapshot_fw.dump",
                            "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
@@ -102,7 +107,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_native(
-             _C.rasterize_gaussians_backward, args, rs.debug, "snapshot_bw.dump",
+             lambda *a: _C.rasterize_gaussians_backward(*a, flags=ctx.gsr_flags), args, rs.debug, "snapshot_bw.dump",
              "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # one slot per forward() input (:213-225)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,

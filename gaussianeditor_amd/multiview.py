@@ -46,10 +46,17 @@ __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview
 _SLOTS = ("means3D", "sh", "scales", "rotations", "means2D", "opacities")
 
 
+def _pad4(n: int) -> int:
+    return (n + 3) & ~3
+
+
 class GradBucket:
     """Flat fp32 buffer `[means3D 3P | sh 3MP | scales 3P | rotations 4P | means2D 3P | opacities P]`
-    = (14 + 3M) * P floats (248 MB at P = 1M, M = 16).  means2D and opacities, the two gradients the backward
-    accumulates with atomics, are adjacent so that one fill clears both."""
+    = (14 + 3M) * P floats (248 MB at P = 1M, M = 16), every segment START rounded up to a multiple of 4 floats:
+    the kernels use dwordx4 accesses on (P,4) / (P,M,3) rows, so a segment must begin on a 16-byte boundary whatever
+    P is (P is arbitrary after a densification or a prune; the padding words stay zero and travel with the all-reduce).
+    means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent so that one fill
+    clears both."""
 
     def __init__(self, P: int, M: int, device, sh_exchange: str = "auto"):
         self.P, self.M = int(P), int(M)
@@ -62,36 +69,36 @@ class GradBucket:
         shapes = {"means3D": (P, 3), "sh": (P, M, 3), "opacities": (P, 1), "scales": (P, 3), "rotations": (P, 4),
                   "means2D": (P, 3)}
         slots = _SLOTS if sh_exchange == "direct" else tuple(s for s in _SLOTS if s != "sh")
-        n = sum(int(torch.Size(shapes[s]).numel()) for s in slots)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        offs, off = {}, 0
+        for name in slots:
+            offs[name] = off
+            off = _pad4(off + int(torch.Size(shapes[name]).numel()))
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        if self.flat.data_ptr() % 16 != 0:  # (torch's allocators hand out >= 256-byte alignment; be explicit anyway)
+            raise RuntimeError("GradBucket: the flat buffer is not 16-byte aligned")
         self.views: Dict[str, torch.Tensor] = {}
         #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
         self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
         self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
         self.last_route = None  # what the last multiview_step's exchange did: "local" | "rows" | "sparse" | "dense"
         self.last_counts = None  # touched rows per view, as gathered by the last touched-rows exchange
-        off = 0
         for name in slots:
             cnt = int(torch.Size(shapes[name]).numel())
-            # every segment starts on a 16-byte boundary as long as P % 4 == 0; otherwise the kernels'
-            # dwordx4 stores on (P,4) rows would be misaligned -> fall back to private tensors for those.
-            self.views[name] = self.flat[off:off + cnt].view(shapes[name])
-            off += cnt
+            self.views[name] = self.flat[offs[name]:offs[name] + cnt].view(shapes[name])
+        # the span one fill clears for the two atomically accumulated gradients (means2D .. end of opacities)
+        self._acc_span = (offs["means2D"], offs["opacities"] + P)
 
-    def allocator(self, name: str, shape: Tuple[int, ...], zero: bool) -> Optional[torch.Tensor]:
+    def allocator(self, name: str, shape: Tuple[int, ...], zero: bool):
         if name == "sh_rgb":  # "rgb" exchange mode: ask the backward for dL_dRGB instead of dL_dsh
             return self.rgb if (self.rgb is not None and tuple(shape) == (self.P, 3)) else None
-        if name == "means2D+opacities":  # one contiguous, zeroed (4P,) block for both accumulators
-            m2, op = self.views["means2D"], self.views["opacities"]
-            if tuple(shape) != (4 * self.P,) or m2.data_ptr() % 16 != 0 or op.data_ptr() != m2.data_ptr() + 12 * self.P:
+        if name == "means2D+opacities":  # both accumulators, zeroed by ONE fill of the span that holds them
+            if tuple(shape) != (4 * self.P,):
                 return None
-            off = m2.storage_offset()
-            block = self.flat[off:off + 4 * self.P]
             if zero:
-                block.zero_()
-            return block
+                self.flat[self._acc_span[0]:self._acc_span[1]].zero_()
+            return self.views["means2D"], self.views["opacities"]
         v = self.views.get(name)
-        if v is None or tuple(v.shape) != tuple(shape) or v.data_ptr() % 16 != 0:
+        if v is None or tuple(v.shape) != tuple(shape):
             return None
         if zero:
             v.zero_()
@@ -134,6 +141,16 @@ def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacitie
         g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
     grads = dict(zip(names, g))
+    if bucket is not None:
+        # Every gradient must now BE its bucket segment.  If the backward had to hand out a private tensor for one
+        # (it never should: all segments are 16-byte aligned), copy it in rather than exchange stale bucket contents.
+        for name, t in grads.items():
+            v = bucket.views.get(name)
+            if t is None or v is None or (name == "sh" and bucket.sh_exchange == "rgb"):
+                continue
+            if t.data_ptr() != v.data_ptr():
+                v.copy_(t.reshape(v.shape))
+            grads[name] = v
     if bucket is not None and bucket.sh_exchange == "rgb":
         bucket.sh_degree = int(settings.sh_degree)
         bucket.means3D_ref = m3.detach()
@@ -190,7 +207,7 @@ def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Op
 
 
 def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = None, group=None, sparse="auto",
-                         sparse_threshold: float = 0.5, rows="auto"):
+                         sparse_threshold: float = 0.5, rows="auto", force_exchange: bool = False):
     """The exchange step of an iteration: SUM over ranks of the gradient bucket, MAX over ranks of the screen
     radii.  No-op in a single-process run.
 
@@ -204,8 +221,10 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
 
     In the "rgb" mode of the bucket `rows` ("auto" | True | False) selects the touched-rows exchange described in the
     module docstring; "auto" uses it unless the gathered row counts say the dense route moves fewer bytes.  Returns the
-    route taken: "local", "rows", "sparse" or "dense"."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    route taken: "local", "rows", "sparse" or "dense".  `force_exchange` runs the collectives even in a group of one
+    rank (tests: every route on the RCCL backend of a single-GPU box)."""
+    single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
+    if single and not (force_exchange and dist.is_available() and dist.is_initialized()):
         if bucket.sh_exchange == "rgb":  # a single view: the "sum" has one term
             bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
                                                      bucket.sh_degree, bucket.M)
@@ -251,7 +270,7 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
 
 
 def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, torch.Tensor], dL_dcolor: torch.Tensor,
-                   bucket: GradBucket, group=None, rows="auto"):
+                   bucket: GradBucket, group=None, rows="auto", sparse="auto", force_exchange: bool = False):
     """One data-parallel iteration for this rank's view: forward, backward, gradient all-reduce.
     `params`: xyz, opacity, features, scaling, rotation (activated, as the rasterizer consumes them).
     After the call `bucket.views[...]` hold the batch-summed gradients on every rank and
@@ -259,14 +278,14 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
     pending = []
 
     def start_radii(radii):  # known after the forward: the collective runs while the backward computes
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange):
             batch_max = radii.clone()  # (the backward still needs this view's own radii)
             pending.append((batch_max, dist.all_reduce(batch_max, op=dist.ReduceOp.MAX, group=group, async_op=True)))
 
     color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
                                                    params["scaling"], params["rotation"], dL_dcolor, bucket,
                                                    after_forward=start_radii)
-    bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows)
+    bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows, sparse=sparse, force_exchange=force_exchange)
     for batch_max, work in pending:
         work.wait()
         radii = batch_max

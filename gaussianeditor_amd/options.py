@@ -1,0 +1,45 @@
+"""Behaviour switches of the rasterizer (include/gsr.h: GSR_FLAG_*).
+
+The native library keeps no option state: the flags travel with every call.  This module holds the DEFAULT a render
+starts with; `_RasterizeGaussians.forward` reads it once, stores the value in the autograd context, and the backward
+of that render reuses the stored value -- so changing the default between a forward and its backward (or from another
+thread: the web UI renders while a training thread steps) can never pair a view's kernels with different flags.
+`override(...)` sets flags for the calling thread only.
+"""
+from __future__ import annotations
+
+import contextlib
+import threading
+
+FLAG_TILE_BOUNDS_ALPHA = 1
+FLAG_FAST_EXP = 2
+FLAG_ALL = 3
+
+_default = 0
+_local = threading.local()
+
+
+def current_flags() -> int:
+    """Flags a render started now by this thread runs with."""
+    f = getattr(_local, "flags", None)
+    return _default if f is None else f
+
+
+def set_default_flags(flags: int) -> None:
+    global _default
+    if flags & ~FLAG_ALL:
+        raise ValueError(f"unknown flag bits in {flags:#x}")
+    _default = int(flags)
+
+
+@contextlib.contextmanager
+def override(flags: int):
+    """Run the renders started inside the block, by this thread, with `flags`."""
+    if flags & ~FLAG_ALL:
+        raise ValueError(f"unknown flag bits in {flags:#x}")
+    prev = getattr(_local, "flags", None)
+    _local.flags = int(flags)
+    try:
+        yield
+    finally:
+        _local.flags = prev

@@ -22,8 +22,9 @@
  *     backward (the reference's geomBuffer / binningBuffer / imgBuffer,
  *     rasterize_points.cu:64-69, diff_gaussian_rasterization/__init__.py:122-133).
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it.
- *     The library is re-entrant; the only state it keeps is, per host thread and device, an 8 KiB pinned host
- *     buffer through which gsr_preprocess receives num_rendered (the device writes it, the host polls it).
+ *     The library is re-entrant and keeps no option state (behaviour switches travel with every call as
+ *     `flags`); the only thing it owns is a small pool of 8 KiB pinned host buffers, one checked out per host thread
+ *     and device, through which gsr_preprocess receives num_rendered (the device writes it, the host polls it).
  *   - an absent optional input is a NULL pointer (the reference uses empty
  *     tensors for the same purpose, diff_gaussian_rasterization/__init__.py:285-295).
  *   - return value: GSR_OK (0) or a negative gsr_status; never exit()/abort().
@@ -41,7 +42,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 typedef enum gsr_status {
   GSR_OK = 0,
@@ -66,19 +67,27 @@ int gsr_last_hip_error(void);
  * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
 int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]);
 
-/* Process-wide options (the defaults reproduce the reference's internal state bit for bit).
- *   GSR_OPT_TILE_BOUNDS  0 (default): a Gaussian is binned into every tile of the reference's square of side
- *                        2 ceil(3 sigma_max) (auxiliary.h:46-56, forward.cu:226-230);
- *                        1: only into the tiles its alpha >= 1/255 level set can reach (bounding box of that ellipse
- *                        with conservative margins, intersected with the reference's square).  Every dropped
- *                        (tile, Gaussian) instance would have been skipped at each pixel by forward.cu:340-344, so images,
- *                        depths, radii, traced weights and gradients are unchanged -- but num_rendered, the instance
- *                        lists in the binning scratch and n_contrib differ from the reference's.
- * Returns GSR_ERR_BAD_ARGUMENT for an unknown option or value.  Applies to gsr_preprocess calls made afterwards; the
- * scratch buffers of one view must be produced and consumed under the same setting. */
-enum { GSR_OPT_TILE_BOUNDS = 1 };
-int gsr_set_option(int option, int value);
-int gsr_get_option(int option, int* value);
+/* Per-call behaviour flags (ABI 2; ABI 1 had a process-wide gsr_set_option instead).  The library keeps no option
+ * state: every entry point below that takes `flags` receives them with the call, and the calls that belong to one view
+ * (gsr_preprocess ... gsr_backward / gsr_trace_weights) must be given the same value.  0 reproduces the reference's
+ * internal state bit for bit.
+ *   GSR_FLAG_TILE_BOUNDS_ALPHA  (read by gsr_preprocess) a Gaussian is binned only into the tiles its alpha >= 1/255
+ *                        level set can reach (bounding box of that ellipse with conservative margins, intersected with
+ *                        the reference's square of side 2 ceil(3 sigma_max), auxiliary.h:46-56, forward.cu:226-230).
+ *                        Every dropped (tile, Gaussian) instance would have been skipped at each pixel by
+ *                        forward.cu:340-344, so images, depths, radii, traced weights and gradients are unchanged --
+ *                        but num_rendered, the instance lists in the binning scratch and n_contrib differ from the
+ *                        reference's.
+ *   GSR_FLAG_FAST_EXP    (read by the blend / trace entry points) exp(power) is evaluated with the hardware's
+ *                        v_exp_f32 (2^x, 1 ulp) on power * log2(e) instead of the exactly specified polynomial
+ *                        gsr_expf.  Colours / depths / gradients stay within the 1e-5 parity
+ *                        bar, but a pixel whose alpha or transmittance sits within a rounding of a threshold
+ *                        (1/255, 1e-4) may take the other branch than the CPU oracle, so n_contrib / final_T are no
+ *                        longer bit-identical to it (they are not bit-identical to the reference's libm build either).
+ * Unknown bits are rejected with GSR_ERR_BAD_ARGUMENT. */
+#define GSR_FLAG_TILE_BOUNDS_ALPHA 1u
+#define GSR_FLAG_FAST_EXP 2u
+#define GSR_FLAG_ALL 3u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);
@@ -100,7 +109,8 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    float scale_modifier, const float* rotations, const float* opacities, const float* shs,
                    const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                    const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
-                   int prefiltered, int skip_color, int32_t* radii, void* geom, int64_t* num_rendered_host);
+                   int prefiltered, int skip_color, unsigned flags, int32_t* radii, void* geom,
+                   int64_t* num_rendered_host);
 
 /* K3 + K4 + K5: emit one (tile, Gaussian) pair per touched tile in depth order of the Gaussians, stable
  * radix sort on the tile id (together with the depth ordering done in gsr_preprocess this yields exactly the
@@ -115,7 +125,7 @@ int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, 
  * forward.cu:261-409.  out_color (3,H,W), out_depth (1,H,W) are fully written
  * (background where nothing is blended); final_T / n_contrib go to `image`. */
 int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                      const void* binning, void* image, float* out_color, float* out_depth);
+                      const void* binning, void* image, float* out_color, float* out_depth, unsigned flags);
 
 /* Auxiliary forward render of the SAME view with other per-Gaussian colours: blends
  * `colors` (P,3) through the geometry / binning state an earlier gsr_preprocess + gsr_bin left in the scratch buffers,
@@ -125,7 +135,8 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
  * gsr_blend_forward would produce.  final_T / n_contrib in `image` are NOT touched, so the backward of the main render
  * is unaffected; no backward exists for the auxiliary image.  out_depth may be NULL. */
 int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth);
+                          const void* binning, void* image, const float* colors, float* out_color, float* out_depth,
+                          unsigned flags);
 
 /* K7 + K8 + K9: the whole backward.  Reference: Rasterizer::backward,
  * rasterizer_impl.cu:289-341 (BACKWARD::render then BACKWARD::preprocess).
@@ -141,14 +152,14 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
                  const void* geom, const void* binning, const void* image, const float* dL_dpix,
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
-                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots);
+                 float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, unsigned flags);
 
 /* The two halves of gsr_backward as separate entry points (same argument meaning), so a caller
  * can time or overlap them: K7 = BACKWARD::render (backward.cu:399-557), K8+K9 = BACKWARD::preprocess
  * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward. */
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                        const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors);
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags);
 int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
@@ -185,7 +196,7 @@ int gsr_mark_visible(void* stream, int P, const float* means3D, const float* vie
  * Reference: APPLY_WEIGHTS::render, apply_weights.cu:239-381.  Unlike the reference,
  * image_weights is only read for pixels inside the image (hazard a). */
 int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const void* geom, const void* binning,
-                      const void* image, const float* image_weights, float* weights, int32_t* cnt);
+                      const void* image, const float* image_weights, float* weights, int32_t* cnt, unsigned flags);
 
 /* ---- the simple-knn submodule -------------------------------------------------
  * mean_dist2[i] = mean of the squared distances from point i to its 3 nearest other points (exact), i.e.

@@ -23,7 +23,7 @@ def _opt(t):
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
+                        prefiltered, debug, flags=None):
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     H, W = int(image_height), int(image_width)
@@ -42,7 +42,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None):
     f = _registry[int(geomBuffer.view(torch.int64)[0])]
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     g = O.backward(f, dL_dout_color, means3D, _opt(scales), _opt(rotations), _opt(sh), _opt(colors), _opt(cov3D_precomp),
@@ -54,8 +54,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                              ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
                              ("cov3Ds_precomp", "dL_dcov3D", (P, 6)), ("sh", "dL_dsh", (P, M, 3)),
                              ("scales", "dL_dscales", (P, 3)), ("rotations", "dL_drotations", (P, 4))):
-        if name == "sh" and M != 0 and real_C._grad_allocator is not None:
-            rgb = real_C._grad_allocator("sh_rgb", (P, 3), False)
+        if name == "sh" and M != 0 and real_C._allocator() is not None:
+            rgb = real_C._allocator()("sh_rgb", (P, 3), False)
             if rgb is not None:  # "rgb" exchange mode: the clamp-masked colour gradient instead of dL_dsh
                 vis = (f["radii"] > 0)[:, None]
                 masked = np.where(np.logical_and(vis, f["clamped"] == 0), g["dL_dcolors"].reshape(P, 3), 0.0)
@@ -126,7 +126,7 @@ def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
 
 
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,
-                            image_width, debug=False):
+                            image_width, debug=False, flags=None):
     f = _registry[int(geomBuffer.view(torch.int64)[0])]
     (means3D, scales, rotations, opacity, cov3D, viewmatrix, projmatrix, campos, W, H, tfx, tfy, smod, degree,
      prefiltered) = f["_view_args"]
@@ -141,7 +141,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def apply_weights(background, means3D, weights, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
                   projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos, prefiltered,
-                  image_weights, cnt, debug):
+                  image_weights, cnt, debug, flags=None):
     w = np.ascontiguousarray(weights.numpy())
     c = np.ascontiguousarray(cnt.numpy().reshape(-1))
     O.apply_weights(means3D, _opt(scales), _opt(rotations), opacity, _opt(cov3D_precomp), viewmatrix, projmatrix, campos,

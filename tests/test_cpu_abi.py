@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_typed():
     # the Python binding types every declared symbol, and nothing that is not declared
     assert sorted(_native.SIGNATURES) == syms
     L = _native.lib()
-    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 1
+    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 2
     assert L.gsr_status_string(0) == b"ok" and b"channels" in L.gsr_status_string(-2)
 
 
@@ -62,11 +62,11 @@ def test_argument_validation_needs_no_gpu():
     r = ctypes.c_int64(7)
     # (P = 0 is a valid empty call everywhere; no pointer is dereferenced)
     assert L.gsr_preprocess(None, 0, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
-                            0, 0, None, None, ctypes.byref(r)) == 0 and r.value == 0
+                            0, 0, 0, None, None, ctypes.byref(r)) == 0 and r.value == 0
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
-                            0, 0, None, None, ctypes.byref(r)) == -1
+                            0, 0, 0, None, None, ctypes.byref(r)) == -1
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
-                            0, 0, None, None, None) == -1
+                            0, 0, 0, None, None, None) == -1
     assert L.gsr_bin(None, 10, -1, 64, 64, None, None, None, None) == -1
     assert L.gsr_bin(None, 10, 1 << 31, 64, 64, None, None, None, ctypes.c_void_p(16)) == -3  # GSR_ERR_TOO_MANY
     assert L.gsr_debug_cov3d(None, 10, None, 1.0, None, None) == -1
@@ -75,12 +75,44 @@ def test_argument_validation_needs_no_gpu():
     assert L.gsr_view_messages_accumulate(None, 10, 3, 16, 0, None, 0, 0, None, None) == -1  # no views
     assert L.gsr_adam_step(None, 0, None, 1, 0.9, 0.999, 1e-15, None, None) in (0, -1)
     assert b"31-bit" in L.gsr_status_string(-3)
-    # process-wide option: only GSR_OPT_TILE_BOUNDS (1) with 0 / 1
-    v = ctypes.c_int(-1)
-    assert L.gsr_get_option(1, ctypes.byref(v)) == 0 and v.value == 0  # the default reproduces the reference's binning
-    assert L.gsr_set_option(1, 2) == -1 and L.gsr_set_option(7, 1) == -1 and L.gsr_get_option(1, None) == -1
-    assert L.gsr_set_option(1, 1) == 0 and L.gsr_get_option(1, ctypes.byref(v)) == 0 and v.value == 1
-    assert L.gsr_set_option(1, 0) == 0
+    # per-call flags (ABI 2): unknown bits are rejected before anything else is looked at; the library has no option state
+    assert not hasattr(L, "gsr_set_option")
+    one = ctypes.c_void_p(16)
+    assert L.gsr_preprocess(None, 10, 3, 16, one, one, 1.0, one, one, one, None, None, one, one, one, 64, 64, 1.0, 1.0,
+                            0, 0, 4, one, one, ctypes.byref(r)) == -1
+    assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 8) == -1
+    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, one, one, one, 4) == -1
+    assert L.gsr_trace_weights(None, 10, 5, 64, 64, 1, one, one, one, one, one, one, 16) == -1
+
+
+def test_options_are_per_render_and_per_thread():
+    """The Python-side default of the flags, its thread-local override, and their validation (no GPU needed)."""
+    import threading
+
+    import gaussianeditor_amd
+    from gaussianeditor_amd import options
+
+    assert options.current_flags() == 0 and gaussianeditor_amd.get_tile_bounds() == "reference"
+    gaussianeditor_amd.set_tile_bounds("alpha")
+    gaussianeditor_amd.set_fast_exp(True)
+    try:
+        assert options.current_flags() == 3 and gaussianeditor_amd.get_fast_exp()
+        seen = {}
+        with options.override(0):
+            assert options.current_flags() == 0
+            t = threading.Thread(target=lambda: seen.setdefault("other", options.current_flags()))
+            t.start()
+            t.join()
+        assert seen["other"] == 3  # the override belonged to this thread only
+        assert options.current_flags() == 3
+        with pytest.raises(ValueError):
+            options.set_default_flags(8)
+        with pytest.raises(ValueError):
+            gaussianeditor_amd.set_tile_bounds("tight")
+    finally:
+        gaussianeditor_amd.set_tile_bounds("reference")
+        gaussianeditor_amd.set_fast_exp(False)
+    assert options.current_flags() == 0
 
 
 def test_no_cpu_fallback():

@@ -97,7 +97,7 @@ def test_debug_snapshot_on_failure(monkeypatch, tmp_path):
     (DGR/diff_gaussian_rasterization/__init__.py:88-107)."""
     import gaussianeditor_amd.diff_gaussian_rasterization as dgr
 
-    def boom(*a):
+    def boom(*a, **kw):
         raise RuntimeError("native failure")
 
     monkeypatch.setattr(dgr._C, "rasterize_gaussians", boom)

@@ -23,7 +23,12 @@ def _free_port():
     return p
 
 
-def _worker_rgb(rank, world, port, out_dir, rows, s0):
+def _segments(bucket):
+    """The bucket's segments in layout order, concatenated WITHOUT the alignment padding between them."""
+    return np.concatenate([v.detach().numpy().reshape(-1) for v in bucket.flat_views().values()])
+
+
+def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
     """The "rgb" exchange: colour gradients all-gathered (dense, or as packed touched rows), SH gradient rebuilt on every rank."""
     import sys
 
@@ -41,7 +46,8 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0):
         case = make_case(P, W, H, seed=5, s0=s0, view=rank, nviews=world)
         sc = case["sc"]
         bucket = GradBucket(P, 16, "cpu")  # "auto" -> "rgb" because two ranks run
-        assert bucket.sh_exchange == "rgb" and bucket.flat.numel() == P * 14
+        assert bucket.sh_exchange == "rgb" and bucket.flat.numel() >= P * 14
+        assert all(v.data_ptr() % 16 == 0 for v in bucket.views.values())  # whatever P is
         G = seed_gradient(H, W, 100 + rank) * H * W
         if rows == "auto":  # the whole step as bench.py runs it: the radii's MAX all-reduce overlaps the backward
             from gaussianeditor_amd.multiview import multiview_step
@@ -66,14 +72,14 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0):
             rows_of = torch.cat([v.reshape(P, -1) for v in bucket.flat_views().values()] + [bucket.rgb], dim=1)
             touched = float((rows_of != 0).any(dim=1).float().mean())
             mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0), rows=rows)
-        np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=bucket.flat.numpy(), sh=bucket.views["sh"].numpy(),
+        np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
                  radii=radii.numpy(), touched=np.array([touched]), rows_route=np.array([mode == "rows"]))
     finally:
         mpatch.undo()
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, P=P):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -109,17 +115,22 @@ def _worker(rank, world, port, out_dir):
         assert 0.0 < touched < 1.0
         # the gradients are views of the flat bucket: no copies between the backward and the collective
         assert grads["sh"].data_ptr() == bucket.views["sh"].data_ptr()
-        assert bucket.flat.numel() == P * (14 + 3 * 16)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=bucket.flat.numpy(), radii=radii.numpy())
+        assert bucket.flat.numel() >= P * (14 + 3 * 16) and (P % 4 or bucket.flat.numel() == P * (14 + 3 * 16))
+        # ... and they hold what autograd returned, for EVERY segment (P % 4 != 0 used to leave all but means3D empty)
+        for name in ("means3D", "sh", "opacities", "scales", "rotations", "means2D"):
+            assert grads[name].data_ptr() == bucket.views[name].data_ptr(), name
+            assert float(bucket.views[name].abs().max()) > 0.0, name
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), flat=_segments(bucket), radii=radii.numpy())
     finally:
         mpatch.undo()
         dist.destroy_process_group()
 
 
-def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
+@pytest.mark.parametrize("P", [1200, 1201, 1203])  # P % 4 != 0: every segment start is padded to 16 bytes
+def test_two_rank_allreduce_matches_single_process(oracle, tmp_path, P):
     world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), P), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     # replicas hold identical reduced buffers
     assert np.array_equal(r0["flat"], r1["flat"]) and np.array_equal(r0["radii"], r1["radii"])
@@ -137,10 +148,11 @@ def test_two_rank_allreduce_matches_single_process(oracle, tmp_path):
     assert np.array_equal(r0["radii"], rad)
 
 
-@pytest.mark.parametrize("rows,s0", [(False, 0.07), (True, 0.07), ("auto", 0.07), ("auto", 0.004)])
-def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path, rows, s0):
+@pytest.mark.parametrize("rows,s0,P", [(False, 0.07, 1200), (True, 0.07, 1200), ("auto", 0.07, 1200), ("auto", 0.004, 1200),
+                                       (False, 0.07, 1201), (True, 0.07, 1201), ("auto", 0.07, 1202)])
+def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path, rows, s0, P):
     world = 2
-    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path), rows, s0), nprocs=world, join=True)
+    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path), rows, s0, P), nprocs=world, join=True)
     r0, r1 = np.load(tmp_path / "rgb_rank0.npz"), np.load(tmp_path / "rgb_rank1.npz")
     # replicas agree bit for bit, including the SH gradient each of them rebuilt on its own
     for k in ("flat", "sh", "radii"):
@@ -191,9 +203,38 @@ def test_bucket_layout_and_allocator():
     assert b.allocator("colors_precomp", (8, 3), True) is None  # not a parameter gradient
     # the two atomically accumulated gradients are adjacent: one fill clears both
     b.flat.fill_(1.0)
-    j = b.allocator("means2D+opacities", (32,), True)
-    assert j.data_ptr() == b.views["means2D"].data_ptr() and j.numel() == 32 and float(j.abs().sum()) == 0.0
-    assert float(b.views["opacities"].abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
-    # unaligned segments (P % 4 != 0) fall back to private tensors instead of misaligned dwordx4 stores
-    b2 = GradBucket(7, 16, "cpu")
-    assert b2.allocator("rotations", (7, 4), False) is None or b2.views["rotations"].data_ptr() % 16 == 0
+    m2, op = b.allocator("means2D+opacities", (32,), True)
+    assert m2.data_ptr() == b.views["means2D"].data_ptr() and op.data_ptr() == b.views["opacities"].data_ptr()
+    assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
+    # P % 4 != 0: every segment still starts on a 16-byte boundary (padding words between the segments), so the
+    # backward's gradients always ARE the bucket's segments -- a bucket that handed out None here lost them silently
+    for P_ in (1, 5, 6, 7, 1201):
+        b2 = GradBucket(P_, 16, "cpu")
+        for name, v in b2.views.items():
+            assert v.data_ptr() % 16 == 0, (P_, name)
+            assert b2.allocator(name, tuple(v.shape), False) is v
+        b2.flat.fill_(1.0)
+        m2, op = b2.allocator("means2D+opacities", (4 * P_,), True)
+        assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0
+        assert float(b2.views["rotations"].sum()) == 4 * P_ and float(b2.views["means3D"].sum()) == 3 * P_
+        b3 = GradBucket(P_, 16, "cpu", sh_exchange="rgb")
+        assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
+
+
+def test_grad_allocator_is_per_thread():
+    """The web UI renders from its own thread while a training thread steps: an allocator
+    installed by one thread must be invisible to the other."""
+    import threading
+
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+
+    seen = {}
+    _C.set_grad_allocator(lambda name, shape, zero: None)
+    try:
+        t = threading.Thread(target=lambda: seen.setdefault("other", _C._allocator()))
+        t.start()
+        t.join()
+        assert seen["other"] is None and _C._allocator() is not None
+    finally:
+        _C.set_grad_allocator(None)
+    assert _C._allocator() is None

@@ -29,7 +29,7 @@ G = seed_gradient(H, W, 0).to(dev)
 z = torch.zeros(P * 11, device=dev)
 d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
 _native.check("bwd", L.gsr_blend_backward(s.cuda_stream, P, R, W, H, p(d(sc["bg"])), p(geom), p(binning), p(img), p(G), p(d_m2),
-                                          p(d_con), p(d_op), p(d_col)))
+                                          p(d_con), p(d_op), p(d_col), 0))
 d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
 d_sh, d_sc, d_rot = torch.empty(P * 48, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
 
