@@ -45,6 +45,38 @@ __device__ __forceinline__ bool setup_wave(const BlendArgs& a, uint32_t tile, ui
   return __any(pw.inside) != 0;
 }
 
+// The pixels of one forward / trace item and the box the cull test uses for it.  `entry` is a work-list entry (WORK_*
+// codes, gsr_common.h), `code` = quad | sub << 2 from run_work_queue.  The item covers its quadrant, or -- when the image is
+// small (SPLIT, image-wide) or the tile is heavy (parts of the entry) -- rows [4 s, 4 s + 4) / the 4x4 block s of it: lanes
+// outside the part are switched off (pw.inside), the box shrinks with it.  Returns false if no pixel is inside the image.
+struct ItemBox {
+  float qx0, qy0, qw, qh;
+};
+template <int SPLIT>
+__device__ __forceinline__ bool setup_item(const BlendArgs& a, uint32_t entry, uint32_t code, PixelWave& pw, ItemBox& b) {
+  uint32_t split = (uint32_t)SPLIT, sub = (code >> 2) & 3u;
+  if (SPLIT == 1) {  // whole quadrants per item: the entry itself may be one of the parts of a heavy tile
+    split = 1u << ((entry >> WORK_SPLIT_SHIFT) & 3u);
+    sub = (entry >> WORK_SUB_SHIFT) & 3u;
+  }
+  if (!setup_wave(a, entry & WORK_TILE_MASK, code & 3u, pw)) return false;
+  const int lane = lane_id();
+  b.qx0 = (float)(pw.px - (lane & 7));
+  b.qy0 = (float)(pw.py - (lane >> 3));
+  b.qw = b.qh = (float)(QUAD - 1);
+  if (split == 2u) {  // rows [4 sub, 4 sub + 4)
+    pw.inside = pw.inside && ((uint32_t)(lane >> 5) == sub);
+    b.qy0 += 4.0f * (float)sub;
+    b.qh = 3.0f;
+  } else if (split == 4u) {  // the 4x4 block (sub & 1, sub >> 1)
+    pw.inside = pw.inside && ((uint32_t)((lane >> 2) & 1) == (sub & 1u)) && ((uint32_t)(lane >> 5) == (sub >> 1));
+    b.qx0 += 4.0f * (float)(sub & 1u);
+    b.qy0 += 4.0f * (float)(sub >> 1);
+    b.qw = b.qh = 3.0f;
+  }
+  return true;
+}
+
 // Persistent work loop.  Queue x (one per XCD) owns entries x, x+8, x+16, ... of work_order;
 // its cursor counts quadrant items (4 per non-empty tile) and then, if `with_empty`, one item
 // per empty tile.  A wave serves the queue of the XCD it happens to run on (HW_REG_XCC_ID, a
@@ -96,7 +128,8 @@ template <int SPLIT, class F>
 __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
   const uint32_t nwork = a.work_meta[0];
   const uint32_t T = (uint32_t)(a.gx * a.gy);
-  const uint32_t nempty = with_empty ? T - nwork : 0u;
+  const uint32_t nempty = with_empty ? a.work_meta[1] : 0u;
+  (void)T;
   // queue x (one per XCD) owns entries x, x+8, ... of work_order: 4 quadrant items per non-empty tile, then one item
   // per empty tile
   // Granularity: a quadrant is one item, unless that leaves fewer than two items per persistent wave (small images,
@@ -270,26 +303,14 @@ template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
                                              uint64_t* prof_cyc) {
   PixelWave pw;
-  // item code: quad | sub << 2 (SPLIT = 1: the whole quadrant)
-  constexpr uint32_t split = (uint32_t)SPLIT;
-  const uint32_t sub = (quad >> 2) & 3u;
+  ItemBox box;
+  if (!setup_item<SPLIT>(a, tile, quad, pw, box)) return;  // (work_est was cleared by tile_worklist_kernel)
+  tile = (uint32_t)pw.tile;
   quad &= 3u;
-  if (!setup_wave(a, tile, quad, pw)) return;  // (work_est was cleared by tile_worklist_kernel)
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
-  float qw = (float)(QUAD - 1), qh = (float)(QUAD - 1);
-  if (split == 2u) {  // rows [4 sub, 4 sub + 4)
-    pw.inside = pw.inside && ((uint32_t)(lane >> 5) == sub);
-    qy0 += 4.0f * (float)sub;
-    qh = 3.0f;
-  } else if (split == 4u) {  // the 4x4 block (sub & 1, sub >> 1)
-    pw.inside = pw.inside && ((uint32_t)((lane >> 2) & 1) == (sub & 1u)) && ((uint32_t)(lane >> 5) == (sub >> 1));
-    qx0 += 4.0f * (float)(sub & 1u);
-    qy0 += 4.0f * (float)(sub >> 1);
-    qw = qh = 3.0f;
-  }
+  const float qx0 = box.qx0, qy0 = box.qy0, qw = box.qw, qh = box.qh;
   bool done = !pw.inside;
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
   uint32_t last_contributor = 0;
@@ -609,6 +630,10 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
       for (int k = 0; k < 9; ++k)
         tot[k] = (ABLATE == 1 || ABLATE == 3) ? (v[k][0] + v[k][1]) + (v[k][2] + v[k][3])  // experiment: no reduction
                                               : wave_sum4_to_rows(v[k][0], v[k][1], v[k][2], v[k][3]);
+      // keep the reductions whole in front of the 4-lane tail: otherwise the last row_shr step is sunk into the masked
+      // region as v_mov 0 + v_mov_dpp + v_add (3 instructions per term instead of one v_add_f32_dpp)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(tot[k]));
       if ((lane & 15) == 15) {
         const uint32_t e = j + (uint32_t)(lane >> 4);
         const float4 co = s0[w][e];  // (-0.5 conic.x, -conic.y, -0.5 conic.z, opacity) of entry e
@@ -658,8 +683,9 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   }
 }
 
+// (held at the 4 waves per SIMD the persistent grid is sized for: #CUs x 4 workgroups must all be resident)
 template <int ABLATE, bool FAST>
-__global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const BlendArgs a) {
+__global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[WAVE];
   __shared__ float sacc[9][WAVE];
@@ -677,6 +703,10 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
   uint32_t ntiles = 0, west = 0;
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
+    if (a.fwd_list) {  // the forward's work list (GSR_BWD_WORKLIST=0): WORK_* codes; a heavy tile appears once per part
+      if ((tile >> WORK_SUB_SHIFT) & 3u) return;
+      tile &= WORK_TILE_MASK;
+    }
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
     backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
     if (prof) {
@@ -700,7 +730,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
   const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   {
     const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
-    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);
+    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);  // (its own list: BWD_ITEM_* codes)
   }
   for (;;) {
     __syncthreads();
@@ -733,27 +763,13 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) blend_backward_kernel(const B
 template <int C, int SPLIT, bool FAST>
 __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
-  // item code as in forward_item: quad | sub << 2 (SPLIT = 1: the whole quadrant)
-  constexpr uint32_t split = (uint32_t)SPLIT;
-  const uint32_t sub = (quad >> 2) & 3u;
-  quad &= 3u;
-  if (!setup_wave(a, tile, quad, pw)) return;
+  ItemBox box;
+  if (!setup_item<SPLIT>(a, tile, quad, pw, box)) return;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));
-  float qw = (float)(QUAD - 1), qh = (float)(QUAD - 1);
-  if (split == 2u) {
-    pw.inside = pw.inside && ((uint32_t)(lane >> 5) == sub);
-    qy0 += 4.0f * (float)sub;
-    qh = 3.0f;
-  } else if (split == 4u) {
-    pw.inside = pw.inside && ((uint32_t)((lane >> 2) & 1) == (sub & 1u)) && ((uint32_t)(lane >> 5) == (sub >> 1));
-    qx0 += 4.0f * (float)(sub & 1u);
-    qy0 += 4.0f * (float)(sub >> 1);
-    qw = qh = 3.0f;
-  }
+  const float qx0 = box.qx0, qy0 = box.qy0, qw = box.qw, qh = box.qh;
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   float Cw[C];
 #pragma unroll
@@ -977,6 +993,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     a.work_meta = a.bwd_meta;
   } else {
     a.units = 0;  // the list-length order is too poor a predictor for assigned first tiles (measured: +4 %)
+    a.fwd_list = 1;
   }
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();

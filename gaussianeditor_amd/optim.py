@@ -50,12 +50,24 @@ class FusedMaskedAdam(torch.optim.Optimizer):
         if row_weight is not None:
             self._row_weight = row_weight.detach().float().contiguous()
 
+    def clear_anchors(self) -> None:
+        """Forget every anchor and the row weights (call after a densification / prune replaced the parameters)."""
+        self._anchors.clear()
+        self._row_weight = None
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        # anchors are keyed by parameter identity: one whose tensor left the optimizer (densify / prune replace the
+        # parameters) would silently stop acting -- refuse instead
+        live = {id(p) for group in self.param_groups for p in group["params"]}
+        stale = [a for a in self._anchors if id(a) not in live]
+        if stale:
+            raise RuntimeError(f"FusedMaskedAdam: {len(stale)} anchor(s) refer to tensors that are no longer parameters of "
+                               "this optimizer; call clear_anchors() / set_anchor() again after densify or prune")
         # tensors that share (betas, eps, step) go into one launch (normally: everything)
         batches: Dict[tuple, list] = {}
         for group in self.param_groups:
@@ -94,6 +106,11 @@ class FusedMaskedAdam(torch.optim.Optimizer):
                         raise RuntimeError("FusedMaskedAdam: the row mask must have one entry per Gaussian")
                     if anchor is not None and anchor[0].shape != p.shape:
                         raise RuntimeError("FusedMaskedAdam: anchor and parameter shapes differ")
+                    # the kernel indexes row_weight[row] for every row of an anchored tensor: a weight vector of another
+                    # length (left over from before a densification / prune) would be read out of bounds
+                    if anchor is not None and self._row_weight is not None and self._row_weight.numel() != rows:
+                        raise RuntimeError(f"FusedMaskedAdam: row_weight has {self._row_weight.numel()} entries, the anchored "
+                                           f"parameter {rows} rows (clear_anchors() after densify / prune)")
                     keep.append(g)
                     arr[i] = _native.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
                                                 anchor[0].data_ptr() if anchor is not None else None, p.numel(),

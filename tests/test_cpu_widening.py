@@ -235,3 +235,25 @@ def test_oracle_compact_rows_is_boolean_indexing(oracle):
     out = oracle.compact_rows([t.numpy() for t in ts], keep.numpy())
     for o, t in zip(out, ts):
         assert np.array_equal(o, t[keep].numpy())
+
+
+def test_fused_adam_rejects_stale_anchor_state():
+    """after densify / prune the parameters are new tensors; anchors keyed by the old ones and a row_weight
+    of the old length must raise instead of being ignored / read out of bounds (checked before any native call)."""
+    import torch
+
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    p = torch.nn.Parameter(torch.zeros(8, 3))
+    opt = FusedMaskedAdam([{"params": [p], "name": "xyz"}], lr=1e-3)
+    opt.set_anchor(p, torch.zeros(8, 3), 1.0, row_weight=torch.ones(8))
+    q = torch.nn.Parameter(torch.zeros(10, 3))  # what densification_postfix leaves in the group
+    opt.param_groups[0]["params"][0] = q
+    q.grad = torch.zeros_like(q)
+    with pytest.raises(RuntimeError, match="no longer parameters"):
+        opt.step()
+    opt.clear_anchors()
+    assert opt._row_weight is None and not opt._anchors
+    opt.set_anchor(q, torch.zeros(10, 3), 1.0, row_weight=torch.ones(8))  # a weight vector of the old length
+    with pytest.raises(RuntimeError):  # CPU tensors: "no CPU fallback" is raised first on this machine; on the GPU the length check
+        opt.step()
