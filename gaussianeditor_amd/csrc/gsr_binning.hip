@@ -18,8 +18,6 @@
 // look-back, so no inter-workgroup hand-off inside a launch (per-XCD L2s are not coherent; a kernel
 // boundary is the cheapest correct fence).  Stability comes from ranking with wave64 ballots in key
 // order, never from atomics.
-#include <stdlib.h>
-
 #include "gsr_kernels.h"
 
 namespace gsr {
@@ -395,14 +393,10 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint3
 // ----------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
-                                                            uint32_t* __restrict__ queues, uint32_t* __restrict__ est,
-                                                            uint32_t heavy) {  // heavy: 0, or the list length (in 64-entry chunks) from which a tile is cut
+                                                            uint32_t* __restrict__ queues, uint32_t* __restrict__ est) {
   // Counting sort of the tiles by bucket.  Most tiles of an image fall into a handful of buckets, and LDS atomics on one
   // address serialise, so every bucket has WORK_SUB counters (chosen by the thread's lane): the order inside a bucket is
   // free anyway, and the sort's time stops growing with the number of tiles per bucket.
-  // A tile whose list is `heavy` chunks or longer is entered 2 (from 2 `heavy`: 4) times, once per part (WORK_* codes,
-  // gsr_common.h): the forward ends with its longest quadrant item, and the parts of a heavy tile are independent items
-  // with shorter evaluated lists (finer culling).
   constexpr int WORK_SUB = 16, NCNT = (WORK_BUCKETS + 1) * WORK_SUB;
   __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];
@@ -422,13 +416,9 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
     const uint32_t c = (len + 63u) / 64u;
     return (uint32_t)(WORK_BUCKETS - 1) - min(c - 1u, (uint32_t)(WORK_BUCKETS - 1));
   };
-  auto parts_log2 = [heavy](uint32_t len) -> uint32_t {
-    const uint32_t c = (len + 63u) / 64u;
-    return (heavy == 0u || c < heavy) ? 0u : (c < 2u * heavy ? 1u : 2u);
-  };
   for (int t = threadIdx.x; t < T; t += 1024) {
     const uint2 r = ranges[t];
-    atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u << parts_log2(r.y - r.x));
+    atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
   }
   __syncthreads();
   {  // exclusive scan over the NCNT counters in (bucket, sub) order: counts -> cursors
@@ -439,28 +429,16 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
       uint32_t chunk;
       const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
       if (i < NCNT) cnt[i] = carry + ex;
-      if (i == WORK_BUCKETS * WORK_SUB) meta[0] = carry + ex;  // number of entries with instances
+      if (i == WORK_BUCKETS * WORK_SUB) meta[0] = carry + ex;  // number of non-empty tiles
       carry += chunk;
     }
-    if (threadIdx.x == 0) meta[1] = carry - meta[0];  // number of empty tiles (one entry each, after the others)
   }
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 1024) {
     const uint2 r = ranges[t];
-    const uint32_t pl = parts_log2(r.y - r.x), n = 1u << pl;
-    const uint32_t pos = atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], n);
-    for (uint32_t s = 0; s < n; ++s) order[pos + s] = (uint32_t)t | (s << WORK_SUB_SHIFT) | (pl << WORK_SPLIT_SHIFT);
+    const uint32_t pos = atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
+    order[pos] = (uint32_t)t;
   }
-}
-
-// List length (in 64-entry chunks) from which the forward's work list cuts a tile into parts; 0 = never.  Only for images
-// whose quadrants are whole items (the small-image split of run_work_queue is a different, image-wide mechanism) and
-// whose tile ids fit the entry code.  GSR_FWD_HEAVY overrides the default (tuning knob; read once).
-static uint32_t heavy_tile_chunks(int gx, int gy) {
-  static const int env = [] { const char* e = getenv("GSR_FWD_HEAVY"); return e ? atoi(e) : 0; }();
-  const unsigned quads = 4u * (unsigned)(gx * gy);
-  if (env <= 0 || quads < 2u * blend_grid_size() || (unsigned)(gx * gy) > WORK_TILE_MASK) return 0u;
-  return (uint32_t)env;
 }
 
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
@@ -470,7 +448,7 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                       im.queue_heads, im.work_est, 0u);
+                       im.queue_heads, im.work_est);
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
@@ -480,7 +458,7 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
   const int64_t nbr = (R + 255) / 256;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.tkey[b.final_buf], im.ranges);
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                     im.queue_heads, im.work_est, heavy_tile_chunks(gx, gy));
+                     im.queue_heads, im.work_est);
   return hipGetLastError();
 }
 

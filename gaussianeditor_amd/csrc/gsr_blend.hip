@@ -45,21 +45,18 @@ __device__ __forceinline__ bool setup_wave(const BlendArgs& a, uint32_t tile, ui
   return __any(pw.inside) != 0;
 }
 
-// The pixels of one forward / trace item and the box the cull test uses for it.  `entry` is a work-list entry (WORK_*
-// codes, gsr_common.h), `code` = quad | sub << 2 from run_work_queue.  The item covers its quadrant, or -- when the image is
-// small (SPLIT, image-wide) or the tile is heavy (parts of the entry) -- rows [4 s, 4 s + 4) / the 4x4 block s of it: lanes
-// outside the part are switched off (pw.inside), the box shrinks with it.  Returns false if no pixel is inside the image.
+// The pixels of one forward / trace item and the box the cull test uses for it.  `code` = quad | sub << 2 from
+// run_work_queue.  The item covers its quadrant, or -- when the image is small (SPLIT, image-wide) -- rows [4 s, 4 s + 4) /
+// the 4x4 block s of it: lanes outside the part are switched off (pw.inside), the box shrinks with it.  Returns false if
+// no pixel is inside the image.
 struct ItemBox {
   float qx0, qy0, qw, qh;
 };
 template <int SPLIT>
-__device__ __forceinline__ bool setup_item(const BlendArgs& a, uint32_t entry, uint32_t code, PixelWave& pw, ItemBox& b) {
-  uint32_t split = (uint32_t)SPLIT, sub = (code >> 2) & 3u;
-  if (SPLIT == 1) {  // whole quadrants per item: the entry itself may be one of the parts of a heavy tile
-    split = 1u << ((entry >> WORK_SPLIT_SHIFT) & 3u);
-    sub = (entry >> WORK_SUB_SHIFT) & 3u;
-  }
-  if (!setup_wave(a, entry & WORK_TILE_MASK, code & 3u, pw)) return false;
+__device__ __forceinline__ bool setup_item(const BlendArgs& a, uint32_t tile, uint32_t code, PixelWave& pw, ItemBox& b) {
+  constexpr uint32_t split = (uint32_t)SPLIT;
+  const uint32_t sub = (code >> 2) & 3u;
+  if (!setup_wave(a, tile, code & 3u, pw)) return false;
   const int lane = lane_id();
   b.qx0 = (float)(pw.px - (lane & 7));
   b.qy0 = (float)(pw.py - (lane >> 3));
@@ -128,8 +125,7 @@ template <int SPLIT, class F>
 __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_empty, F&& item) {
   const uint32_t nwork = a.work_meta[0];
   const uint32_t T = (uint32_t)(a.gx * a.gy);
-  const uint32_t nempty = with_empty ? a.work_meta[1] : 0u;
-  (void)T;
+  const uint32_t nempty = with_empty ? T - nwork : 0u;
   // queue x (one per XCD) owns entries x, x+8, ... of work_order: 4 quadrant items per non-empty tile, then one item
   // per empty tile
   // Granularity: a quadrant is one item, unless that leaves fewer than two items per persistent wave (small images,
@@ -305,7 +301,6 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   PixelWave pw;
   ItemBox box;
   if (!setup_item<SPLIT>(a, tile, quad, pw, box)) return;  // (work_est was cleared by tile_worklist_kernel)
-  tile = (uint32_t)pw.tile;
   quad &= 3u;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
@@ -703,10 +698,6 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   uint32_t ntiles = 0, west = 0;
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
-    if (a.fwd_list) {  // the forward's work list (GSR_BWD_WORKLIST=0): WORK_* codes; a heavy tile appears once per part
-      if ((tile >> WORK_SUB_SHIFT) & 3u) return;
-      tile &= WORK_TILE_MASK;
-    }
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
     backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
     if (prof) {
@@ -730,7 +721,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   {
     const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
-    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);  // (its own list: BWD_ITEM_* codes)
+    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);
   }
   for (;;) {
     __syncthreads();
@@ -993,7 +984,6 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     a.work_meta = a.bwd_meta;
   } else {
     a.units = 0;  // the list-length order is too poor a predictor for assigned first tiles (measured: +4 %)
-    a.fwd_list = 1;
   }
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();

@@ -86,19 +86,12 @@ constexpr int QUEUE_STRIDE = 32;      // u32 words between queue heads (128 B: o
 constexpr int QUEUE_KINDS = 3;        // forward, backward, trace
 constexpr int QUEUE_GROUPS = 128;     // retire counters: one per 64 workgroups of a launch (grids of up to 8192)
 constexpr int QUEUE_LINES = 8 + 1 + QUEUE_GROUPS;  // per kind: 8 per-XCD heads, the top retire counter, the group counters
-// Work-list entry of the forward / trace kernels: tile id | part << WORK_SUB_SHIFT | log2(parts) << WORK_SPLIT_SHIFT.
-// An entry stands for four items (one per quadrant); with 2 (4) parts, part s covers rows [4 s, 4 s + 4) of every
-// quadrant (its 4x4 block s).  Every (pixel) of the tile belongs to exactly one entry.
-constexpr uint32_t WORK_TILE_MASK = 0x00ffffffu;
-constexpr int WORK_SUB_SHIFT = 24;
-constexpr int WORK_SPLIT_SHIFT = 28;
 struct Image {
   uint2* ranges;        // (T)  [begin,end) into point_list
   float* final_T;       // (N)
   uint32_t* n_contrib;  // (N)
-  uint32_t* work_order; // (4T) work-list entries (a tile, or one of the 2 / 4 parts of a heavy tile: WORK_* codes below):
-                        //      tiles with instances, longest list first (bucketed), then the empty tiles
-  uint32_t* work_meta;  // [0] = number of entries with instances, [1] = number of empty tiles
+  uint32_t* work_order; // (T)  tile ids: non-empty tiles, longest list first (bucketed), then the empty tiles
+  uint32_t* work_meta;  // [0] = number of non-empty tiles
   uint32_t* work_est;   // (T,4) entries the forward blend evaluated per (tile, quadrant): the backward's work estimate
   uint32_t* bwd_order;  // (2T) items of the backward blend (a tile, or half of a heavy tile): most forward work first,
                         //      tiles without any work dropped
@@ -115,7 +108,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.ranges = (uint2*)(p + off);        off += align_up(sizeof(uint2) * T);
   im.final_T = (float*)(p + off);       off += align_up(sizeof(float) * N);
   im.n_contrib = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * N);
-  im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * 4 * T);
+  im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * T);
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 4 * T);
   im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * 2 * T);

@@ -56,8 +56,8 @@ struct PreBwdArgs {
 // K6 / K7 / K12 arguments (gsr_blend.hip)
 struct BlendArgs {
   int W, H, gx, gy;
-  const uint32_t* work_order;  // work-list entries (WORK_* codes, gsr_common.h), longest first, empty tiles last
-  const uint32_t* work_meta;   // [0] = number of entries with instances, [1] = number of empty tiles
+  const uint32_t* work_order;  // tile ids, longest first, empty tiles last
+  const uint32_t* work_meta;   // [0] = number of non-empty tiles
   uint32_t* work_est;          // forward: out, (T,4) evaluated entries per quadrant; null = not recorded
   uint32_t* bwd_order;         // backward launch: scratch for its own work list (gsr_blend.hip: backward_worklist_kernel)
   uint32_t* bwd_meta;
@@ -87,7 +87,6 @@ struct BlendArgs {
   float* weights;
   int32_t* cnt;
   int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)
-  int fwd_list;    // backward launched on the forward's work list (entries carry WORK_* codes)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block

@@ -9,7 +9,6 @@ fails if the HIP library is not built.
 from __future__ import annotations
 
 import ctypes
-import threading
 from typing import Optional
 
 import torch
@@ -20,20 +19,20 @@ _native.lib()  # fail loudly at import time if the extension is missing
 
 NUM_CHANNELS = 3  # config.h:15
 
-#: optional allocator for the backward's gradient outputs: fn(name, shape, zero) -> tensor | None.
-#: Used by gaussianeditor_amd.multiview to make the gradients views of one flat all-reduce bucket.  PER THREAD: the
-#: web UI's render thread and a training thread must not see each other's allocator, and
-#: autograd runs a backward on the thread that called it when invoked through torch.autograd.grad / .backward().
-_tls = threading.local()
+#: Allocator for the backward's gradient outputs: fn(name, shape, zero) -> tensor | None, handed to
+#: rasterize_gaussians_backward PER CALL (`grad_allocator=`).  gaussianeditor_amd.multiview uses it to make the gradients
+#: views of one flat all-reduce bucket.  It travels on the autograd node of the render it belongs to
+#: (`attach_grad_allocator`), not in module or thread state: the engine runs the backward of CUDA tensors on its own
+#: device thread, and the web UI renders from a second Python thread while a training thread steps.
 
 
-def set_grad_allocator(fn) -> None:
-    """Install (or with None remove) the gradient allocator of the CALLING thread."""
-    _tls.grad_allocator = fn
-
-
-def _allocator():
-    return getattr(_tls, "grad_allocator", None)
+def attach_grad_allocator(output: torch.Tensor, fn) -> None:
+    """Make the backward of the render that produced `output` (the colour image of GaussianRasterizer / render())
+    allocate its gradients through `fn` (None removes it)."""
+    node = output.grad_fn
+    if node is None or not hasattr(node, "raster_settings"):
+        raise RuntimeError("attach_grad_allocator: the tensor is not the output of a GaussianRasterizer render")
+    node.gsr_grad_allocator = fn
 
 
 def _flags(flags) -> int:
@@ -156,8 +155,7 @@ def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binnin
     return out
 
 
-def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
-    fn = _allocator()
+def _alloc(fn, name: str, shape, zero: bool, dev) -> torch.Tensor:
     if fn is not None:
         t = fn(name, tuple(shape), zero)
         if t is not None:
@@ -167,10 +165,11 @@ def _alloc(name: str, shape, zero: bool, dev) -> torch.Tensor:
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None, grad_allocator=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:97-157 ->
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
-    `flags` (extension, keyword): the flags the forward of this view ran with; None = options.current_flags()."""
+    `flags` (extension, keyword): the flags the forward of this view ran with; None = options.current_flags().
+    `grad_allocator` (extension, keyword): fn(name, shape, zero) -> tensor | None for the gradient outputs."""
     flags = _flags(flags)
     dev = means3D.device
     P = int(means3D.size(0))
@@ -191,31 +190,31 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     has_scales = scales.numel() != 0
     # accumulated with atomics -> zero-filled (with as few fill launches as possible: one block, or two when a
     # gradient allocator owns means2D + opacities); the rest is fully written by the kernels
-    grad_alloc = _allocator()
+    grad_alloc = grad_allocator
     # "means2D+opacities": an allocator may hand back BOTH accumulators, already zeroed by ONE fill of the span that
     # holds them, as a pair (dL_dmeans2D (P,3), dL_dopacity (P,1))
-    joint = grad_alloc("means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
+    joint = grad_alloc(grad_alloc, "means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
     if joint is not None:
         dL_dmeans2D, dL_dopacity = joint
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
     elif grad_alloc is not None:
-        dL_dmeans2D = _alloc("means2D", (P, 3), True, dev)
-        dL_dopacity = _alloc("opacities", (P, 1), True, dev)
+        dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), True, dev)
+        dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), True, dev)
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
     else:
         acc = torch.zeros((11 * P,), dtype=torch.float32, device=dev)  # conic first: its rows are dwordx4-accessed
         dL_dconic, dL_dmeans2D = acc[:4 * P].view(P, 4), acc[4 * P:7 * P].view(P, 3)
         dL_dcolors, dL_dopacity = acc[7 * P:10 * P].view(P, NUM_CHANNELS), acc[10 * P:].view(P, 1)
-    dL_dmeans3D = _alloc("means3D", (P, 3), False, dev)
-    dL_dcov3D = _alloc("cov3Ds_precomp", (P, 6), False, dev)
+    dL_dmeans3D = _alloc(grad_alloc, "means3D", (P, 3), False, dev)
+    dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev)
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
     # colour gradient INSTEAD of the (P,M,3) SH gradient; dL_dsh is then returned as None and rebuilt after the exchange
-    dL_drgb = grad_alloc("sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
-    dL_dsh = None if dL_drgb is not None else _alloc("sh", (P, M, 3), M == 0, dev)
-    dL_dscales = _alloc("scales", (P, 3), not has_scales, dev)
-    dL_drotations = _alloc("rotations", (P, 4), not has_scales, dev)
+    dL_drgb = grad_alloc(grad_alloc, "sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
+    dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
+    dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
+    dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)
     L = _native.lib()
     with torch.cuda.device(dev):
         if dL_drgb is None:

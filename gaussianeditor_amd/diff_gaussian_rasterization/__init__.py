@@ -107,7 +107,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                 geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.debug)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = _call_native(
-             lambda *a: _C.rasterize_gaussians_backward(*a, flags=ctx.gsr_flags), args, rs.debug, "snapshot_bw.dump",
+             lambda *a: _C.rasterize_gaussians_backward(*a, flags=ctx.gsr_flags,
+                                                        grad_allocator=getattr(ctx, "gsr_grad_allocator", None)),
+             args, rs.debug, "snapshot_bw.dump",
              "\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
         # one slot per forward() input (:213-225)
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,

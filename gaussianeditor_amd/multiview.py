@@ -9,7 +9,7 @@ single flat fp32 bucket, and the per-Gaussian screen radii are combined with one
 all-reduce (the reference takes `torch.max` over the views, GassuianEditor.py:175-178).
 
 The bucket is filled without copies: the backward's gradient tensors are *allocated as views
-into the bucket* (see `_C.set_grad_allocator`), so the kernels write straight into the
+into the bucket* (see `_C.attach_grad_allocator`), so the kernels write straight into the
 buffer RCCL reduces.
 
 The SH gradient is 3M of the bucket's 14+3M floats per Gaussian (77 % at M = 16), but per view it is rank one:
@@ -32,7 +32,6 @@ take the dense route (the decision is made from the gathered counts, so it is th
 """
 from __future__ import annotations
 
-import contextlib
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -104,14 +103,10 @@ class GradBucket:
             v.zero_()
         return v
 
-    @contextlib.contextmanager
-    def capture(self):
-        """While active, the rasterizer backward writes its gradients into this bucket."""
-        _C.set_grad_allocator(self.allocator)
-        try:
-            yield self
-        finally:
-            _C.set_grad_allocator(None)
+    def attach(self, color: torch.Tensor) -> None:
+        """The backward of the render that produced `color` writes its gradients into this bucket.  (The allocator
+        rides on that render's autograd node: no module or thread state, whichever thread runs the backward.)"""
+        _C.attach_grad_allocator(color, self.allocator)
 
     def grads(self) -> Dict[str, torch.Tensor]:
         return dict(self.views)
@@ -135,22 +130,21 @@ def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacitie
     color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
     if after_forward is not None:
         after_forward(radii)
-    ctx = bucket.capture() if bucket is not None else contextlib.nullcontext()
-    with ctx:
-        # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by allreduce_view_grads)
-        g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
+    if bucket is not None:
+        bucket.attach(color)
+    # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by allreduce_view_grads)
+    g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
     grads = dict(zip(names, g))
     if bucket is not None:
-        # Every gradient must now BE its bucket segment.  If the backward had to hand out a private tensor for one
-        # (it never should: all segments are 16-byte aligned), copy it in rather than exchange stale bucket contents.
+        # Every gradient must now BE its bucket segment (all segments are 16-byte aligned, so the backward can always
+        # write there).  Exchanging a bucket the backward did not fill would silently reduce stale data: refuse.
         for name, t in grads.items():
             v = bucket.views.get(name)
             if t is None or v is None or (name == "sh" and bucket.sh_exchange == "rgb"):
                 continue
             if t.data_ptr() != v.data_ptr():
-                v.copy_(t.reshape(v.shape))
-            grads[name] = v
+                raise RuntimeError(f"render_view_grads: the gradient of `{name}` was not written into the bucket")
     if bucket is not None and bucket.sh_exchange == "rgb":
         bucket.sh_degree = int(settings.sh_degree)
         bucket.means3D_ref = m3.detach()

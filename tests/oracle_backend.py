@@ -42,7 +42,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
-                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None):
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None, grad_allocator=None):
     f = _registry[int(geomBuffer.view(torch.int64)[0])]
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     g = O.backward(f, dL_dout_color, means3D, _opt(scales), _opt(rotations), _opt(sh), _opt(colors), _opt(cov3D_precomp),
@@ -54,15 +54,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                              ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
                              ("cov3Ds_precomp", "dL_dcov3D", (P, 6)), ("sh", "dL_dsh", (P, M, 3)),
                              ("scales", "dL_dscales", (P, 3)), ("rotations", "dL_drotations", (P, 4))):
-        if name == "sh" and M != 0 and real_C._allocator() is not None:
-            rgb = real_C._allocator()("sh_rgb", (P, 3), False)
+        if name == "sh" and M != 0 and grad_allocator is not None:
+            rgb = grad_allocator("sh_rgb", (P, 3), False)
             if rgb is not None:  # "rgb" exchange mode: the clamp-masked colour gradient instead of dL_dsh
                 vis = (f["radii"] > 0)[:, None]
                 masked = np.where(np.logical_and(vis, f["clamped"] == 0), g["dL_dcolors"].reshape(P, 3), 0.0)
                 rgb.copy_(torch.from_numpy(np.ascontiguousarray(masked, dtype=np.float32)))
                 out.append(None)
                 continue
-        t = real_C._alloc(name, shape, False, means3D.device)  # honours the gradient-bucket allocator
+        t = real_C._alloc(grad_allocator, name, shape, False, means3D.device)  # honours the gradient-bucket allocator
         t.copy_(torch.from_numpy(np.ascontiguousarray(g[key])).reshape(shape))
         out.append(t)
     return tuple(out)

@@ -221,20 +221,35 @@ def test_bucket_layout_and_allocator():
         assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
 
 
-def test_grad_allocator_is_per_thread():
-    """The web UI renders from its own thread while a training thread steps: an allocator
-    installed by one thread must be invisible to the other."""
+def test_grad_allocator_rides_on_the_autograd_node(oracle, monkeypatch):
+    """The allocator belongs to ONE render (it is an attribute of that render's autograd node): the backward finds it
+    whichever thread runs it -- autograd runs CUDA backwards on its own device thread, and the web UI renders from a
+    second Python thread while a training thread steps -- and no other render sees it."""
     import threading
 
-    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+    import oracle_backend
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer, _C
 
-    seen = {}
-    _C.set_grad_allocator(lambda name, shape, zero: None)
-    try:
-        t = threading.Thread(target=lambda: seen.setdefault("other", _C._allocator()))
-        t.start()
-        t.join()
-        assert seen["other"] is None and _C._allocator() is not None
-    finally:
-        _C.set_grad_allocator(None)
-    assert _C._allocator() is None
+    oracle_backend.install(monkeypatch)
+    case = make_case(300, 48, 32, seed=2, s0=0.08)
+    sc = case["sc"]
+    calls = {"a": [], "b": []}
+
+    def render():
+        leaves = [sc[k].clone().requires_grad_(True) for k in ("xyz", "opacity", "features", "scaling", "rotation")]
+        x, o, f, s_, r = leaves
+        c, _, _ = GaussianRasterizer(settings(case, "cpu"))(x, torch.zeros_like(x, requires_grad=True), o, shs=f, scales=s_,
+                                                            rotations=r)
+        return c, leaves
+
+    ca, la = render()
+    cb, lb = render()
+    _C.attach_grad_allocator(ca, lambda name, shape, zero: calls["a"].append(name))
+    # the backward of render a on ANOTHER thread still finds a's allocator; render b (same thread as the attach) has none
+    t = threading.Thread(target=lambda: ca.sum().backward())
+    t.start()
+    t.join()
+    cb.sum().backward()
+    assert "means3D" in calls["a"] and "sh" in calls["a"] and calls["b"] == []
+    with pytest.raises(RuntimeError, match="not the output"):
+        _C.attach_grad_allocator(torch.zeros(3, requires_grad=True) * 2, None)
