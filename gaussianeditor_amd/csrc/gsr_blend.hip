@@ -161,6 +161,9 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
   if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
 
+#ifndef GSR_FWD_CHAIN
+#define GSR_FWD_CHAIN 0
+#endif
 constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 
 // Sums each of four per-lane values over the 64 lanes of the wave, 10 instructions for all four
@@ -371,6 +374,33 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
         // region that consumes it and the independent exp chains no longer overlap (forward blend -2 %)
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(al[u]));
+#if GSR_FWD_CHAIN == 1
+        // EXPERIMENT: the transmittance of the group as a prefix product (a skipped entry multiplies by exactly 1, so
+        // every value is the reference's), everything else selects: no exec-mask regions, no VALU -> SALU -> VALU turns
+        // inside the serial part; the only dependent chain is four multiplies.
+        float t[GROUP + 1];
+        t[0] = T;
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) t[u + 1] = t[u] * (ok[u] ? (1.0f - al[u]) : 1.0f);
+        bool alive = !done;
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+          const bool hit = alive && ok[u];
+          const bool term = hit && (t[u + 1] < 0.0001f);
+          const bool blended = hit && !term;
+          alive = alive && !term;
+          const float w = al[u] * t[u];
+          const float n0 = __builtin_fmaf(cc[u].x, w, C0), n1 = __builtin_fmaf(cc[u].y, w, C1);
+          const float n2 = __builtin_fmaf(cc[u].z, w, C2), nd = __builtin_fmaf(gg[u].z, w, D);
+          C0 = blended ? n0 : C0;
+          C1 = blended ? n1 : C1;
+          C2 = blended ? n2 : C2;
+          D = blended ? nd : D;
+          T = blended ? t[u + 1] : T;
+          last_contributor = blended ? __float_as_uint(gg[u].w) : last_contributor;
+        }
+        done = !alive;
+#else
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) {
           const bool hit = ok[u] && !done;
@@ -387,6 +417,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
             last_contributor = __float_as_uint(gg[u].w);
           }
         }
+#endif
       }
       if (PROFILE) prof_cyc[1] += __builtin_amdgcn_s_memtime() - tc1;  // group loop
     }
@@ -906,20 +937,24 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
 }
 
-// Number of persistent single-wave workgroups: (SIMDs on the device) x (waves per SIMD).
-// GSR_BLEND_WAVES_PER_SIMD overrides the default (tuning knob; read once).
-unsigned blend_grid_size() {
-  static const unsigned n = [] {
-    int cus = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (cus <= 0) cus = 256;
-    int per_simd = 4;
-    if (const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD")) per_simd = atoi(e);
-    if (per_simd < 1) per_simd = 1;
-    if (per_simd > 8) per_simd = 8;
-    return (unsigned)cus * 4u * (unsigned)per_simd;
-  }();
-  return n;
+// Number of persistent waves of a launch: (SIMDs on the device) x (waves per SIMD), 4 by default.
+// GSR_BLEND_WAVES_PER_SIMD overrides the default for all blend kernels, GSR_FWD_WAVES_PER_SIMD for the forward / trace
+// kernels only (the backward is built for exactly 4: amdgpu_waves_per_eu) -- tuning knobs, read once.
+static unsigned grid_for(const char* specific) {
+  int cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  if (cus <= 0) cus = 256;
+  int per_simd = 4;
+  if (const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD")) per_simd = atoi(e);
+  if (specific != nullptr)
+    if (const char* e = getenv(specific)) per_simd = atoi(e);
+  if (per_simd < 1) per_simd = 1;
+  if (per_simd > 8) per_simd = 8;
+  return (unsigned)cus * 4u * (unsigned)per_simd;
+}
+unsigned blend_grid_size(bool backward) {
+  static const unsigned fwd = grid_for("GSR_FWD_WAVES_PER_SIMD"), bwd = grid_for(nullptr);
+  return backward ? bwd : fwd;
 }
 // Placement units of a launch with `waves_per_wg`-wave workgroups (see first_item_of_block): SIMDs or CUs; 0 turns the
 // assigned first items off (GSR_BLEND_FOLD=0, or a CU count the fold does not divide).
@@ -931,7 +966,7 @@ static unsigned blend_units(unsigned waves_per_wg) {
     return (unsigned)(c > 0 ? c : 256);
   }();
   const unsigned units = waves_per_wg == 1 ? cus * 4u : cus;
-  const unsigned grid = blend_grid_size() / waves_per_wg;
+  const unsigned grid = blend_grid_size(waves_per_wg != 1) / waves_per_wg;
   if (!fold || units % 8u != 0u || grid % units != 0u) return 0u;
   return units;
 }
@@ -971,7 +1006,7 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size() / BWD_WAVES);
+  hipError_t e = prepare_queue(s, a, blend_grid_size(true) / BWD_WAVES);
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(BWD_WAVES);
   // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
@@ -979,7 +1014,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   if (own_list && a.work_est != nullptr) {
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
     hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta,
-                       blend_grid_size() / BWD_WAVES, halves);
+                       blend_grid_size(true) / BWD_WAVES, halves);
     a.work_order = a.bwd_order;
     a.work_meta = a.bwd_meta;
   } else {
@@ -988,7 +1023,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
-  const dim3 g(blend_grid_size() / BWD_WAVES), b(WAVE * BWD_WAVES);
+  const dim3 g(blend_grid_size(true) / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false>), g, b, 0, s, a); break;

@@ -356,7 +356,7 @@ int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int 
                                      float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
                                      int64_t max_records, int64_t* n_records_host) {
   if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
-  const int64_t n = (int64_t)blend_grid_size() / 4;
+  const int64_t n = (int64_t)blend_grid_size(true) / 4;
   *n_records_host = n;
   if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
   if (P < 0 || R <= 0 || W <= 0 || H <= 0 || !bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;

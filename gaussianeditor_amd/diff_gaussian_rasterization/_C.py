@@ -193,7 +193,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     grad_alloc = grad_allocator
     # "means2D+opacities": an allocator may hand back BOTH accumulators, already zeroed by ONE fill of the span that
     # holds them, as a pair (dL_dmeans2D (P,3), dL_dopacity (P,1))
-    joint = grad_alloc(grad_alloc, "means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
+    joint = grad_alloc("means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
     if joint is not None:
         dL_dmeans2D, dL_dopacity = joint
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
@@ -211,7 +211,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev)
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
     # colour gradient INSTEAD of the (P,M,3) SH gradient; dL_dsh is then returned as None and rebuilt after the exchange
-    dL_drgb = grad_alloc(grad_alloc, "sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
+    dL_drgb = grad_alloc("sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
     dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)

@@ -284,16 +284,33 @@ def test_needle_gaussians_match_oracle(oracle, bounds):
     # oracle adds pixel after pixel, the kernels reduce waves and tiles, the reference's atomics any order), so those
     # rows are only required to be finite and to agree in bulk.
     n = case["sc"]["xyz"].shape[0] // 4
+    # the reference's own backward on the same scene: how far IT is from the oracle on the needle rows
+    from oracle import ref as _refmod
+
+    gr = None
+    if _refmod.available("nofma"):
+        sc, cam = case["sc"], case["cam"]
+        R_ = _refmod.Reference("nofma", DEV)
+        R_.forward(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], None, None,
+                   cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], W, H, case["tfx"],
+                   case["tfy"], 1.0, case["D"])
+        gr = {k: _np(v) for k, v in R_.backward(G).items()}
     for k in GRADS:
         a = gp[k].reshape(gp[k].shape[0], -1).astype(np.float64)
         b = g[k].reshape(a.shape).astype(np.float64)
         scale = max(np.abs(b[n:]).max(), 1e-30)
         e_rest = float(np.abs(a[n:] - b[n:]).max() / scale)
-        l2_needles = float(np.linalg.norm(a[:n] - b[:n]) / max(np.linalg.norm(b[:n]), 1e-30))
-        print(f"  {bounds} {k}: well-conditioned rows max err {e_rest:.2e}; needle rows rel-L2 {l2_needles:.2e}")
+        l2 = lambda x, y: float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-30))  # noqa: E731
+        row = np.abs(a[:n] - b[:n]).max(axis=1) / np.maximum(np.abs(b[:n]).max(axis=1), 1e-30)
+        l2_prod = l2(a[:n], b[:n])
+        l2_ref = l2(gr[k].reshape(a.shape).astype(np.float64)[:n], b[:n]) if gr is not None else float("nan")
+        print(f"  {bounds} {k}: well-conditioned rows max err {e_rest:.2e}; needle rows: median row error {np.median(row):.2e}, "
+              f"rel-L2 product vs oracle {l2_prod:.2e}, reference(nofma) vs oracle {l2_ref:.2e}")
         assert np.isfinite(a).all(), k
         assert e_rest <= 1e-5, k
-        assert l2_needles <= 0.25, k
+        assert np.median(row) <= 1e-3, k
+        if gr is not None:  # no further from the oracle than the reference's own atomics put it
+            assert l2_prod <= 3.0 * l2_ref + 0.05, k
 
 
 def test_fast_exp_flag_parity_and_flag_pinning(oracle):
