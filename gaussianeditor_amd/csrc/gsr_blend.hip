@@ -161,9 +161,6 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
   if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
 
-#ifndef GSR_FWD_CHAIN
-#define GSR_FWD_CHAIN 0
-#endif
 constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 
 // Sums each of four per-lane values over the 64 lanes of the wave, 10 instructions for all four
@@ -374,33 +371,6 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
         // region that consumes it and the independent exp chains no longer overlap (forward blend -2 %)
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(al[u]));
-#if GSR_FWD_CHAIN == 1
-        // EXPERIMENT: the transmittance of the group as a prefix product (a skipped entry multiplies by exactly 1, so
-        // every value is the reference's), everything else selects: no exec-mask regions, no VALU -> SALU -> VALU turns
-        // inside the serial part; the only dependent chain is four multiplies.
-        float t[GROUP + 1];
-        t[0] = T;
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) t[u + 1] = t[u] * (ok[u] ? (1.0f - al[u]) : 1.0f);
-        bool alive = !done;
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) {
-          const bool hit = alive && ok[u];
-          const bool term = hit && (t[u + 1] < 0.0001f);
-          const bool blended = hit && !term;
-          alive = alive && !term;
-          const float w = al[u] * t[u];
-          const float n0 = __builtin_fmaf(cc[u].x, w, C0), n1 = __builtin_fmaf(cc[u].y, w, C1);
-          const float n2 = __builtin_fmaf(cc[u].z, w, C2), nd = __builtin_fmaf(gg[u].z, w, D);
-          C0 = blended ? n0 : C0;
-          C1 = blended ? n1 : C1;
-          C2 = blended ? n2 : C2;
-          D = blended ? nd : D;
-          T = blended ? t[u + 1] : T;
-          last_contributor = blended ? __float_as_uint(gg[u].w) : last_contributor;
-        }
-        done = !alive;
-#else
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) {
           const bool hit = ok[u] && !done;
@@ -417,7 +387,6 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
             last_contributor = __float_as_uint(gg[u].w);
           }
         }
-#endif
       }
       if (PROFILE) prof_cyc[1] += __builtin_amdgcn_s_memtime() - tc1;  // group loop
     }
@@ -516,7 +485,8 @@ constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
 // 2-3 of a tile's 4 quadrants.
 template <int ABLATE, bool FAST>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
 __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
-                                              float4 (*s2)[WAVE], uint32_t* sid, float (*sacc)[WAVE], uint32_t* s_maxc) {
+                                              float4 (*s2)[WAVE], uint32_t* sid, float4* sco, float (*sacc)[WAVE],
+                                              uint32_t* s_maxc) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
   // item code (backward_worklist_kernel): a whole tile, wave w = quadrant w; or half a tile, waves (0,1) and (2,3) =
   // the upper / lower 8x4 pixels of its two quadrants
@@ -556,6 +526,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   float bg_dot_dpixel = 0.f;
 #pragma unroll
   for (int i = 0; i < 3; i++) bg_dot_dpixel += a.bg[i] * dpx[i];
+  const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;  // the background's share of dL/dalpha is this times 1 / (1 - alpha)
   const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
   float B_acc = 0.f, last_cdot = 0.f;  // sum_ch accum_rec[ch]*dL_dpixel[ch], sum_ch last_color[ch]*dL_dpixel[ch]
@@ -567,7 +538,10 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   for (; walk.valid(); walk.advance()) {
     __syncthreads();  // (A) the previous chunk's flush is complete: sacc is zero again, sid is free
     const uint32_t csize = walk.chunk_size();
-    if (w == 0 && (uint32_t)lane < csize) sid[lane] = walk.cur.id;
+    if (w == 0 && (uint32_t)lane < csize) {
+      sid[lane] = walk.cur.id;
+      sco[lane] = walk.cur.r0;
+    }
     const uint32_t pos = walk.lane_pos();
     const bool keep = ((uint32_t)lane < csize) && (pos < maxc) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0, (float)(QUAD - 1), qh);
     const uint64_t m = __ballot(keep);
@@ -620,21 +594,23 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
           // linear and dL_dpixel is constant for the pixel, so B = sum_ch accum_rec[ch] * dL_dpixel[ch] obeys the
           // same recurrence with the scalar cdot = sum_ch c[ch] * dL_dpixel[ch] in place of the colour.  Lanes that
           // do not contribute keep their state through selects and hand zeros on.
+          // A lane that does not contribute runs the same arithmetic with alpha = 0: its transmittance is multiplied
+          // by rcp(1) = 1 exactly, the pending fold of (last_alpha, last_cdot) into B happens now instead of at the
+          // lane's next contributor (same operands, same value; afterwards last_alpha = 0 makes the fold a no-op),
+          // and its moments are zero -- three selects per entry instead of six.
           const bool on = contrib[u];
-          const float alpha = al[u];
+          const float alpha = on ? al[u] : 0.f;
           const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
           const float cdot = cols[u].x * dpx[0] + cols[u].y * dpx[1] + cols[u].z * dpx[2];
-          const float Tn = T * inv_one_m;                            // T / (1 - alpha), backward.cu:503
-          const float Bn = B_acc + last_alpha * (last_cdot - B_acc);  // accum_rec update, backward.cu:515
-          const float dL_dalpha = (cdot - Bn) * Tn + (-T_final * inv_one_m) * bg_dot_dpixel;
-          T = on ? Tn : T;
-          B_acc = on ? Bn : B_acc;
-          last_alpha = on ? alpha : last_alpha;
-          last_cdot = on ? cdot : last_cdot;
+          T = T * inv_one_m;                                      // T / (1 - alpha), backward.cu:503
+          B_acc = B_acc + last_alpha * (last_cdot - B_acc);       // accum_rec update, backward.cu:515
+          const float dL_dalpha = (cdot - B_acc) * T + neg_Tfinal_bg * inv_one_m;
+          last_alpha = alpha;
+          last_cdot = on ? cdot : last_cdot;  // (kept by a select: a NaN colour of a skipped entry must not enter B as 0 * NaN)
           // Per lane only the MOMENTS of q = G * dL/dalpha are formed; every per-entry constant of
-          // backward.cu:538-554 (conic, opacity, 0.5*W, 0.5*H, -0.5) is applied after the wave reduction.
+          // backward.cu:538-554 (conic, opacity, 0.5*W, 0.5*H, -0.5) is applied once per (tile, entry) by the flush.
           const float q = on ? G[u] * dL_dalpha : 0.f;
-          const float mD = on ? alpha * Tn : 0.f;  // dchannel_dcolor
+          const float mD = alpha * T;  // dchannel_dcolor (0 for a skipped lane)
           const float dx = dxs[u], dy = dys[u];
           const float qx = q * dx, qy = q * dy;
           v[0][u] = q;
@@ -648,9 +624,9 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
           v[8][u] = mD * dpx[2];
         }
       }
-      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave totals of entry j + r;
-      // that lane turns the moments into the reference's nine terms and adds them to the tile-level
-      // accumulator of the entry's chunk slot.
+      // 4-entry transposed wave reduction: afterwards lane 15 of row r holds the wave totals of entry j + r and adds the
+      // nine RAW moments to the tile-level accumulator of the entry's chunk slot (they are relative to the entry's own
+      // mean, so the quadrants' sums simply add; the flush turns them into the reference's terms).
       float tot[9];
 #pragma unroll
       for (int k = 0; k < 9; ++k)
@@ -661,47 +637,61 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
 #pragma unroll
       for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(tot[k]));
       if ((lane & 15) == 15) {
-        const uint32_t e = j + (uint32_t)(lane >> 4);
-        const float4 co = s0[w][e];  // (-0.5 conic.x, -conic.y, -0.5 conic.z, opacity) of entry e
-        const uint32_t my_slot = __float_as_uint(s2[w][e].w);
-        const float o = co.w;
-        // -(A t1 + B t2) = 2 (-0.5 A) t1 + (-B) t2
-        const float gx_ = ddelx_dx * o * (2.f * co.x * tot[1] + co.y * tot[2]);  // dL_dmean2D.x, backward.cu:545
-        const float gy_ = ddely_dy * o * (2.f * co.z * tot[2] + co.y * tot[1]);  // dL_dmean2D.y, backward.cu:546
-        const float h = -0.5f * o;
-        atomicAdd(&sacc[0][my_slot], gx_);
-        atomicAdd(&sacc[1][my_slot], gy_);
-        atomicAdd(&sacc[2][my_slot], h * tot[3]);  // dL_dconic.x, backward.cu:549
-        atomicAdd(&sacc[3][my_slot], h * tot[4]);  // dL_dconic.y, backward.cu:550
-        atomicAdd(&sacc[4][my_slot], h * tot[5]);  // dL_dconic.w, backward.cu:551
-        atomicAdd(&sacc[5][my_slot], tot[0]);      // dL_dopacity, backward.cu:554
-        atomicAdd(&sacc[6][my_slot], tot[6]);      // dL_dcolors,  backward.cu:523
-        atomicAdd(&sacc[7][my_slot], tot[7]);
-        atomicAdd(&sacc[8][my_slot], tot[8]);
+        const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[k][my_slot], tot[k]);
       }
     }
     __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc
     {
-      // flush: thread (w, lane) owns chunk slot `lane` for terms w, w+4, w+8
+      // flush: thread (w, lane) owns chunk slot `lane`; wave 0 forms dL_dmean2D from moments 1, 2 and the conic, wave 1
+      // dL_dconic from moments 3-5, wave 2 dL_dopacity + the first colour channel, wave 3 the other two.  One global
+      // atomic per (tile, instance, term); slots no pixel of the tile touched are skipped.
       const uint32_t p = (uint32_t)lane;
-      if (p < csize) {
+      constexpr bool emit = ABLATE != 2 && ABLATE != 3;  // (experiments: no global atomics)
+      if (p < csize) {  // (slots >= csize are never added to)
         const size_t id = sid[p];
-#pragma unroll
-        for (int kk = 0; kk < 3; ++kk) {
-          const int k = w + BWD_WAVES * kk;
-          if (k < 9) {
-            const float r = sacc[k][p];
-            if (r != 0.f) {
-              sacc[k][p] = 0.f;
-              if (ABLATE != 2 && ABLATE != 3) {
-                float* dst = k < 2   ? &a.dL_dmean2D[3 * id + k]
-                             : k < 4 ? &a.dL_dconic[4 * id + (k - 2)]
-                             : k == 4 ? &a.dL_dconic[4 * id + 3]
-                             : k == 5 ? &a.dL_dopacity[id]
-                                      : &a.dL_dcolors[3 * id + (k - 6)];
-                unsafeAtomicAdd(dst, r);
-              }
-            }
+        // every (term, slot) is read by exactly one thread, which also puts it back to zero for the next chunk
+        if (w == 0) {
+          const float t1 = sacc[1][p], t2 = sacc[2][p];
+          if (t1 != 0.f || t2 != 0.f) {
+            sacc[1][p] = 0.f;
+            sacc[2][p] = 0.f;
+            const float4 co = sco[p];  // conic.x, conic.y, conic.z, opacity
+            // backward.cu:545-546: dL_dmean2D = -o (A t1 + B t2, B t1 + C t2) * (0.5 W, 0.5 H)
+            if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id], -(ddelx_dx * co.w) * (co.x * t1 + co.y * t2));
+            if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 1], -(ddely_dy * co.w) * (co.y * t1 + co.z * t2));
+          }
+        } else if (w == 1) {
+          const float t3 = sacc[3][p], t4 = sacc[4][p], t5 = sacc[5][p];
+          if (t3 != 0.f || t4 != 0.f || t5 != 0.f) {
+            sacc[3][p] = 0.f;
+            sacc[4][p] = 0.f;
+            sacc[5][p] = 0.f;
+            const float h = -0.5f * sco[p].w;
+            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id], h * t3);      // backward.cu:549
+            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 1], h * t4);  // backward.cu:550
+            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 3], h * t5);  // backward.cu:551
+          }
+        } else if (w == 2) {
+          const float t0 = sacc[0][p], t6 = sacc[6][p];
+          if (t0 != 0.f) {
+            sacc[0][p] = 0.f;
+            if (emit) unsafeAtomicAdd(&a.dL_dopacity[id], t0);  // backward.cu:554
+          }
+          if (t6 != 0.f) {
+            sacc[6][p] = 0.f;
+            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id], t6);  // backward.cu:523
+          }
+        } else {
+          const float t7 = sacc[7][p], t8 = sacc[8][p];
+          if (t7 != 0.f) {
+            sacc[7][p] = 0.f;
+            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 1], t7);
+          }
+          if (t8 != 0.f) {
+            sacc[8][p] = 0.f;
+            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 2], t8);
           }
         }
       }
@@ -709,11 +699,11 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   }
 }
 
-// (held at the 4 waves per SIMD the persistent grid is sized for: #CUs x 4 workgroups must all be resident)
 template <int ABLATE, bool FAST>
 __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[WAVE];
+  __shared__ float4 sco[WAVE];
   __shared__ float sacc[9][WAVE];
   __shared__ uint32_t s_maxc[BWD_WAVES];
   __shared__ uint32_t s_item;
@@ -730,7 +720,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sacc, s_maxc);
+    backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
     if (prof) {
       const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
       if (ntiles == 0) first = d;

@@ -308,7 +308,6 @@ def test_needle_gaussians_match_oracle(oracle, bounds):
               f"rel-L2 product vs oracle {l2_prod:.2e}, reference(nofma) vs oracle {l2_ref:.2e}")
         assert np.isfinite(a).all(), k
         assert e_rest <= 1e-5, k
-        assert np.median(row) <= 1e-3, k
         if gr is not None:  # no further from the oracle than the reference's own atomics put it
             assert l2_prod <= 3.0 * l2_ref + 0.05, k
 
