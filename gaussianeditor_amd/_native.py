@@ -30,6 +30,11 @@ class DenseGrads(ctypes.Structure):
     _fields_ = [("means3D", _P), ("scales", _P), ("rotations", _P), ("means2D", _P), ("opacities", _P), ("sh", _P)]
 
 
+class AppendTensor(ctypes.Structure):
+    """gsr_append_tensor (include/gsr.h)."""
+    _fields_ = [("src", _P), ("ext", _P), ("dst", _P), ("row_bytes", c_int64)]
+
+
 class CompactTensor(ctypes.Structure):
     """gsr_compact_tensor (include/gsr.h)."""
     _fields_ = [("src", _P), ("dst", _P), ("row_bytes", c_int64)]
@@ -64,6 +69,7 @@ SIGNATURES = {
     "gsr_compact_workspace_size": (c_int, [c_int64, POINTER(c_size_t)]),
     "gsr_compact_plan": (c_int, [_P, c_int64, _P, _P, POINTER(c_int64)]),
     "gsr_compact_apply": (c_int, [_P, c_int64, _P, _P, c_int, POINTER(CompactTensor)]),
+    "gsr_append_rows": (c_int, [_P, c_int64, c_int64, c_int, POINTER(AppendTensor)]),
     "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
                             _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),

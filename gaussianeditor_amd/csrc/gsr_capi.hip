@@ -579,6 +579,18 @@ int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* worksp
   return GSR_OK;
 }
 
+int gsr_append_rows(void* stream, int64_t P, int64_t n, int num_tensors, const gsr_append_tensor* tensors) {
+  if (P < 0 || n < 0 || num_tensors < 0 || num_tensors > 32) return GSR_ERR_BAD_ARGUMENT;
+  if (num_tensors == 0 || P + n == 0) return GSR_OK;
+  if (!tensors) return GSR_ERR_BAD_ARGUMENT;
+  for (int i = 0; i < num_tensors; ++i) {
+    const gsr_append_tensor& t = tensors[i];
+    if (t.row_bytes < 1 || t.row_bytes > (1 << 20) || !t.dst || (P > 0 && !t.src)) return GSR_ERR_BAD_ARGUMENT;
+  }
+  GSR_HIP(launch_append_rows((hipStream_t)stream, P, n, num_tensors, tensors));
+  return GSR_OK;
+}
+
 int gsr_debug_cov3d(void* stream, int P, const float* scales, float scale_modifier, const float* rotations, float* cov3D) {
   if (P <= 0) return GSR_OK;
   if (!scales || !rotations || !cov3D) return GSR_ERR_BAD_ARGUMENT;

@@ -162,4 +162,68 @@ hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, v
   return hipGetLastError();
 }
 
+// ----------------------------------------------------------------------------------
+// Row append for MANY tensors in one launch (densification): dst = [src (P rows) ; ext (n rows) or zeros].
+// Replaces the torch.cat + torch.zeros_like pairs of cat_tensors_to_optimizer
+// (gaussiansplatting/scene/gaussian_model.py:609-641: per parameter group the parameter itself and its two Adam
+// moments, the moments extended by zeros).  Pure streaming: the P old rows move as 16-byte vectors.
+// ----------------------------------------------------------------------------------
+struct AppendTensorDev {
+  const uint8_t* src;
+  const uint8_t* ext;  // null: the appended rows are zero
+  uint8_t* dst;
+  uint64_t old_bytes;  // P * row_bytes
+  uint64_t new_bytes;  // n * row_bytes
+};
+struct AppendArgs {
+  AppendTensorDev t[CMP_MAX_TENSORS];
+};
+// grid = (blocks per tensor, tensors)
+__global__ void __launch_bounds__(256) append_rows_kernel(const AppendArgs a) {
+  const AppendTensorDev t = a.t[blockIdx.y];
+  const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x, stride = (uint64_t)gridDim.x * 256;
+  // the old rows: 16-byte vectors where source and destination allow it, then the odd bytes
+  uint64_t done = 0;
+  if ((((uintptr_t)t.src | (uintptr_t)t.dst) & 15u) == 0) {
+    const uint64_t nv = t.old_bytes >> 4;
+    const uint4* __restrict__ s = reinterpret_cast<const uint4*>(t.src);
+    uint4* __restrict__ d = reinterpret_cast<uint4*>(t.dst);
+    for (uint64_t i = tid; i < nv; i += stride) d[i] = s[i];
+    done = nv << 4;
+  }
+  for (uint64_t i = done + tid; i < t.old_bytes; i += stride) t.dst[i] = t.src[i];
+  // the appended rows (few): 4-byte words when everything is word aligned, bytes otherwise
+  uint8_t* __restrict__ d2 = t.dst + t.old_bytes;
+  if ((((uintptr_t)d2 | (uintptr_t)t.ext | t.new_bytes) & 3u) == 0) {
+    const uint64_t nw = t.new_bytes >> 2;
+    const uint32_t* __restrict__ e = reinterpret_cast<const uint32_t*>(t.ext);
+    uint32_t* __restrict__ d = reinterpret_cast<uint32_t*>(d2);
+    for (uint64_t i = tid; i < nw; i += stride) d[i] = e ? e[i] : 0u;
+  } else {
+    for (uint64_t i = tid; i < t.new_bytes; i += stride) d2[i] = t.ext ? t.ext[i] : (uint8_t)0;
+  }
+}
+
+hipError_t launch_append_rows(hipStream_t s, int64_t P, int64_t n, int nt, const gsr_append_tensor* tensors) {
+  if (nt <= 0 || P + n <= 0) return hipSuccess;
+  if (nt > CMP_MAX_TENSORS) return hipErrorInvalidValue;
+  AppendArgs a;
+  memset(&a, 0, sizeof(a));
+  uint64_t most = 0;
+  for (int i = 0; i < nt; ++i) {
+    a.t[i].src = (const uint8_t*)tensors[i].src;
+    a.t[i].ext = (const uint8_t*)tensors[i].ext;
+    a.t[i].dst = (uint8_t*)tensors[i].dst;
+    a.t[i].old_bytes = (uint64_t)P * (uint64_t)tensors[i].row_bytes;
+    a.t[i].new_bytes = (uint64_t)n * (uint64_t)tensors[i].row_bytes;
+    const uint64_t b = a.t[i].old_bytes + a.t[i].new_bytes;
+    if (b > most) most = b;
+  }
+  // enough blocks for the largest tensor at 64 bytes per thread, capped (the loops are grid-stride)
+  const uint64_t want = (most + 256ull * 64ull - 1) / (256ull * 64ull);
+  const unsigned bx = (unsigned)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(append_rows_kernel, dim3(bx, (unsigned)nt), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace gsr

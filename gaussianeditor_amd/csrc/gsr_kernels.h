@@ -127,6 +127,7 @@ hipError_t launch_compact_plan(hipStream_t s, int64_t P, const uint8_t* keep, vo
 const uint64_t* compact_total_ptr(void* workspace, int64_t P);
 hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace, int nt,
                                 const gsr_compact_tensor* tensors);
+hipError_t launch_append_rows(hipStream_t s, int64_t P, int64_t n, int nt, const gsr_append_tensor* tensors);
 hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
                             double beta2, double eps, const uint8_t* row_mask, const float* row_weight);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);

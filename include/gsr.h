@@ -293,6 +293,22 @@ int gsr_compact_plan(void* stream, int64_t P, const uint8_t* keep, void* workspa
 int gsr_compact_apply(void* stream, int64_t P, const uint8_t* keep, void* workspace, int num_tensors,
                       const gsr_compact_tensor* tensors);
 
+/* ---- SURVEY.md section 8(f) rank 4, second half: densification = rows APPENDED to many tensors in one launch ----
+ * Replaces cat_tensors_to_optimizer (gaussiansplatting/scene/gaussian_model.py:609-641), which per parameter group runs
+ * torch.cat on the parameter and on its two Adam moments (the moments extended by torch.zeros_like): 18 cats + 12 fills
+ * per densification step (densify_and_clone :730-766 and densify_and_split :673-728 both end in it through
+ * densification_postfix :643-671).  For every tensor: dst (P + n rows) = src (P rows) followed by ext (n rows), or by n
+ * zero rows when ext == NULL -- what torch.cat((src, ext)) / torch.cat((src, zeros_like(ext))) return, bit for bit.
+ * The caller allocates dst; src / ext / dst must not overlap; at most 32 tensors per call.  Which rows are appended (the
+ * clone mask, the split samples) stays with the caller: a clone's ext is gsr_compact_apply's output for that mask. */
+typedef struct gsr_append_tensor {
+  const void* src;   /* P rows */
+  const void* ext;   /* n rows, or NULL for zeros */
+  void* dst;         /* P + n rows */
+  int64_t row_bytes;
+} gsr_append_tensor;
+int gsr_append_rows(void* stream, int64_t P, int64_t n, int num_tensors, const gsr_append_tensor* tensors);
+
 /* ---- introspection used by the parity tests (not needed by the drop-in) ----
  * Copy internal per-Gaussian / per-instance / per-pixel state out of the opaque
  * scratch buffers into caller-provided DEVICE arrays (any may be NULL):

@@ -283,3 +283,15 @@ def compact_rows(arrays, keep):
     what `tensor[mask]` does in GaussianModel._prune_optimizer, gaussian_model.py:568-591)."""
     k = np.asarray(keep).astype(bool)
     return [np.ascontiguousarray(np.asarray(a)[k]) for a in arrays]
+
+
+def append_rows(arrays, extensions, n=None):
+    """Densification restated: np.concatenate((a, e)) per tensor, None = n zero rows (what torch.cat((t, e)) /
+    torch.cat((t, zeros_like(e))) do in GaussianModel.cat_tensors_to_optimizer, gaussian_model.py:609-641)."""
+    out = []
+    for a, e in zip(arrays, extensions):
+        a = np.asarray(a)
+        if e is None:
+            e = np.zeros((n,) + a.shape[1:], dtype=a.dtype)
+        out.append(np.ascontiguousarray(np.concatenate((a, np.asarray(e, dtype=a.dtype)), axis=0)))
+    return out

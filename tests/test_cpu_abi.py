@@ -74,6 +74,11 @@ def test_argument_validation_needs_no_gpu():
     assert L.gsr_view_message_plan(None, 10, None, None, None, None, None) == -1
     assert L.gsr_view_messages_accumulate(None, 10, 3, 16, 0, None, 0, 0, None, None) == -1  # no views
     assert L.gsr_adam_step(None, 0, None, 1, 0.9, 0.999, 1e-15, None, None) in (0, -1)
+    assert L.gsr_append_rows(None, 10, 5, 0, None) == 0 and L.gsr_append_rows(None, 0, 0, 3, None) == 0  # nothing to do
+    assert L.gsr_append_rows(None, 10, 5, 3, None) == -1 and L.gsr_append_rows(None, -1, 5, 1, None) == -1
+    assert L.gsr_append_rows(None, 10, 5, 33, None) == -1
+    bad = (_native.AppendTensor * 1)(_native.AppendTensor(None, None, ctypes.c_void_p(16), 12))  # P > 0 without a source
+    assert L.gsr_append_rows(None, 10, 5, 1, bad) == -1
     assert b"31-bit" in L.gsr_status_string(-3)
     # per-call flags (ABI 2): unknown bits are rejected before anything else is looked at; the library has no option state
     assert not hasattr(L, "gsr_set_option")

@@ -119,6 +119,7 @@ CASES = [
     (20000, 512, 512, 0.02, 4, 3),
     (1_000_000, 1920, 1080, 0.01, 0, 3),  # the headline view of bench.py (synth-v1, seed 0, ring-v1 view 0 of 8)
     (6_000_000, 1920, 1080, 0.01, 0, 3),  # BASELINE configs[1] substitute: 6 M Gaussians, 1080p
+    (1_000_000, 1920, 1080, 0.04, 0, 3),  # deep tiles: R ~ 2e7, lists an order of magnitude longer (the regime of real captures)
 ]
 
 
@@ -402,3 +403,82 @@ def test_bench_refuses_more_gpus_than_visible():
                        capture_output=True, text=True, timeout=300, cwd=ROOT,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert p.returncode != 0 and "refusing" in (p.stderr + p.stdout)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# SURVEY.md section 8(f) rank 4, second half: densification appends (gsr_append_rows)
+@pytest.mark.parametrize("P,n", [(0, 5), (1, 0), (1, 1), (1023, 77), (100001, 12345), (5, 4096)])
+def test_append_rows_equals_torch_cat(oracle, P, n):
+    from gaussianeditor_amd.densify import append_rows
+
+    g = torch.Generator().manual_seed(P + n)
+    mk = lambda rows: [torch.randn(rows, 3, generator=g), torch.randn(rows, 15, 3, generator=g), torch.randn(rows, 1, generator=g),  # noqa: E731
+                       torch.randn(rows, 4, generator=g), torch.arange(rows, dtype=torch.int64),
+                       torch.rand(rows, generator=g) > 0.5, torch.randint(0, 255, (rows, 3), generator=g, dtype=torch.uint8)]
+    ts, es = mk(P), mk(n)
+    es[1] = None  # zero rows, as for an Adam moment
+    es[6] = None
+    out = append_rows([t.to(DEV) for t in ts], [None if e is None else e.to(DEV) for e in es], n=n)
+    ref = oracle.append_rows([t.numpy() for t in ts], [None if e is None else e.numpy() for e in es], n)
+    for o, r, t, e in zip(out, ref, ts, es):
+        assert o.dtype == t.dtype and o.shape[0] == P + n
+        assert np.array_equal(_np(o), r)
+        want = torch.cat((t, torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype) if e is None else e), dim=0)
+        assert torch.equal(o.cpu(), want)
+
+
+def test_cat_tensors_to_optimizer_and_clone_like_reference():
+    """cat_tensors_to_optimizer / clone_rows == GaussianModel.cat_tensors_to_optimizer (gaussian_model.py:609-641) after
+    the selection of densify_and_clone (:743-748), on an Adam with state: parameters, both moments, Parameter identity in
+    the optimizer's state dict; and the grown optimizer keeps working."""
+    from gaussianeditor_amd.densify import cat_tensors_to_optimizer, clone_rows
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    P = 5003
+    gen = torch.Generator().manual_seed(3)
+    init = {"xyz": torch.randn(P, 3, generator=gen), "f_dc": torch.randn(P, 1, 3, generator=gen),
+            "f_rest": torch.randn(P, 15, 3, generator=gen), "opacity": torch.randn(P, 1, generator=gen),
+            "scaling": torch.randn(P, 3, generator=gen), "rotation": torch.randn(P, 4, generator=gen)}
+
+    def build():
+        params = {k: v.clone().to(DEV).requires_grad_(True) for k, v in init.items()}
+        opt = FusedMaskedAdam([{"params": [p], "lr": 1e-3, "name": k} for k, p in params.items()], lr=0.0, eps=1e-15)
+        g2 = torch.Generator().manual_seed(1)
+        for p in params.values():
+            p.grad = torch.randn(p.shape, generator=g2).to(DEV)
+        opt.step()
+        return opt
+
+    def reference_cat(opt, d):  # the reference's loop, verbatim in behaviour
+        res = {}
+        for group in opt.param_groups:
+            ext = d[group["name"]]
+            st = opt.state.get(group["params"][0], None)
+            st["exp_avg"] = torch.cat((st["exp_avg"], torch.zeros_like(ext)), dim=0)
+            st["exp_avg_sq"] = torch.cat((st["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
+            del opt.state[group["params"][0]]
+            group["params"][0] = torch.nn.Parameter(torch.cat((group["params"][0], ext), dim=0).requires_grad_(True))
+            opt.state[group["params"][0]] = st
+            res[group["name"]] = group["params"][0]
+        return res
+
+    sel = (torch.rand(P, generator=gen) < 0.13).to(DEV)
+    a, b = build(), build()
+    new = clone_rows(a, sel)
+    reference_cat(b, {g["name"]: g["params"][0][sel] for g in b.param_groups})
+    n = int(sel.sum())
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        pa, pb = ga["params"][0], gb["params"][0]
+        assert new[ga["name"]] is pa and pa.requires_grad and pa.shape[0] == P + n and torch.equal(pa, pb)
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(a.state[pa][k], b.state[pb][k]) and float(a.state[pa][k][P:].abs().max()) == 0.0
+    # the split path hands over tensors computed in torch
+    ext = {g["name"]: torch.randn((7,) + tuple(g["params"][0].shape[1:]), generator=gen).to(DEV) for g in a.param_groups}
+    cat_tensors_to_optimizer(a, ext)
+    reference_cat(b, ext)
+    for ga, gb in zip(a.param_groups, b.param_groups):
+        assert torch.equal(ga["params"][0], gb["params"][0])
+        assert torch.equal(a.state[ga["params"][0]]["exp_avg_sq"], b.state[gb["params"][0]]["exp_avg_sq"])
+    for p in (g["params"][0] for g in a.param_groups):
+        p.grad = torch.ones_like(p)
+    a.step()
