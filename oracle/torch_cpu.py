@@ -110,8 +110,14 @@ def preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatri
 
 
 def render(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, bg, W: int, H: int, tanfovx: float,
-           tanfovy: float, scale_modifier: float = 1.0, sh_degree: int = 0, colors_precomp: Optional[torch.Tensor] = None):
-    """Forward render on the host: (color (3,H,W), depth (1,H,W), radii (P) int32, num_rendered)."""
+           tanfovy: float, scale_modifier: float = 1.0, sh_degree: int = 0, colors_precomp: Optional[torch.Tensor] = None,
+           tile_stride: int = 1, stats: Optional[dict] = None):
+    """Forward render on the host: (color (3,H,W), depth (1,H,W), radii (P) int32, num_rendered).
+    tile_stride > 1 (timing only): blend every tile_stride-th non-empty tile; `stats`, if given, receives the seconds
+    spent before blending, in blending, and the tile counts."""
+    import time as _time
+
+    _t0 = _time.perf_counter()
     with torch.no_grad():
         g = preprocess(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy,
                        scale_modifier, sh_degree, colors_precomp)
@@ -139,7 +145,11 @@ def render(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, c
         ends = torch.cumsum(counts, 0)
         begins = ends - counts
         ys, xs = torch.meshgrid(torch.arange(TILE), torch.arange(TILE), indexing="ij")
-        for t in counts.nonzero().view(-1).tolist():
+        nonempty = counts.nonzero().view(-1).tolist()
+        _t1 = _time.perf_counter()
+        if stats is not None:
+            stats.update(prepare_s=_t1 - _t0, tiles_nonempty=len(nonempty), tiles_blended=len(nonempty[::tile_stride]))
+        for t in nonempty[::tile_stride]:
             ids = point_list[begins[t]:ends[t]]
             tx, ty = t % gx, t // gx
             px = (tx * TILE + xs).reshape(-1)
@@ -165,4 +175,38 @@ def render(means3D, scales, rotations, opacities, shs, viewmatrix, projmatrix, c
             final_T = torch.where(alive, 1.0 - a, torch.ones_like(a)).prod(dim=1)
             color[:, py, px] = (col + final_T[:, None] * bg[None, :]).t()
             depth[0, py, px] = dep
+        if stats is not None:
+            stats["blend_s"] = _time.perf_counter() - _t1
         return color, depth, g["radii"], R
+
+
+def _bench_main(argv):
+    """`python -m oracle.torch_cpu P W H s0 view nviews tile_stride threads` -> one JSON line (bench.py's second
+    cpu_baseline leg, run as a subprocess so that its thread pool and a hard timeout are its own)."""
+    import json
+    import math
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from gaussianeditor_amd.synth import ring_cameras, synth_scene
+
+    P, W, H = int(argv[0]), int(argv[1]), int(argv[2])
+    s0, view, nviews, stride, threads = float(argv[3]), int(argv[4]), int(argv[5]), int(argv[6]), int(argv[7])
+    torch.set_num_threads(threads)
+    sc = synth_scene(P, seed=0, s0=s0, sh_degree=3)
+    cam = ring_cameras(nviews, W, H)[view]
+    st = {}
+    color, _, _, R = render(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], cam.world_view_transform,
+                            cam.full_proj_transform, cam.camera_center, sc["bg"], W, H, math.tan(cam.FoVx / 2),
+                            math.tan(cam.FoVy / 2), 1.0, 3, tile_stride=stride, stats=st)
+    full = st["prepare_s"] + st["blend_s"] * st["tiles_nonempty"] / max(st["tiles_blended"], 1)
+    print(json.dumps({"seconds_per_render": full, "prepare_s": st["prepare_s"], "blend_s_sampled": st["blend_s"],
+                      "tiles_nonempty": st["tiles_nonempty"], "tiles_blended": st["tiles_blended"], "num_rendered": R,
+                      "threads": torch.get_num_threads()}))
+
+
+if __name__ == "__main__":
+    import sys as _sys
+
+    _bench_main(_sys.argv[1:])

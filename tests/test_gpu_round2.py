@@ -351,9 +351,9 @@ def test_fast_exp_flag_parity_and_flag_pinning(oracle):
     seen = []
     orig = _C.rasterize_gaussians_backward
 
-    def spy(*a, flags=None):
+    def spy(*a, flags=None, **kw):
         seen.append(flags)
-        return orig(*a, flags=flags)
+        return orig(*a, flags=flags, **kw)
 
     _C.rasterize_gaussians_backward = spy
     try:
