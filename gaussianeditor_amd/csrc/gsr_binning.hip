@@ -41,7 +41,8 @@ constexpr int RBINS = 1 << RBITS;
 // depth keys) and writes the four words into the caller's pinned, device-mapped host buffer -- the readback of
 // gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before) and without a
 // header to clear in front of K1.
-__global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t* __restrict__ keys, int64_t n, int shift,
+template <class K>
+__global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t nblocks, const uint4* __restrict__ publish_src,
                                                                 uint32_t publish_count, uint32_t* __restrict__ publish_dst,
@@ -94,7 +95,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t*
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
-    kv[i] = keys[k < n ? k : n - 1];
+    kv[i] = (uint32_t)keys[k < n ? k : n - 1];
   }
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
@@ -105,18 +106,30 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const uint32_t*
   hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
-// One block per bin; exclusive scan of that bin's nblocks counts in place.
+// One block per bin; exclusive scan of that bin's nblocks counts in place.  Every thread takes SCAN_PER consecutive counts
+// per round (the rows of a deep scene hold > 10^4 counts: one count per thread and round made this kernel as long as a
+// histogram pass).
+constexpr int SCAN_PER = 8;
 __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bin_total,
                                                                 uint32_t nblocks) {
   __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
   uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
   uint32_t carry = 0;
-  for (uint32_t base = 0; base < nblocks; base += SORT_THREADS) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nblocks ? row[i] : 0u;
+  for (uint32_t base = 0; base < nblocks; base += SORT_THREADS * SCAN_PER) {
+    const uint32_t i0 = base + threadIdx.x * SCAN_PER;
+    uint32_t v[SCAN_PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) {
+      v[j] = i0 + j < nblocks ? row[i0 + j] : 0u;
+      sum += v[j];
+    }
     uint32_t chunk;
-    const uint32_t ex = block_excl_scan_u32<SORT_THREADS>(v, &chunk, smem);
-    if (i < nblocks) row[i] = carry + ex;
+    uint32_t run = carry + block_excl_scan_u32<SORT_THREADS>(sum, &chunk, smem);
+#pragma unroll
+    for (int j = 0; j < SCAN_PER; ++j) {
+      if (i0 + j < nblocks) row[i0 + j] = run;
+      run += v[j];
+    }
     carry += chunk;
   }
   if (threadIdx.x == 0) bin_total[blockIdx.x] = carry;
@@ -127,10 +140,10 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __res
 // (lower lanes with the same digit in this iteration, from 8 ballots).  The block's pairs are then
 // permuted into digit order IN LDS and written out with consecutive threads covering consecutive
 // sorted slots, so every digit's run is one contiguous global store stream.
-template <bool IOTA>
-__global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32_t* __restrict__ keys_in,
+template <bool IOTA, class K>
+__global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const K* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
-                                                                   uint32_t* __restrict__ keys_out,
+                                                                   K* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                                    uint32_t mask, const uint32_t* __restrict__ hist,
                                                                    const uint32_t* __restrict__ bin_total,
@@ -154,7 +167,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
-    key[i] = keys_in[kc];
+    key[i] = (uint32_t)keys_in[kc];
     val[i] = IOTA ? (uint32_t)kc : vals_in[kc];
   }
   const uint32_t my_hist = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
@@ -218,7 +231,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
       const uint32_t kk = skey[j];
       const uint32_t d = (kk >> shift) & mask;
       const uint32_t pos = gbase[d] + ((uint32_t)j - lexcl[d]);
-      keys_out[pos] = kk;
+      keys_out[pos] = (K)kk;
       vals_out[pos] = sval[j];
     }
   }
@@ -227,7 +240,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const uint32
 // Sorts (keys[0], vals[0]) by key bits [0, sum(digits)); result in buffer (npass & 1).  Passes [p0, npass) of the
 // sequence are launched (pass p reads buffer p & 1), so a caller can enqueue a prefix of the passes, decide how
 // many more are needed and continue.
-static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
+template <class K>
+static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
                              const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0,
                              const uint4* publish_src = nullptr, uint32_t publish_count = 0, uint32_t* publish_dst = nullptr,
                              uint32_t publish_seq = 0) {
@@ -237,15 +251,15 @@ static void radix_sort_pairs(hipStream_t s, uint32_t* const keys[2], uint32_t* c
   for (int p = p0; p < npass; ++p) {
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
     const bool pub = p == p0 && publish_dst != nullptr;
-    hipLaunchKernelGGL(sort_hist_kernel, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], n, shift, mask, hist, nblocks,
+    hipLaunchKernelGGL(sort_hist_kernel<K>, dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur], n, shift, mask, hist, nblocks,
                        pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
-      hipLaunchKernelGGL(sort_scatter_kernel<true>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
-                         keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+      hipLaunchKernelGGL((sort_scatter_kernel<true, K>), dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur],
+                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
     else
-      hipLaunchKernelGGL(sort_scatter_kernel<false>, dim3(nblocks), dim3(SORT_THREADS), 0, s, keys[cur], vals[cur],
-                         keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+      hipLaunchKernelGGL((sort_scatter_kernel<false, K>), dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur],
+                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
     shift += digit_bits[p];
     cur ^= 1;
   }
@@ -286,7 +300,7 @@ __global__ void __launch_bounds__(1024) scan_blocks_kernel(const uint32_t* __res
 // exported for the other translation units (gsr_knn.hip)
 void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
                           const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first) {
-  radix_sort_pairs(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first);
+  radix_sort_pairs<uint32_t>(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first);
 }
 
 // Depth order of the Gaussians: passes [p0, p1) of the 8-bit LSD sort on the depth bits.  Only the bits in which
@@ -294,7 +308,7 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
 // first passes, learns the key range from K1 and adds what is missing.
 static const int kDepthDigits[4] = {8, 8, 8, 8};
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst, uint32_t publish_seq) {
-  radix_sort_pairs(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0, g.k1_partials,
+  radix_sort_pairs<uint32_t>(s, g.dkey, g.dval, P, p1, kDepthDigits, g.ghist, g.gbin_total, true, p0, g.k1_partials,
                    (uint32_t)((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK), publish_dst, publish_seq);
   return hipGetLastError();
 }
@@ -318,8 +332,9 @@ hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes) 
 // inside its rectangle gives the tile, rows first as the reference's loops do.
 // Only the tile id is written as key (the depth is implied by the position).
 // ----------------------------------------------------------------------------------
+template <class K>
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
-                                                               const Geom g, uint32_t* __restrict__ tkeys,
+                                                               const Geom g, K* __restrict__ tkeys,
                                                                uint32_t* __restrict__ vals, uint2* __restrict__ ranges) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_org[GAUSS_BLOCK], s_w[GAUSS_BLOCK];
@@ -360,7 +375,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
     if (row * wj > k) row--;
     if ((row + 1u) * wj <= k) row++;
     const uint32_t col = k - row * wj;
-    tkeys[boff + s] = s_org[lo] + row * (uint32_t)gx + col;
+    tkeys[boff + s] = (K)(s_org[lo] + row * (uint32_t)gx + col);
     vals[boff + s] = s_idx[lo];
   }
 }
@@ -368,7 +383,8 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
 // ----------------------------------------------------------------------------------
 // K5: identifyTileRanges, rasterizer_impl.cu:105-125 (ranges zeroed beforehand, :263-265).
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const uint32_t* __restrict__ tkeys,
+template <class K>
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const K* __restrict__ tkeys,
                                                          uint2* __restrict__ ranges) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
@@ -452,18 +468,26 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const i
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(emit_keys_kernel, dim3(max(nbg, (gx * gy + GAUSS_BLOCK - 1) / GAUSS_BLOCK)), dim3(GAUSS_BLOCK), 0, s, P, gx,
-                     gy, radii, g, b.tkey[0], b.vals[0], im.ranges);
-  radix_sort_pairs(s, b.tkey, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
-  const int64_t nbr = (R + 255) / 256;
-  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)nbr), dim3(256), 0, s, R, b.tkey[b.final_buf], im.ranges);
+  const dim3 ge(max(nbg, (gx * gy + GAUSS_BLOCK - 1) / GAUSS_BLOCK)), gr((unsigned)((R + 255) / 256));
+  if (b.key_bytes == 2) {  // tile ids fit 16 bits: 6 instead of 8 bytes per sorted pair
+    uint16_t* const tk[2] = {(uint16_t*)b.tkey[0], (uint16_t*)b.tkey[1]};
+    hipLaunchKernelGGL(emit_keys_kernel<uint16_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, tk[0], b.vals[0], im.ranges);
+    radix_sort_pairs<uint16_t>(s, tk, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
+    hipLaunchKernelGGL(tile_ranges_kernel<uint16_t>, gr, dim3(256), 0, s, R, (const uint16_t*)tk[b.final_buf], im.ranges);
+  } else {
+    uint32_t* const tk[2] = {(uint32_t*)b.tkey[0], (uint32_t*)b.tkey[1]};
+    hipLaunchKernelGGL(emit_keys_kernel<uint32_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, tk[0], b.vals[0], im.ranges);
+    radix_sort_pairs<uint32_t>(s, tk, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
+    hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, gr, dim3(256), 0, s, R, (const uint32_t*)tk[b.final_buf], im.ranges);
+  }
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
                      im.queue_heads, im.work_est);
   return hipGetLastError();
 }
 
 // Test-only: rebuild the reference's 64-bit sorted keys, (tile << 32) | depth bits.
-__global__ void __launch_bounds__(256) export_keys_kernel(int64_t R, const uint32_t* __restrict__ tkeys,
+template <class K>
+__global__ void __launch_bounds__(256) export_keys_kernel(int64_t R, const K* __restrict__ tkeys,
                                                          const uint32_t* __restrict__ vals, const float4* __restrict__ rec1,
                                                          uint64_t* __restrict__ keys) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -471,8 +495,12 @@ __global__ void __launch_bounds__(256) export_keys_kernel(int64_t R, const uint3
   keys[i] = ((uint64_t)tkeys[i] << 32) | (uint64_t)__float_as_uint(rec1[vals[i]].z);
 }
 hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys) {
-  hipLaunchKernelGGL(export_keys_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R, b.tkey[b.final_buf],
-                     b.vals[b.final_buf], g.rec1, keys);
+  if (b.key_bytes == 2)
+    hipLaunchKernelGGL(export_keys_kernel<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
+                       (const uint16_t*)b.tkey[b.final_buf], b.vals[b.final_buf], g.rec1, keys);
+  else
+    hipLaunchKernelGGL(export_keys_kernel<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
+                       (const uint32_t*)b.tkey[b.final_buf], b.vals[b.final_buf], g.rec1, keys);
   return hipGetLastError();
 }
 

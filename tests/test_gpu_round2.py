@@ -482,3 +482,24 @@ def test_cat_tensors_to_optimizer_and_clone_like_reference():
     for p in (g["params"][0] for g in a.param_groups):
         p.grad = torch.ones_like(p)
     a.step()
+
+
+def test_images_beyond_65535_tiles_use_wide_tile_keys(oracle):
+    """Tile ids are sorted as uint16 when they fit (6 instead of 8 bytes per sorted pair); an image of 257 x 257 = 66049
+    tiles takes the uint32 path.  Both against the oracle: keys, lists, ranges bit-exact."""
+    from gaussianeditor_amd import _native
+
+    for W, H, wide in ((4112, 4112, True), (4096, 4080, False)):
+        assert (int(_native.lib().gsr_sort_key_bits(W, H)) - 32 > 16) == wide
+        case = make_case(3000, W, H, seed=6, s0=0.05, nviews=3, view=1)
+        f = oracle_forward(oracle, case)
+        G = torch.zeros(3, H, W)
+        G[:, ::7, ::5] = 1.0
+        color, depth, radii, R, st, gp = _product(case, G)
+        assert R == f["num_rendered"] and R > 0
+        assert np.array_equal(st["keys"], f["keys"]) and np.array_equal(st["point_list"], f["point_list"])
+        assert np.array_equal(st["ranges"], f["ranges"]) and np.array_equal(st["n_contrib"], f["n_contrib"])
+        assert np.array_equal(color, f["color"])
+        g = oracle_backward(oracle, case, f, G)
+        for k in GRADS:
+            assert rel_err(gp[k], g[k].reshape(gp[k].shape)) <= 1e-5, k
