@@ -39,7 +39,9 @@ def test_scratch_sizes_and_sort_bits():
     assert L.gsr_sort_key_bits(1920, 1080) == 45
     g0, b0, i0 = _native.scratch_sizes(1000, 0, 640, 480)
     g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480)
-    assert b0 == 0 and b1 > 5000 * 16 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
+    # per instance: ping-pong tile ids (uint16 while an image has at most 65535 tiles, uint32 beyond) + ping-pong indices
+    assert b0 == 0 and b1 > 5000 * 12 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
+    assert _native.scratch_sizes(2000, 5000, 4112, 4112)[1] > 5000 * 16
     with pytest.raises(_native.GsrError):
         _native.scratch_sizes(-1, 0, 640, 480)
 
