@@ -268,16 +268,23 @@ static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const va
 // ----------------------------------------------------------------------------------
 // Depth order of the Gaussians + prefix of tiles_touched in that order.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, const uint32_t* __restrict__ order,
-                                                                       const uint32_t* __restrict__ tiles,
-                                                                       uint32_t* __restrict__ tiles_sorted,
+__global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, int gx, const uint32_t* __restrict__ order,
+                                                                       const uint2* __restrict__ rect,
+                                                                       uint32_t* __restrict__ wh_sorted,
+                                                                       uint32_t* __restrict__ org_sorted,
                                                                        uint32_t* __restrict__ block_sums,
                                                                        uint32_t* __restrict__ hdr, uint32_t final_buf) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   if (blockIdx.x == 0 && threadIdx.x == 0) hdr[GEOM_HDR_FINAL] = final_buf;  // for emit_keys_kernel (gsr_bin)
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  const uint32_t n = i < P ? tiles[order[i]] : 0u;
-  if (i < P) tiles_sorted[i] = n;  // the emit kernel reads the counts coalesced instead of gathering them again
+  // THE gather of the binning: the tile rectangle of the i-th Gaussian in depth order (8 bytes; its area is the tile count).
+  // It is left in depth order for the emit kernel, which then reads everything coalesced.
+  const uint2 rc = i < P ? rect[order[i]] : make_uint2(0u, 0u);
+  const uint32_t n = (rc.y & 0xffffu) * (rc.y >> 16);
+  if (i < P) {
+    wh_sorted[i] = rc.y;                                            // width | height << 16
+    org_sorted[i] = (rc.x >> 16) * (uint32_t)gx + (rc.x & 0xffffu);  // tile id of the rectangle's first tile
+  }
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
   if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
@@ -313,12 +320,12 @@ hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int 
   return hipGetLastError();
 }
 // After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).
-hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes) {
+hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx) {
   const int fin = passes & 1;
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  // dkey[fin ^ 1] (the input of the last pass) is dead: reuse it for the depth-ordered counts
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g.dval[fin], g.tiles, g.dkey[fin ^ 1],
-                     g.block_sums, reinterpret_cast<uint32_t*>(g.total), (uint32_t)fin);
+  // dkey[fin ^ 1] / dval[fin ^ 1] (the input of the last pass) are dead: reuse them for the depth-ordered rectangles
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, gx, g.dval[fin], g.rect, g.dkey[fin ^ 1],
+                     g.dval[fin ^ 1], g.block_sums, reinterpret_cast<uint32_t*>(g.total), (uint32_t)fin);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, g.block_offs, nb);
   return hipGetLastError();
 }
@@ -345,16 +352,13 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
   if ((int)blockIdx.x * GAUSS_BLOCK >= P) return;  // (extra blocks only clear ranges)
   const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
   const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
-  const uint32_t n = i < P ? g.dkey[fin ^ 1u][i] : 0u;  // tiles_touched in depth order (sorted_block_sums_kernel)
+  // the rectangle of the Gaussian in depth order, left there by sorted_block_sums_kernel: no gather in this kernel
+  const uint32_t wh = i < P ? g.dkey[fin ^ 1u][i] : 0u;
+  const uint32_t w = max(wh & 0xffffu, 1u), n = (wh & 0xffffu) * (wh >> 16);  // n = tiles_touched
+  const uint32_t org = i < P ? g.dval[fin ^ 1u][i] : 0u;
   uint32_t total;
   const uint32_t boff = g.block_offs[blockIdx.x];
   const uint32_t off = block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
-  uint32_t org = 0, w = 1;
-  if (n != 0) {
-    const uint2 rc = g.rect[idx];  // the only gather: the rectangle K1 binned the Gaussian into (n == width * height)
-    org = (rc.x >> 16) * (uint32_t)gx + (rc.x & 0xffffu);  // tile id of the rectangle's first tile
-    w = rc.y & 0xffffu;
-  }
   s_off[threadIdx.x] = off;
   s_idx[threadIdx.x] = idx;
   s_org[threadIdx.x] = org;

@@ -218,7 +218,7 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   for (uint32_t d = total ? (kmax ^ kmin) : 0u; d; d >>= 1) ++nbits;
   const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
   if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
-  GSR_HIP(launch_depth_finish(s, P, a.g, passes));
+  GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx));
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
   *num_rendered_host = (int64_t)total;
   return GSR_OK;

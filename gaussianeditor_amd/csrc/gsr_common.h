@@ -31,7 +31,7 @@ struct Geom {
   float4* rec0;
   float4* rec1;
   float4* rec2;
-  uint2* rect;           // (P)     tile rectangle of a binned Gaussian: x = minx | miny << 16, y = width | height << 16
+  uint2* rect;           // (P)     tile rectangle, written for every Gaussian: x = minx | miny << 16, y = width | height << 16 (0 if culled)
   uint32_t* tiles;       // (P)     tiles_touched
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
   uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order

@@ -116,7 +116,7 @@ hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2
                               float* conic_opacity, uint8_t* clamped);
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst = nullptr,
                                uint32_t publish_seq = 0);
-hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes);
+hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx);
 hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys);
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
                           const Binning& b, const Image& im);

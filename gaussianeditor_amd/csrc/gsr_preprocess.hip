@@ -173,6 +173,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
     const float* proj = cam.proj;
     int my_radius_i = 0;
     float my_depth = 0.f;
+    uint2 my_rect = make_uint2(0u, 0u);  // tile rectangle (origin, width | height << 16); width * height == tiles_touched
     do {
       const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       // in_frustum, auxiliary.h:139-164: only the near test survives
@@ -266,7 +267,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
           ntiles = (maxx > minx && maxy > miny) ? (maxx - minx) * (maxy - miny) : 0u;
         }
       }
-      if (ntiles != 0) a.g.rect[idx] = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
+      if (ntiles != 0) my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
 
       // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
     } while (false);
     a.radii[idx] = my_radius_i;
     a.g.tiles[idx] = my_tiles;
+    a.g.rect[idx] = my_tiles ? my_rect : make_uint2(0u, 0u);  // written for every Gaussian: the binning reads nothing else of it
     // key of the depth ordering (gsr_binning.hip): depth bits, culled Gaussians after every live one
     a.g.dkey[0][idx] = my_tiles ? __float_as_uint(my_depth) : 0xffffffffu;
     if (my_tiles) {
