@@ -484,7 +484,7 @@ constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
 // cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
 // 2-3 of a tile's 4 quadrants.
 template <int ABLATE, bool FAST>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
-__device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
+__device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
                                               float4 (*s2)[WAVE], uint32_t* sid, float4* sco, float (*sacc)[WAVE],
                                               uint32_t* s_maxc) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
@@ -515,7 +515,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
   __syncthreads();
   const uint32_t tile_max = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
   __syncthreads();
-  if (tile_max == 0) return;  // uniform over the workgroup
+  if (tile_max == 0) return 0u;  // uniform over the workgroup
 
   float dpx[3] = {0.f, 0.f, 0.f};
   if (live) {
@@ -697,6 +697,7 @@ __device__ __forceinline__ void backward_tile(const BlendArgs& a, uint32_t tile,
       }
     }
   }
+  return tile_max;
 }
 
 template <int ABLATE, bool FAST>
@@ -720,9 +721,19 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
+    const uint32_t tmax = backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
     if (prof) {
       const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
+      if (a.profile_items != nullptr && threadIdx.x == 0 && a.work_est != nullptr) {
+        // per item: cycles, the forward's per-quadrant counts of the tile, positions walked, item code
+        const uint32_t tt = tile & BWD_ITEM_TILE;
+        uint64_t* r = a.profile_items + ((size_t)tt * 2 + ((tile & BWD_ITEM_PART) ? 1 : 0)) * 4;
+        const uint4 e = reinterpret_cast<const uint4*>(a.work_est)[tt];
+        r[0] = d;
+        r[1] = ((uint64_t)e.x) | ((uint64_t)e.y << 16) | ((uint64_t)e.z << 32) | ((uint64_t)e.w << 48);
+        r[2] = tmax;
+        r[3] = tile;
+      }
       if (ntiles == 0) first = d;
       longest = d > longest ? d : longest;
       ntiles++;

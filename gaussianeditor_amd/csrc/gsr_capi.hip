@@ -371,7 +371,12 @@ int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int 
   a.dL_dopacity = dL_dopacity;
   a.dL_dcolors = dL_dcolors;
   a.profile = records;
-  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 8 * (size_t)n, (hipStream_t)stream));
+  // optional extension: with room for T more records, 4 x u64 per (tile, half) follow the workgroup records:
+  // {cycles, the forward's four per-quadrant counts (16 bits each), positions the backward walked, item code}
+  const int64_t T = (int64_t)a.gx * a.gy;
+  const bool items = max_records >= n + T;
+  a.profile_items = items ? records + 8 * n : nullptr;
+  GSR_HIP(hipMemsetAsync(records, 0, sizeof(uint64_t) * 8 * (size_t)(items ? n + T : n), (hipStream_t)stream));
   GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
   return GSR_OK;
 }

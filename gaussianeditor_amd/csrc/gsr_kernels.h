@@ -91,6 +91,7 @@ struct BlendArgs {
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
   // debug: per-workgroup timing records (4 x u64 each), or null
+  uint64_t* profile_items;  // debug (backward): 4 x u64 per (tile, half) after the workgroup records, or null
   uint64_t* profile;
 };
 
