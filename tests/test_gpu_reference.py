@@ -130,27 +130,45 @@ def test_product_vs_reference_nofma_integers():
     assert np.array_equal(st["ranges"], _np(r["ranges"]).view(np.uint32))
 
 
-def test_apply_weights_vs_reference():
+@pytest.mark.parametrize("P,W,H,s0,C,big", [(6000, 256, 256, 0.04, 1, False), (20000, 512, 512, 0.02, 3, False),
+                                            (20000, 512, 512, 0.02, 2, False), (1_000_000, 1920, 1088, 0.01, 1, True)])
+def test_apply_weights_vs_reference(oracle, P, W, H, s0, C, big):
+    """K11+K12 against the reference's own apply_weights.cu (contraction-free build), C = 1, 2, 3 and at the headline size
+    (1088 rows: the reference reads image_weights out of bounds unless both sides are multiples of 16).  `cnt` is an
+    integer per Gaussian: it must be IDENTICAL except for the Gaussians blended at a pixel whose threshold decision
+    differs between libm's exp (reference) and gsr_expf (here) -- those pixels are found by comparing the two forward
+    renders' n_contrib / final_T, counted and bounded; the float weights agree to the atomics' re-association."""
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+    from test_gpu_round2 import _flipped_pixels, _gaussians_under
 
-    P, W, H = 6000, 256, 256  # multiples of 16: the reference reads image_weights out of bounds otherwise
-    case = make_case(P, W, H, seed=11, s0=0.04)
+    case = make_case(P, W, H, seed=11 if not big else 0, s0=s0, view=0, nviews=8 if big else 4,
+                     bg=(0.0, 0.0, 0.0))
     sc, cam = case["sc"], case["cam"]
-    mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(12)) > 0.5).float()
-    w_ref = torch.zeros((P, 1), device=DEV)
+    mask = (torch.rand(C, H, W, generator=torch.Generator().manual_seed(12)) > 0.5).float()  # 0 / 1: exact sums
+    R_ = _ref("nofma")
+    w_ref = torch.zeros((P, C), device=DEV)
     c_ref = torch.zeros((P,), dtype=torch.int32, device=DEV)
-    _ref("nofma").apply_weights(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], cam.world_view_transform,
-                                cam.full_proj_transform, cam.camera_center, W, H, case["tfx"], case["tfy"], mask, w_ref, c_ref)
-    w = torch.zeros((P, 1), device=DEV)
+    R_.apply_weights(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], cam.world_view_transform,
+                     cam.full_proj_transform, cam.camera_center, W, H, case["tfx"], case["tfy"], mask, w_ref, c_ref)
+    w = torch.zeros((P, C), device=DEV)
     cnt = torch.zeros((P, 1), dtype=torch.int32, device=DEV)
     GaussianRasterizer(settings(case, DEV, D=0)).apply_weights(sc["xyz"].to(DEV), None, sc["opacity"].to(DEV), None, w,
                                                              sc["scaling"].to(DEV), sc["rotation"].to(DEV), None, cnt,
                                                              mask.to(DEV))
     torch.cuda.synchronize()
-    mism = float((cnt.reshape(-1) != c_ref).float().mean())
-    print("cnt mismatch fraction vs reference", mism, "total", int(c_ref.sum()))
-    assert mism < 2e-3 and abs(int(cnt.sum()) - int(c_ref.sum())) <= 1e-4 * int(c_ref.sum()) + 8
-    assert float((w - w_ref).abs().max()) <= 2.0
+    # where may the two differ at all?  pixels whose blend decisions flip between the two exps
+    r = _ref_forward(_ref("nofma"), case)
+    f = oracle_forward(oracle, case)
+    flips = _flipped_pixels(_np(r["n_contrib"]).view(np.uint32), _np(r["final_T"]), f["n_contrib"], f["final_T"])
+    masked = _gaussians_under(flips, W, f, _np(r["n_contrib"]).view(np.uint32))
+    diff = _np(cnt).reshape(-1) != _np(c_ref)
+    print(f"[{P} @ {W}x{H}, C={C}] flipped pixels {flips.size}, Gaussians under them {int(masked.sum())}; cnt differs on "
+          f"{int(diff.sum())} Gaussians ({int((diff & ~masked).sum())} outside them); total {int(c_ref.sum())}")
+    assert flips.size <= 4 + 2e-4 * W * H
+    assert not (diff & ~masked).any()
+    assert np.abs(_np(cnt).reshape(-1).astype(np.int64) - _np(c_ref).astype(np.int64))[masked].max(initial=0) <= 4 * C
+    dw = (w - w_ref).abs().cpu().numpy()
+    assert dw[~masked].max(initial=0.0) <= 1e-5 * max(1.0, float(w_ref.abs().max()))
 
 
 @pytest.mark.parametrize("P,kind", [(5000, "uniform"), (200000, "uniform"), (100000, "clustered")])
