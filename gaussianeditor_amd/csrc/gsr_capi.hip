@@ -4,6 +4,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 
 
@@ -190,18 +191,20 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
   GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
   // Poll the generation word (an event would put a barrier packet into the stream -- a 6 us bubble -- and sleeping on
-  // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED: after ~2 ms (earlier work
-  // is still queued on the stream, or a launch failed) the thread stops burning a core and blocks in
+  // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED in time: after 5 ms (a long
+  // queue of earlier work on the stream, or a failed launch) the thread stops burning a core and blocks in
   // hipStreamSynchronize, which also surfaces any launch error; the word is then either there or the call fails.
   {
     volatile const uint32_t* flag = slot->words + GEOM_HDR_FINAL;
     bool seen = false;
-    for (uint32_t spin = 0; spin < (1u << 20); ++spin) {
+    const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+    for (uint32_t spin = 1;; ++spin) {
       if (*flag == seq) {
         seen = true;
         break;
       }
       __builtin_ia32_pause();
+      if ((spin & 0x3ffu) == 0 && std::chrono::steady_clock::now() >= give_up) break;
     }
     if (!seen) {
       GSR_HIP(hipStreamSynchronize(s));
