@@ -162,6 +162,9 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
 }
 
 constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
+#ifndef GSR_FWD_SELECT_CHAIN
+#define GSR_FWD_SELECT_CHAIN 1  // 0: the masked (exec-region) serial part for every chunk (A/B builds)
+#endif
 
 // Sums each of four per-lane values over the 64 lanes of the wave, 10 instructions for all four
 // instead of 4 x 6: two v_permlane32_swap + adds fold the half-waves (a,c | b,d), one
@@ -201,30 +204,39 @@ struct Entry {
   float4 r0, r1, r2;
 };
 
-// Can the alpha >= 1/255 level set of an entry reach the pixel box [qx0, qx0 + qw] x [qy0, qy0 + qh]?  Conservative:
-// `false` only if every pixel of the box would take `alpha < 1/255 -> continue` (forward.cu:340-344) anyway.
-// The test bounds the level set {d : d^T Q d <= tau2}, tau2 = 2 ln(255 o), by its axis-aligned box with half extents
-// sqrt(tau2 Q_zz / det Q), sqrt(tau2 Q_xx / det Q).  det Q = Q_xx Q_zz - Q_xy^2 cancels for a needle that is not axis
-// aligned: its binary32 value is off by up to ~2e-7 Q_xx Q_zz, and the blend loops' own evaluation of the quadratic form
-// then carries rounding errors of the same relative size against terms that are 1/rho times larger than the result
-// (rho = det Q / (Q_xx Q_zz)).  So the box is trusted only for rho >= 1e-3, where both effects stay below the margins
-// applied here (extents^2 x 1.001 for det, tau2 x 1.001 + 0.02 for the evaluated exponent); worse-conditioned entries
-// are never culled (tools/cull_replay.py replays this arithmetic against the reference's per-pixel evaluation).
+// Can the alpha >= 1/255 level set of an entry reach the pixel rectangle [qx0, qx0 + qw] x [qy0, qy0 + qh]?  Conservative:
+// `false` only if every pixel of the rectangle would take `alpha < 1/255 -> continue` (forward.cu:340-344) anyway.
+// The level set is the ellipse {d : d^T Q d <= tau2}, tau2 = 2 ln(255 o), d = pixel - mean.  The test is exact up to its
+// margins: the minimum of the convex form d^T Q d over the rectangle is attained on one of the two sides that face the
+// mean (or is 0 when the mean lies inside), so with (cx, cy) the mean clamped into the rectangle it is
+//     min( min_x q(x, cy), min_y q(cx, y) ),   min_x q(x, cy) at x = clamp(-Q_xy cy / Q_xx)  (and likewise for y).
+// A misplaced minimiser only makes the value larger by a second-order amount.  (Round 1/2 bounded the ellipse by its
+// axis-aligned box instead; on the headline scene 14 % of the (quadrant, entry) pairs that passed that box are rejected
+// here, tools/cull_study.py, and each rejected pair saves ~40 wave instructions in the forward and ~90 in the backward.)
+// Rounding: det Q = Q_xx Q_zz - Q_xy^2 cancels for a needle that is not axis aligned, and both this function's and the
+// blend loops' evaluation of the form carry errors of relative size ~1e-7 against terms that are up to 2/rho times larger
+// than the result (rho = det Q / (Q_xx Q_zz)).  So the test is trusted only for rho >= 1e-3, where these stay below the
+// margins applied (tau2 x 1.001 + 0.02 for the exponent the loops evaluate, x 1.001 again for the value computed here,
+// the rectangle widened by 0.01 pixel); worse-conditioned entries are never culled (tools/cull_replay.py replays this
+// arithmetic in binary32 against the reference's per-pixel evaluation).
 __device__ __forceinline__ bool can_touch_quad(const float4& r0, const float4& r1, float qx0, float qy0,
                                                float qw = (float)(QUAD - 1), float qh = (float)(QUAD - 1)) {
   // r0 = conic.x, conic.y, conic.z, opacity; r1 = mean.x, mean.y, depth, radius
   const float o = r0.w;
   if (!(o >= 1.0f / 255.0f)) return !(o == o) ? true : false;  // o < 1/255: alpha < 1/255 everywhere (NaN: keep)
-  const float xz = r0.x * r0.z;
-  const float det = xz - r0.y * r0.y;
-  if (!(det >= 1e-3f * xz) || !(det > 0.0f)) return true;  // ill-conditioned / degenerate / NaN conic: never cull
-  const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f);
-  const float inv = __builtin_amdgcn_rcpf(det) * 1.001f;
-  const float hx = __builtin_sqrtf(tau2 * r0.z * inv) + 0.01f;
-  const float hy = __builtin_sqrtf(tau2 * r0.x * inv) + 0.01f;
-  if (!(hx == hx) || !(hy == hy)) return true;
-  const bool out = (r1.x + hx < qx0) || (r1.x - hx > qx0 + qw) || (r1.y + hy < qy0) || (r1.y - hy > qy0 + qh);
-  return !out;
+  const float A = r0.x, B = r0.y, C = r0.z;
+  const float xz = A * C;
+  const float det = xz - B * B;
+  if (!(det >= 1e-3f * xz) || !(det > 0.0f) || !(A > 0.0f)) return true;  // ill-conditioned / degenerate / NaN: never cull
+  const float tau2 = 2.0f * (__logf(255.0f * o) * 1.001f + 0.01f) * 1.001f;
+  const float xl = (qx0 - 0.01f) - r1.x, xh = (qx0 + qw + 0.01f) - r1.x;
+  const float yl = (qy0 - 0.01f) - r1.y, yh = (qy0 + qh + 0.01f) - r1.y;
+  const float cx = __builtin_amdgcn_fmed3f(0.0f, xl, xh), cy = __builtin_amdgcn_fmed3f(0.0f, yl, yh);
+  const float x1 = __builtin_amdgcn_fmed3f(-(B * cy) * __builtin_amdgcn_rcpf(A), xl, xh);
+  const float y2 = __builtin_amdgcn_fmed3f(-(B * cx) * __builtin_amdgcn_rcpf(C), yl, yh);
+  const float q1 = (A * x1) * x1 + ((2.0f * B) * x1) * cy + (C * cy) * cy;
+  const float q2 = (A * cx) * cx + ((2.0f * B) * cx) * y2 + (C * y2) * y2;
+  return !(q1 > tau2) || !(q2 > tau2);  // culled only if both candidates are outside (NaN anywhere: keep)
 }
 
 // exp(power) of the blend loops: the exactly specified polynomial (bit-identical to the CPU oracle), or -- per-call
@@ -234,6 +246,24 @@ template <bool FAST>
 __device__ __forceinline__ float blend_exp(float power) {
   if (FAST) return __builtin_amdgcn_exp2f(power * 0x1.715476p+0f);
   return gsr_expf_noclamp(power);
+}
+
+// The same for two entries at once (packed binary32: v_pk_mul / v_pk_add / v_pk_fma_f32 round each half exactly as the
+// scalar instructions do; v_rndne, v_cvt and v_ldexp have no packed form and run per half).
+template <bool FAST>
+__device__ __forceinline__ f32x2 blend_exp2(f32x2 power) {
+  const f32x2 t = power * f32x2{0x1.715476p+0f, 0x1.715476p+0f};
+  if (FAST) return f32x2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  const f32x2 n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  const f32x2 f = t - n;
+  f32x2 p = {0x1.44138ap-13f, 0x1.44138ap-13f};
+  p = __builtin_elementwise_fma(p, f, f32x2{0x1.5f0890p-10f, 0x1.5f0890p-10f});
+  p = __builtin_elementwise_fma(p, f, f32x2{0x1.3b2a54p-7f, 0x1.3b2a54p-7f});
+  p = __builtin_elementwise_fma(p, f, f32x2{0x1.c6af6cp-5f, 0x1.c6af6cp-5f});
+  p = __builtin_elementwise_fma(p, f, f32x2{0x1.ebfbe0p-3f, 0x1.ebfbe0p-3f});
+  p = __builtin_elementwise_fma(p, f, f32x2{0x1.62e430p-1f, 0x1.62e430p-1f});
+  p = __builtin_elementwise_fma(p, f, f32x2{1.0f, 1.0f});
+  return f32x2{__builtin_amdgcn_ldexpf(p.x, (int)n.x), __builtin_amdgcn_ldexpf(p.y, (int)n.y)};
 }
 
 // Walks list positions in chunks.  FORWARD: positions [0,len) ascending, lane l of chunk c holds
@@ -307,12 +337,35 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   const float pfx = (float)pw.px, pfy = (float)pw.py;
   const float qx0 = box.qx0, qy0 = box.qy0, qw = box.qw, qh = box.qh;
   bool done = !pw.inside;
-  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f;
+  float T = 1.0f;
   uint32_t last_contributor = 0;
   uint32_t evaluated = 0;  // entries this quadrant evaluated (wave-uniform): the backward's work estimate for the tile
 
-  __shared__ float4 s0[WAVE], s1[WAVE], s2[WAVE];
+  // Staging layout: the survivors of a chunk are stored in PAIRS, the two entries' values of each footprint input next
+  // to each other, so that one uniform ds_read_b128 puts them into adjacent registers and the footprint arithmetic of
+  // two entries runs as packed binary32 instructions (v_pk_add / v_pk_mul / v_pk_fma_f32: two IEEE operations per lane
+  // and issue slot, the same roundings as the scalar forms).  A wave issues at most one instruction every four cycles,
+  // and the forward ends with its longest item, so the instruction count of an entry is what the kernel's length follows.
+  //   pair p (entries 2p, 2p+1), FWD_PAIR floats: [0] hA0 hA1 nB0 nB1 | [4] hC0 hC1 op0 op1 | [8] x0 x1 y0 y1 |
+  //                                               [12] r0 g0 b0 z0 | [16] r1 g1 b1 z1 | [20] pos0 pos1 - -
+  constexpr int FWD_PAIR = 24;
+  constexpr bool SELECT_CHAIN = GSR_FWD_SELECT_CHAIN != 0;
+  __shared__ __attribute__((aligned(16))) float sp[(WAVE / 2) * FWD_PAIR];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const f32x2 pfx2 = {pfx, pfx}, pfy2 = {pfy, pfy};
+  f32x2 C01 = {0.f, 0.f}, C2D = {0.f, 0.f};  // (C0, C1), (C2, D)
+  auto stage = [&](uint32_t slot, float hA, float nB, float hC, float op, float x, float y, float z, float r, float g,
+                   float b, float pos) {
+    float* q = sp + (slot >> 1) * FWD_PAIR + (slot & 1u);
+    q[0] = hA;
+    q[2] = nB;
+    q[4] = hC;
+    q[6] = op;
+    q[8] = x;
+    q[10] = y;
+    q[20] = pos;
+    *reinterpret_cast<float4*>(sp + (slot >> 1) * FWD_PAIR + 12 + 4 * (slot & 1u)) = make_float4(r, g, b, z);
+  };
   if (range.y > range.x) {
     ChunkWalker<true, AUX> walk(a, range.x, range.y - range.x);
     for (; walk.valid(); walk.advance()) {
@@ -329,18 +382,16 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       const uint32_t cnt = (uint32_t)__popcll(m);
       const uint32_t cnt4 = (cnt + GROUP - 1) & ~(uint32_t)(GROUP - 1);
       __syncthreads();
-      if (keep) {
-        const uint32_t slot = (uint32_t)__popcll(m & lt_mask);
-        s0[slot] = make_float4(-0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w);
-        s1[slot] = make_float4(walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, __uint_as_float(walk.lane_pos() + 1u));
-        s2[slot] = walk.cur.r2;
-      }
-      if ((uint32_t)lane >= cnt && (uint32_t)lane < cnt4) {
+      // a staged colour or depth that is NaN / Inf (0 * c would no longer be 0): this chunk takes the masked form
+      const float csum = (walk.cur.r2.x + walk.cur.r2.y) + (walk.cur.r2.z + walk.cur.r1.z);
+      const bool bad_value = keep && !(csum - csum == 0.0f);
+      if (keep)  // conic pre-scaled: (-0.5 A, -B, -0.5 C), exact
+        stage((uint32_t)__popcll(m & lt_mask), -0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w,
+              walk.cur.r1.x, walk.cur.r1.y, walk.cur.r1.z, walk.cur.r2.x, walk.cur.r2.y, walk.cur.r2.z,
+              __uint_as_float(walk.lane_pos() + 1u));
+      if ((uint32_t)lane >= cnt && (uint32_t)lane < cnt4)
         // null entries pad the survivors to a multiple of GROUP: opacity 0 => alpha 0 => never a hit
-        s0[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s1[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-        s2[lane] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+        stage((uint32_t)lane, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f);
       __syncthreads();
       // GROUP entries per iteration: the footprint / exp evaluations of a group are independent
       // straight-line code (ILP for a wave that is alone on its SIMD); only the short
@@ -350,47 +401,132 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
         tc1 = __builtin_amdgcn_s_memtime();
         prof_cyc[0] += tc1 - tc0;  // chunk start -> staged
       }
-      for (uint32_t j = 0; j < cnt4; j += GROUP) {
-        if (__all(done)) break;
-        evaluated += GROUP;
-        if (PROFILE) prof_visited += GROUP;
-        float al[GROUP];
-        bool ok[GROUP];
-        float4 gg[GROUP], cc[GROUP];
+      if (SELECT_CHAIN && !__any(bad_value)) {
+        // Fast path (every staged colour / depth of the chunk is finite): the serial part runs on selects only, in one
+        // basic block without a single scalar instruction.  A wave issues one instruction about every 4.7 cycles whatever
+        // its type, and a v_cmp -> SALU -> exec -> VALU turn costs ~40 cycles against ~13 for v_mul -> v_cmp -> v_cndmask
+        // (tools/microbench/issue_rate.hip), so the length of the longest item follows the instruction count and the
+        // number of such turns.  State: Ts = T for a live lane, -T for one that is done (out of the image, or saturated).
+        //   entry skipped for this pixel (power > 0 or alpha < 1/255): alpha := 0, so 1 - alpha = 1, test_T = T exactly,
+        //     w = 0 and the accumulators take c * 0 = 0 (c finite);
+        //   T (1 - alpha) < 0.0001: A is false, w := 0, Ts := -T (final_T stays the T before this entry, forward.cu:349-354);
+        //   lane done: test_T <= 0 < 0.0001, A false, nothing changes.
+        // Same operations and roundings as the masked form below wherever a value is kept.
+        float Ts = done ? -T : T;
+        for (uint32_t j = 0; j < cnt4; j += GROUP) {
+          if (__all(Ts < 0.0f)) break;
+          evaluated += GROUP;
+          if (PROFILE) prof_visited += GROUP;
+          float ae[GROUP], om[GROUP], posf[GROUP];
+          f32x2 rg[GROUP], bz[GROUP];
 #pragma unroll
-        for (int u = 0; u < GROUP; ++u) {
-          gg[u] = s1[j + u];
-          const float4 co = s0[j + u];
-          cc[u] = s2[j + u];
-          const float dx = gg[u].x - pfx, dy = gg[u].y - pfy;
-          const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
-          al[u] = fminf(0.99f, co.w * blend_exp<FAST>(power));
-          ok[u] = !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
+          for (int pp = 0; pp < GROUP / 2; ++pp) {
+            const float* q = sp + ((j >> 1) + pp) * FWD_PAIR;
+            const float4 q0 = *reinterpret_cast<const float4*>(q), q1 = *reinterpret_cast<const float4*>(q + 4),
+                         q2 = *reinterpret_cast<const float4*>(q + 8), c0 = *reinterpret_cast<const float4*>(q + 12),
+                         c1 = *reinterpret_cast<const float4*>(q + 16);
+            const float2 ps = *reinterpret_cast<const float2*>(q + 20);
+            const f32x2 hA = {q0.x, q0.y}, nB = {q0.z, q0.w}, hC = {q1.x, q1.y}, op = {q1.z, q1.w};
+            const f32x2 dx = f32x2{q2.x, q2.y} - pfx2, dy = f32x2{q2.z, q2.w} - pfy2;
+            const f32x2 a_ = (hA * dx) * dx;
+            const f32x2 s_ = __builtin_elementwise_fma(hC * dy, dy, a_);
+            const f32x2 power = __builtin_elementwise_fma(nB * dx, dy, s_);
+            const f32x2 ao = op * blend_exp2<FAST>(power);
+            const float a0 = fminf(0.99f, ao.x), a1 = fminf(0.99f, ao.y);
+            const float g0 = (power.x > 0.0f) ? 0.0f : a0, g1 = (power.y > 0.0f) ? 0.0f : a1;
+            const f32x2 a2 = {(g0 < 1.0f / 255.0f) ? 0.0f : g0, (g1 < 1.0f / 255.0f) ? 0.0f : g1};
+            const f32x2 o2 = f32x2{1.0f, 1.0f} - a2;
+            ae[2 * pp] = a2.x;
+            ae[2 * pp + 1] = a2.y;
+            om[2 * pp] = o2.x;
+            om[2 * pp + 1] = o2.y;
+            rg[2 * pp] = f32x2{c0.x, c0.y};
+            bz[2 * pp] = f32x2{c0.z, c0.w};
+            rg[2 * pp + 1] = f32x2{c1.x, c1.y};
+            bz[2 * pp + 1] = f32x2{c1.z, c1.w};
+            posf[2 * pp] = ps.x;
+            posf[2 * pp + 1] = ps.y;
+          }
+#pragma unroll
+          for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(ae[u]), "+v"(om[u]));
+#pragma unroll
+          for (int u = 0; u < GROUP; ++u) {
+            const float test_T = Ts * om[u];
+            const bool A = !(test_T < 0.0001f);
+            const float w = ae[u] * Ts;
+            const float wz = A ? w : 0.0f;
+            const f32x2 w2 = {wz, wz};
+            C01 = __builtin_elementwise_fma(rg[u], w2, C01);
+            C2D = __builtin_elementwise_fma(bz[u], w2, C2D);
+            Ts = A ? test_T : -__builtin_fabsf(Ts);
+            last_contributor = (wz > 0.0f) ? __float_as_uint(posf[u]) : last_contributor;
+          }
         }
-        // pin the four footprints ahead of the serial part: otherwise the optimiser sinks each one into the masked
-        // region that consumes it and the independent exp chains no longer overlap (forward blend -2 %)
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(al[u]));
-#pragma unroll
-        for (int u = 0; u < GROUP; ++u) {
-          const bool hit = ok[u] && !done;
-          const float test_T = T * (1.0f - al[u]);
-          const bool term = hit && (test_T < 0.0001f);
-          done = done || term;
-          if (hit && !term) {  // kept as a lane-masked region: 6 instructions under exec instead of 10 selects
-            const float w = al[u] * T;
-            C0 = __builtin_fmaf(cc[u].x, w, C0);
-            C1 = __builtin_fmaf(cc[u].y, w, C1);
-            C2 = __builtin_fmaf(cc[u].z, w, C2);
-            D = __builtin_fmaf(gg[u].z, w, D);
-            T = test_T;
-            last_contributor = __float_as_uint(gg[u].w);
+        done = Ts < 0.0f;
+        T = __builtin_fabsf(Ts);
+      } else {
+        for (uint32_t j = 0; j < cnt4; j += GROUP) {
+          if (__all(done)) break;
+          evaluated += GROUP;
+          if (PROFILE) prof_visited += GROUP;
+          float al[GROUP], om[GROUP], posf[GROUP];
+          bool ok[GROUP];
+          f32x2 rg[GROUP], bz[GROUP];
+  #pragma unroll
+          for (int pp = 0; pp < GROUP / 2; ++pp) {
+            const float* q = sp + ((j >> 1) + pp) * FWD_PAIR;
+            const float4 q0 = *reinterpret_cast<const float4*>(q), q1 = *reinterpret_cast<const float4*>(q + 4),
+                         q2 = *reinterpret_cast<const float4*>(q + 8), c0 = *reinterpret_cast<const float4*>(q + 12),
+                         c1 = *reinterpret_cast<const float4*>(q + 16);
+            const float2 ps = *reinterpret_cast<const float2*>(q + 20);
+            const f32x2 hA = {q0.x, q0.y}, nB = {q0.z, q0.w}, hC = {q1.x, q1.y}, op = {q1.z, q1.w};
+            const f32x2 dx = f32x2{q2.x, q2.y} - pfx2, dy = f32x2{q2.z, q2.w} - pfy2;
+            // blend_power_prescaled on both entries
+            const f32x2 a_ = (hA * dx) * dx;
+            const f32x2 s_ = __builtin_elementwise_fma(hC * dy, dy, a_);
+            const f32x2 power = __builtin_elementwise_fma(nB * dx, dy, s_);
+            const f32x2 e = blend_exp2<FAST>(power);
+            const f32x2 ao = op * e;
+            const f32x2 a2 = {fminf(0.99f, ao.x), fminf(0.99f, ao.y)};
+            const f32x2 o2 = f32x2{1.0f, 1.0f} - a2;
+            al[2 * pp] = a2.x;
+            al[2 * pp + 1] = a2.y;
+            om[2 * pp] = o2.x;
+            om[2 * pp + 1] = o2.y;
+            ok[2 * pp] = !(power.x > 0.0f) && !(a2.x < 1.0f / 255.0f);
+            ok[2 * pp + 1] = !(power.y > 0.0f) && !(a2.y < 1.0f / 255.0f);
+            rg[2 * pp] = f32x2{c0.x, c0.y};
+            bz[2 * pp] = f32x2{c0.z, c0.w};
+            rg[2 * pp + 1] = f32x2{c1.x, c1.y};
+            bz[2 * pp + 1] = f32x2{c1.z, c1.w};
+            posf[2 * pp] = ps.x;
+            posf[2 * pp + 1] = ps.y;
+          }
+          // pin the four footprints ahead of the serial part: otherwise the optimiser sinks each one into the masked
+          // region that consumes it and the independent exp chains no longer overlap (forward blend -2 %)
+  #pragma unroll
+          for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(al[u]), "+v"(om[u]));
+  #pragma unroll
+          for (int u = 0; u < GROUP; ++u) {
+            const bool hit = ok[u] && !done;
+            const float test_T = T * om[u];
+            const bool term = hit && (test_T < 0.0001f);
+            done = done || term;
+            if (hit && !term) {  // kept as a lane-masked region: fewer instructions under exec than selects
+              const float w = al[u] * T;
+              const f32x2 w2 = {w, w};
+              C01 = __builtin_elementwise_fma(rg[u], w2, C01);
+              C2D = __builtin_elementwise_fma(bz[u], w2, C2D);
+              T = test_T;
+              last_contributor = __float_as_uint(posf[u]);
+            }
           }
         }
       }
       if (PROFILE) prof_cyc[1] += __builtin_amdgcn_s_memtime() - tc1;  // group loop
     }
   }
+  const float C0 = C01.x, C1 = C01.y, C2 = C2D.x, D = C2D.y;
   // (the sub-items of a cut quadrant report the largest of their counts: they walk the same list)
   if (a.work_est != nullptr && lane == 0) atomicMax(&a.work_est[4u * tile + quad], evaluated);
   if (pw.inside) {
@@ -407,7 +543,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
 }
 
 template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
-__global__ void __launch_bounds__(WAVE) blend_forward_kernel(const BlendArgs a) {
+__global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
   uint64_t prof_cyc[4] = {0, 0, 0, 0};
@@ -954,7 +1090,12 @@ static unsigned grid_for(const char* specific) {
   return (unsigned)cus * 4u * (unsigned)per_simd;
 }
 unsigned blend_grid_size(bool backward) {
-  static const unsigned fwd = grid_for("GSR_FWD_WAVES_PER_SIMD"), bwd = grid_for(nullptr);
+  // (GSR_FWD_GRID: development knob, any number of persistent forward waves -- tools/microbench, profiles/r02_e)
+  static const unsigned fwd = [] {
+    const char* e = getenv("GSR_FWD_GRID");
+    return e && atoi(e) > 0 ? (unsigned)atoi(e) : grid_for("GSR_FWD_WAVES_PER_SIMD");
+  }();
+  static const unsigned bwd = grid_for(nullptr);
   return backward ? bwd : fwd;
 }
 // Placement units of a launch with `waves_per_wg`-wave workgroups (see first_item_of_block): SIMDs or CUs; 0 turns the

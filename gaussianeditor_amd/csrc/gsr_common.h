@@ -182,6 +182,9 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, i
 // every float op below is one IEEE binary32 operation unless fmaf is spelled out.
 // ----------------------------------------------------------------------------------
 
+// two binary32 values in one 64-bit register pair: the operand type of the packed instructions v_pk_{add,mul,fma}_f32
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // The exactly specified exponential (see oracle/gsr_oracle.cpp and DESIGN.md section 4):
 // exp(x) = 2^n p(f), t = max(x log2 e, -125), n = rint(t), f = t - n, p = degree-6
 // Horner polynomial in fmaf.  9 full-rate VALU ops + v_rndne + v_cvt + v_ldexp; no

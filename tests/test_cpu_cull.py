@@ -25,3 +25,13 @@ def test_kernel_source_uses_the_replayed_rule():
     for f in ("gsr_blend.hip", "gsr_preprocess.hip"):
         src = open(os.path.join(ROOT, "gaussianeditor_amd", "csrc", f)).read()
         assert "1e-3f * xz" in src and "* 1.001f" in src, f
+
+
+def test_ellipse_rectangle_cull_is_conservative():
+    """can_touch_quad's exact ellipse-against-rectangle test (round 2), replayed in binary32: no (Gaussian, rectangle) pair
+    it culls contains a pixel the reference would blend."""
+    import cull_replay
+
+    culled, fails, worst, kept = cull_replay.replay_rect(600, seed=2, rects_per=30)
+    assert culled > 2000 and kept > 2000
+    assert fails == 0, (fails, worst)
