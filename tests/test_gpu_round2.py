@@ -503,3 +503,38 @@ def test_images_beyond_65535_tiles_use_wide_tile_keys(oracle):
         g = oracle_backward(oracle, case, f, G)
         for k in GRADS:
             assert rel_err(gp[k], g[k].reshape(gp[k].shape)) <= 1e-5, k
+
+
+def test_forward_select_and_masked_chunks_mix_bit_exactly(oracle):
+    """Round 2, forward blend: chunks whose staged colours / depths are all finite run the select-only serial part, a chunk
+    holding a NaN / Inf / overflowing colour runs the masked one, and a quadrant's per-pixel state crosses between the two
+    from chunk to chunk.  A deep scene (lists of several chunks per tile) with a sprinkle of such colours must reproduce
+    the oracle: integer outputs and the set of non-finite pixels exactly, finite pixels to 1e-5 (they are bit-identical
+    in practice: same operations in the same order)."""
+    from test_gpu_parity import _run_hip_forward
+
+    case = make_case(20000, 256, 192, seed=23, s0=0.06)
+    P = 20000
+    gen = torch.Generator().manual_seed(5)
+    colors = torch.rand(P, 3, generator=gen)
+    pick = torch.randperm(P, generator=gen)
+    colors[pick[:60], 0] = float("nan")
+    colors[pick[60:120], 1] = float("inf")
+    colors[pick[120:180], 2] = -float("inf")
+    colors[pick[180:260]] = 3.0e38  # finite, but the chunk's screening sum overflows: masked form, finite result path
+    f = oracle_forward(oracle, case, colors_precomp=colors)
+    R, color, depth, radii, geom, binning, img = _run_hip_forward(case, colors_precomp=colors)
+    st = hip_state(P, R, 256, 192, geom, binning, img)
+    assert R == f["num_rendered"] and np.array_equal(st["n_contrib"], f["n_contrib"])
+    assert np.abs(st["final_T"] - f["final_T"]).max() <= 1e-6
+    col, ref = color.cpu().numpy(), f["color"]
+    bad = ~np.isfinite(ref)
+    assert np.array_equal(col[bad], ref[bad], equal_nan=True)  # the same NaN, +Inf and -Inf pixels
+    assert 0 < int(bad.sum()) < ref.size // 2  # the sprinkle reaches some pixels and leaves most alone
+    big = np.abs(ref) > 1e30
+    assert np.abs(col[~bad & ~big] - ref[~bad & ~big]).max() <= 1e-5 and rel_err(col[~bad & big], ref[~bad & big]) <= 1e-5
+    print("finite pixels bit-identical:", bool(np.array_equal(col[~bad], ref[~bad])))
+    assert rel_err(depth.cpu().numpy(), f["depth"]) <= 1e-5
+    # lists long enough that quadrants walk several chunks (otherwise the test would not cross between the two forms)
+    lens = (st["ranges"][:, 1] - st["ranges"][:, 0])
+    assert int(np.percentile(lens, 90)) > 3 * 64
