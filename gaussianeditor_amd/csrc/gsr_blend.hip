@@ -951,7 +951,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
-  const float qx0 = box.qx0, qy0 = box.qy0, qw = box.qw, qh = box.qh;
+  (void)box;  // (the cull rectangle follows the pixels that are still live, live_pixel_box)
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   float Cw[C];
 #pragma unroll
@@ -966,8 +966,10 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   ChunkWalker<true> walk(a, range.x, range.y - range.x);
   for (; walk.valid(); walk.advance()) {
-    if (__all(done)) break;
-    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, qx0, qy0, qw, qh);
+    const uint64_t live_m = __ballot(!done);
+    if (live_m == 0) break;
+    const LiveBox lb = live_pixel_box(live_m, pfx - (float)(lane & 7), pfy - (float)(lane >> 3));
+    const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, lb.x0, lb.y0, lb.w, lb.h);
     const uint64_t km = __ballot(keep);
     if (km == 0) continue;
     const uint32_t n = (uint32_t)__popcll(km);

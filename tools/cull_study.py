@@ -4,7 +4,12 @@ For a sample of tiles of synth-v1 (1 M Gaussians, 1080p, view 0) and each 8x8 qu
 (up to the quadrant's largest n_contrib), how many pass (a) the present box test (can_touch_quad), (b) an exact test of
 the alpha >= 1/255 ellipse against the quadrant's pixel-centre rectangle, (c) have a pixel that really blends them.
 
-    python tools/cull_study.py [P] [tiles_sampled]
+    python tools/cull_study.py [P] [tiles_sampled] [s0] [--live]
+
+--live adds the study behind `live_pixel_box` (gsr_blend.hip): for every quadrant item of the view, the entries the exact
+test keeps against the whole quadrant and against the bounding box of the pixels that are still live when a chunk starts
+(approximated by n_contrib: a pixel is live at least up to its last contributor), for the 300 items with the most
+evaluated entries, the 20 longest of those, and 600 random items; plus how well the list length predicts an item's work.
 """
 import math
 import os
@@ -17,9 +22,10 @@ sys.path.insert(0, ROOT)
 from gaussianeditor_amd.synth import ring_cameras, synth_scene  # noqa: E402
 from oracle import cpu as oracle  # noqa: E402
 
-P = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-NT = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-s0 = float(sys.argv[3]) if len(sys.argv) > 3 else 0.01
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+P = int(_pos[0]) if len(_pos) > 0 else 1_000_000
+NT = int(_pos[1]) if len(_pos) > 1 else 300
+s0 = float(_pos[2]) if len(_pos) > 2 else 0.01
 W, H = 1920, 1080
 sc = synth_scene(P, seed=0, s0=s0)
 cam = ring_cameras(8, W, H)[0]
@@ -92,3 +98,59 @@ print(f"P {P} s0 {s0}: tiles sampled {len(tiles)}, R {binning['num_rendered']}")
 print({k: v for k, v in tot.items()})
 print("passes box / walked %.3f; exact rectangle test / box %.3f; really blended by a pixel / box %.3f; lanes used per box pair %.1f of 64" % (
     tot["box"] / tot["walked"], tot["exact"] / tot["box"], tot["pixel"] / tot["box"], tot["pix_lanes"] / tot["box"]))
+
+
+def _exact_mask(g, x0, y0, w, h):
+    A, B, C, o = co[g, 0], co[g, 1], co[g, 2], co[g, 3]
+    mx, my = xy[g, 0], xy[g, 1]
+    tau2 = 2.0 * np.log(np.maximum(255.0 * o, 1e-30))
+    xl, xh, yl, yh = x0 - mx, x0 + w - mx, y0 - my, y0 + h - my
+    cx, cy = np.clip(0, xl, xh), np.clip(0, yl, yh)
+    x1, y2 = np.clip(-B * cy / A, xl, xh), np.clip(-B * cx / C, yl, yh)
+    q1 = A * x1 * x1 + 2 * B * x1 * cy + C * cy * cy
+    q2 = A * cx * cx + 2 * B * cx * y2 + C * y2 * y2
+    return (o >= 1.0 / 255.0) & (np.minimum(q1, q2) <= tau2)
+
+
+def _live_study():
+    items = []
+    for t in nonempty:
+        ty, tx = divmod(int(t), gx)
+        ids = binning["point_list"][ranges[t, 0]:ranges[t, 1]]
+        for q in range(4):
+            x0, y0 = tx * 16 + 8 * (q & 1), ty * 16 + 8 * (q >> 1)
+            if x0 >= W or y0 >= H:
+                continue
+            walked = int(ncontrib[y0:y0 + 8, x0:x0 + 8].max())
+            if walked:
+                items.append((int(_exact_mask(ids[:walked], x0, y0, 7, 7).sum()), int(t), q, walked, len(ids)))
+    items = np.array(items)
+    print("quadrant items %d; evaluated entries: total %d, mean %.0f, p90 %.0f, p99 %.0f, max %d" % (
+        len(items), items[:, 0].sum(), items[:, 0].mean(), np.percentile(items[:, 0], 90), np.percentile(items[:, 0], 99), items[:, 0].max()))
+    print("corr(evaluated, list length) %.3f; corr(evaluated, positions walked) %.3f" % (
+        np.corrcoef(items[:, 0], items[:, 4])[0, 1], np.corrcoef(items[:, 0], items[:, 3])[0, 1]))
+
+    def study(sel, label):
+        per = []
+        for (_v, t, q, _w, _l) in sel:
+            ty, tx = divmod(int(t), gx)
+            ids = binning["point_list"][ranges[t, 0]:ranges[t, 1]]
+            x0, y0 = tx * 16 + 8 * (int(q) & 1), ty * 16 + 8 * (int(q) >> 1)
+            nc = ncontrib[y0:y0 + 8, x0:x0 + 8].astype(np.int64)
+            full = live = 0
+            for c0 in range(0, int(nc.max()), 64):
+                g = ids[c0:min(c0 + 64, int(nc.max()))]
+                full += int(_exact_mask(g, x0, y0, 7, 7).sum())
+                ys, xs = np.nonzero(nc > c0)
+                live += int(_exact_mask(g, x0 + xs.min(), y0 + ys.min(), xs.max() - xs.min(), ys.max() - ys.min()).sum())
+            per.append((full, live))
+        per = np.array(per)
+        print("%s %d items: %d entries against the whole quadrant, %d against the live pixels' box (%.3f); the 20 longest: %.3f" % (
+            label, len(sel), per[:, 0].sum(), per[:, 1].sum(), per[:, 1].sum() / per[:, 0].sum(), per[:20, 1].sum() / per[:20, 0].sum()))
+
+    study(items[np.argsort(-items[:, 0])[:300]], "the 300 longest")
+    study(items[np.random.default_rng(1).choice(len(items), min(600, len(items)), replace=False)], "random")
+
+
+if "--live" in sys.argv:
+    _live_study()
