@@ -193,8 +193,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     grad_alloc = grad_allocator
     # "means2D+opacities": an allocator may hand back BOTH accumulators, already zeroed by ONE fill of the span that
     # holds them, as a pair (dL_dmeans2D (P,3), dL_dopacity (P,1))
-    joint = grad_alloc("means2D+opacities", (4 * P,), True) if grad_alloc is not None else None
-    if joint is not None:
+    # "accumulators": all four buffers the blend backward adds into -- dL_dmeans2D (P,3), dL_dopacity (P,1) and the internal
+    # dL_dconic (P,4), dL_dcolors (P,3) -- zeroed by ONE fill (an allocator that owns them contiguously)
+    four = grad_alloc("accumulators", (11 * P,), True) if grad_alloc is not None else None
+    joint = None if (four is not None or grad_alloc is None) else grad_alloc("means2D+opacities", (4 * P,), True)
+    if four is not None:
+        dL_dmeans2D, dL_dopacity, dL_dconic, dL_dcolors = four
+    elif joint is not None:
         dL_dmeans2D, dL_dopacity = joint
         rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4

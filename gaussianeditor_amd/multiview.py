@@ -54,8 +54,8 @@ class GradBucket:
     = (14 + 3M) * P floats (248 MB at P = 1M, M = 16), every segment START rounded up to a multiple of 4 floats:
     the kernels use dwordx4 accesses on (P,4) / (P,M,3) rows, so a segment must begin on a 16-byte boundary whatever
     P is (P is arbitrary after a densification or a prune; the padding words stay zero and travel with the all-reduce).
-    means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent so that one fill
-    clears both."""
+    means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent -- and followed, outside
+    the exchanged part, by the backward's two internal accumulators -- so that one fill clears all four."""
 
     def __init__(self, P: int, M: int, device, sh_exchange: str = "auto"):
         self.P, self.M = int(P), int(M)
@@ -72,7 +72,12 @@ class GradBucket:
         for name in slots:
             offs[name] = off
             off = _pad4(off + int(torch.Size(shapes[name]).numel()))
-        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        # Behind the exchanged part: 7 P floats for the backward's two INTERNAL accumulators (dL_dconic (P,4), dL_dcolors
+        # (P,3)).  They follow means2D / opacities directly, so ONE fill clears everything the blend backward accumulates
+        # into with atomics ("accumulators" request below); they are not part of `flat` and never travel.
+        self._buf = torch.zeros(off + 7 * P, dtype=torch.float32, device=device)
+        self.flat = self._buf[:off]
+        self._scratch_off = off
         if self.flat.data_ptr() % 16 != 0:  # (torch's allocators hand out >= 256-byte alignment; be explicit anyway)
             raise RuntimeError("GradBucket: the flat buffer is not 16-byte aligned")
         self.views: Dict[str, torch.Tensor] = {}
@@ -90,6 +95,14 @@ class GradBucket:
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool):
         if name == "sh_rgb":  # "rgb" exchange mode: ask the backward for dL_dRGB instead of dL_dsh
             return self.rgb if (self.rgb is not None and tuple(shape) == (self.P, 3)) else None
+        if name == "accumulators":  # means2D, opacities and the two internal accumulators, zeroed by ONE fill
+            if tuple(shape) != (11 * self.P,):
+                return None
+            P, so = self.P, self._scratch_off
+            if zero:
+                self._buf[self._acc_span[0]:so + 7 * P].zero_()
+            return (self.views["means2D"], self.views["opacities"], self._buf[so:so + 4 * P].view(P, 4),
+                    self._buf[so + 4 * P:so + 7 * P].view(P, 3))
         if name == "means2D+opacities":  # both accumulators, zeroed by ONE fill of the span that holds them
             if tuple(shape) != (4 * self.P,):
                 return None

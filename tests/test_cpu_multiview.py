@@ -206,6 +206,17 @@ def test_bucket_layout_and_allocator():
     m2, op = b.allocator("means2D+opacities", (32,), True)
     assert m2.data_ptr() == b.views["means2D"].data_ptr() and op.data_ptr() == b.views["opacities"].data_ptr()
     assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
+    # ... and so are the backward's two internal accumulators, behind the exchanged part: one fill for all four
+    b.flat.fill_(1.0)
+    m2, op, conic, cols = b.allocator("accumulators", (88,), True)
+    assert m2.data_ptr() == b.views["means2D"].data_ptr() and op.data_ptr() == b.views["opacities"].data_ptr()
+    assert tuple(conic.shape) == (8, 4) and tuple(cols.shape) == (8, 3) and conic.data_ptr() % 16 == 0
+    assert conic.data_ptr() == op.data_ptr() + 4 * 8 and cols.data_ptr() == conic.data_ptr() + 4 * 32
+    assert float(m2.abs().sum()) == float(op.abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
+    conic.fill_(2.0)
+    cols.fill_(3.0)
+    assert float(b.flat.sum()) == float(b.flat.numel() - 32)  # the internal accumulators are not part of the exchanged buffer
+    assert b.allocator("accumulators", (87,), True) is None
     # P % 4 != 0: every segment still starts on a 16-byte boundary (padding words between the segments), so the
     # backward's gradients always ARE the bucket's segments -- a bucket that handed out None here lost them silently
     for P_ in (1, 5, 6, 7, 1201):
@@ -217,6 +228,8 @@ def test_bucket_layout_and_allocator():
         m2, op = b2.allocator("means2D+opacities", (4 * P_,), True)
         assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0
         assert float(b2.views["rotations"].sum()) == 4 * P_ and float(b2.views["means3D"].sum()) == 3 * P_
+        four = b2.allocator("accumulators", (11 * P_,), True)
+        assert four[2].data_ptr() % 16 == 0 and tuple(four[2].shape) == (P_, 4) and tuple(four[3].shape) == (P_, 3)
         b3 = GradBucket(P_, 16, "cpu", sh_exchange="rgb")
         assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
 
