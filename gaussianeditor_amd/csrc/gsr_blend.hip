@@ -45,7 +45,8 @@ __device__ __forceinline__ bool setup_wave(const BlendArgs& a, uint32_t tile, ui
   return __any(pw.inside) != 0;
 }
 
-// The pixels of one forward / trace item and the box the cull test uses for it.  `code` = quad | sub << 2 from
+// The pixels of one forward / trace item and its pixel rectangle (the cull test of the blend loops starts from the pixels
+// that are live, live_pixel_box, which lie inside it).  `code` = quad | sub << 2 from
 // run_work_queue.  The item covers its quadrant, or -- when the image is small (SPLIT, image-wide) -- rows [4 s, 4 s + 4) /
 // the 4x4 block s of it: lanes outside the part are switched off (pw.inside), the box shrinks with it.  Returns false if
 // no pixel is inside the image.

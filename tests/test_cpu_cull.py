@@ -1,6 +1,6 @@
-"""CPU: the blend kernels' cull box (gsr_blend.hip: can_touch_quad; the same box bounds the tile rectangle of
-GSR_FLAG_TILE_BOUNDS_ALPHA) replayed in binary32 against the reference's per-pixel evaluation (forward.cu:335-344) on
-random Gaussians that include needles -- tools/cull_replay.py.  ADVICE r01: the round-1 rule dropped pixels the
+"""CPU: the conservative cull rules -- the alpha >= 1/255 box that bounds the tile rectangle of GSR_FLAG_TILE_BOUNDS_ALPHA (K1)
+and the blend kernels' ellipse-against-rectangle test (gsr_blend.hip: can_touch_quad) -- replayed in binary32 against the
+reference's per-pixel evaluation (forward.cu:335-344) on random Gaussians that include needles -- tools/cull_replay.py.  ADVICE r01: the round-1 rule dropped pixels the
 reference blends when det(conic) cancels; the current rule must not, and must still cull the well-conditioned ones."""
 import os
 import sys
