@@ -235,16 +235,16 @@ def main():
         d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
         d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-        Rc = ctypes.c_int64(0)
+        Rc = (ctypes.c_int64 * 2)()
         ev[0].record(s)
         _native.check("pre", L.gsr_preprocess(sp, P, 3, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
                                               p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
-                                              p(rs.campos), W, H, tfx, tfy, 0, 0, flags, p(radii_t), p(geom), ctypes.byref(Rc)))
+                                              p(rs.campos), W, H, tfx, tfy, 0, 0, flags, p(radii_t), p(geom), Rc))
         ev[1].record(s)
-        R = int(Rc.value)
-        _, bb, _ = _native.scratch_sizes(P, R, W, H)
+        R, Gi = int(Rc[0]), int(Rc[1])
+        _, bb, _ = _native.scratch_sizes(P, R, W, H, Gi)
         binning = torch.empty(bb, dtype=torch.uint8, device=dev)
-        _native.check("bin", L.gsr_bin(sp, P, R, W, H, p(radii_t), p(geom), p(binning), p(img)))
+        _native.check("bin", L.gsr_bin(sp, P, R, Gi, W, H, p(geom), p(binning), p(img)))
         ev[2].record(s)
         _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
         ev[3].record(s)

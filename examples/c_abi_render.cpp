@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
         *d_opac = to_device(opac), *d_shs = to_device(shs), *d_view = to_device(view), *d_proj = to_device(proj),
         *d_campos = to_device(campos);
   size_t sizes[3];
-  GSR_OK_(gsr_scratch_sizes(P, 0, W, H, sizes));
+  GSR_OK_(gsr_scratch_sizes(P, 0, 0, W, H, sizes));
   void *geom = nullptr, *image = nullptr, *binning = nullptr;
   int32_t* d_radii = nullptr;
   float *d_color = nullptr, *d_depth = nullptr;
@@ -81,12 +81,13 @@ int main(int argc, char** argv) {
   HIP_OK(hipMalloc(&d_color, sizeof(float) * 3 * (size_t)W * H));
   HIP_OK(hipMalloc(&d_depth, sizeof(float) * (size_t)W * H));
 
-  int64_t R = 0;  // the one blocking readback: sizes the per-instance scratch
+  int64_t counts[2] = {0, 0};  // the one blocking readback: {tile instances, tile-group instances} size the binning scratch
   GSR_OK_(gsr_preprocess(stream, P, D, M, d_means, d_scales, fl[2], d_rots, d_opac, d_shs, nullptr, nullptr, d_view, d_proj,
-                         d_campos, W, H, fl[0], fl[1], 0, 0, /*flags=*/0u, d_radii, geom, &R));
-  GSR_OK_(gsr_scratch_sizes(P, R, W, H, sizes));
+                         d_campos, W, H, fl[0], fl[1], 0, 0, /*flags=*/0u, d_radii, geom, counts));
+  const int64_t R = counts[0], G = counts[1];
+  GSR_OK_(gsr_scratch_sizes(P, R, G, W, H, sizes));
   if (sizes[1]) HIP_OK(hipMalloc(&binning, sizes[1]));
-  GSR_OK_(gsr_bin(stream, P, R, W, H, d_radii, geom, binning, image));
+  GSR_OK_(gsr_bin(stream, P, R, G, W, H, geom, binning, image));
   GSR_OK_(gsr_blend_forward(stream, P, R, W, H, d_bg, geom, binning, image, d_color, d_depth, /*flags=*/0u));
   HIP_OK(hipStreamSynchronize(stream));
 

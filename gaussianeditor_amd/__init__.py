@@ -42,14 +42,14 @@ def set_tile_bounds(mode: str) -> None:
 
     if mode not in ("reference", "alpha"):
         raise ValueError('tile bounds: "reference" or "alpha"')
-    f = options.current_flags() & ~options.FLAG_TILE_BOUNDS_ALPHA
+    f = options.default_flags() & ~options.FLAG_TILE_BOUNDS_ALPHA  # the default only: never a thread's override()
     options.set_default_flags(f | (options.FLAG_TILE_BOUNDS_ALPHA if mode == "alpha" else 0))
 
 
 def get_tile_bounds() -> str:
     from . import options
 
-    return "alpha" if options.current_flags() & options.FLAG_TILE_BOUNDS_ALPHA else "reference"
+    return "alpha" if options.default_flags() & options.FLAG_TILE_BOUNDS_ALPHA else "reference"
 
 
 def set_fast_exp(on: bool) -> None:
@@ -58,11 +58,11 @@ def set_fast_exp(on: bool) -> None:
     final_T are then no longer bit-identical to the CPU oracle."""
     from . import options
 
-    f = options.current_flags() & ~options.FLAG_FAST_EXP
+    f = options.default_flags() & ~options.FLAG_FAST_EXP
     options.set_default_flags(f | (options.FLAG_FAST_EXP if on else 0))
 
 
 def get_fast_exp() -> bool:
     from . import options
 
-    return bool(options.current_flags() & options.FLAG_FAST_EXP)
+    return bool(options.default_flags() & options.FLAG_FAST_EXP)

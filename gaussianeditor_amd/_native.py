@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: GSR_LIBRARY_PATH (development only: A/B timing of differently built libraries, tools/ab_variants.py) replaces the
 #: in-tree library; it must export the same ABI and is loaded under the same "no fallback" rule.
 LIB_PATH = os.environ.get("GSR_LIBRARY_PATH") or os.path.join(_HERE, "libgsr_hip.so")
-GSR_ABI_VERSION = 2
+GSR_ABI_VERSION = 3
 
 _P = c_void_p
 
@@ -45,11 +45,11 @@ SIGNATURES = {
     "gsr_abi_version": (c_int, []),
     "gsr_status_string": (ctypes.c_char_p, [c_int]),
     "gsr_last_hip_error": (c_int, []),
-    "gsr_scratch_sizes": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_size_t)]),
+    "gsr_scratch_sizes": (c_int, [c_int, c_int64, c_int64, c_int, c_int, POINTER(c_size_t)]),
     "gsr_sort_key_bits": (c_int, [c_int, c_int]),
     "gsr_preprocess": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                                c_float, c_float, c_int, c_int, c_uint, _P, _P, POINTER(c_int64)]),
-    "gsr_bin": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "gsr_bin": (c_int, [_P, c_int, c_int64, c_int64, c_int, c_int, _P, _P, _P]),
     "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
@@ -124,7 +124,8 @@ def check(fn: str, status: int) -> None:
         raise GsrError(fn, status, msg, L.gsr_last_hip_error() if status == -4 else 0)
 
 
-def scratch_sizes(P: int, R: int, W: int, H: int):
+def scratch_sizes(P: int, R: int, W: int, H: int, G: int = 0):
+    """(geometry, binning, image) scratch bytes; R, G = the two counts gsr_preprocess returns (0, 0 before they are known)."""
     sizes = (c_size_t * 3)()
-    check("gsr_scratch_sizes", lib().gsr_scratch_sizes(P, R, W, H, sizes))
+    check("gsr_scratch_sizes", lib().gsr_scratch_sizes(P, R, G, W, H, sizes))
     return int(sizes[0]), int(sizes[1]), int(sizes[2])

@@ -3,16 +3,27 @@
 // The reference builds one 64-bit key (tile | depth bits) per (Gaussian, tile) instance and runs a
 // stable radix sort over all R instances on 32 + getHigherMsb(T) key bits (rasterizer_impl.cu:67-100,
 // 253-261: 45 bits at 1080p).  Every instance of a Gaussian carries the SAME depth, so the identical
-// order is obtained far cheaper as two stable sorts (a stable sort by the minor key followed by a stable
-// sort by the major key):
+// order is obtained far cheaper by ordering the Gaussians first and the instances by tile afterwards
+// (a stable sort by the minor key followed by a stable sort by the major key):
 //
 //   1. stable LSD radix sort of the P Gaussians by their 32 depth bits (value = index, culled ones
 //      last).  P is ~5x smaller than R, and it runs inside gsr_preprocess, i.e. under the host's
-//      blocking readback of num_rendered (launch_depth_order);
-//   2. instances are emitted in that Gaussian order, so the instance array is already depth-ordered,
-//      ties in emission order = ascending Gaussian index exactly like the reference's;
-//   3. stable LSD radix sort of the R instances by tile id only: 13 bits at 1080p = 2 passes over
-//      8-byte (tile, index) pairs instead of 6 passes over 12-byte pairs.
+//      blocking readback of num_rendered (launch_depth_passes);
+//   2. GROUP INSTANCES: tiles are taken in groups of 8 x 8 (128 x 128 pixels).  One (group, Gaussian)
+//      pair per group a Gaussian's tile rectangle reaches is emitted in depth order -- ~1.3 per visible
+//      Gaussian where the reference emits ~5 (tile, Gaussian) pairs, ~3 instead of ~30 on deep-tile scenes --
+//      and sorted stably by group id in ONE radix pass (at most GROUP_MAX = 2048 groups);
+//   3. inside a group a Gaussian's tiles are a 64-bit mask.  One wave takes 64 consecutive group
+//      instances, transposes the 64 x 64 bit matrix (lane j: mask of instance j -> lane t: which of the
+//      64 instances touch tile t, in order) and lane t appends those Gaussian indices to ITS tile's list:
+//      the per-tile order is the instance order = depth order, ties in ascending Gaussian index exactly
+//      like the reference's.  Where a wave's run of a tile starts comes from a count pass with the same
+//      transposes and a column scan over the chunks of a group; the per-tile ranges (K5) are the prefix
+//      of the tile totals -- no (tile, index) pair is ever written, sorted or re-read: 4 bytes per
+//      instance leave the chip once.
+//
+// Images with more than GROUP_MAX groups (> 131 072 tiles, 33 MPix) keep the round-2 path: (tile id,
+// Gaussian) pairs emitted in depth order and radix-sorted on the tile id in ceil(bits / 8) passes.
 //
 // A radix pass is three kernels (histogram -> per-bin scan -> scatter); there is no decoupled
 // look-back, so no inter-workgroup hand-off inside a launch (per-XCD L2s are not coherent; a kernel
@@ -51,22 +62,26 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __rest
   if (publish_dst != nullptr && blockIdx.x == 0) {
     __shared__ unsigned long long psum[SORT_THREADS / 64];
     __shared__ uint32_t pmax[SORT_THREADS / 64], pinv[SORT_THREADS / 64];
-    unsigned long long sum = 0;
+    __shared__ unsigned long long pgrp[SORT_THREADS / 64];
+    unsigned long long sum = 0, gsum = 0;
     uint32_t kmax = 0, kinv = 0;
     for (uint32_t i = threadIdx.x; i < publish_count; i += SORT_THREADS) {
       const uint4 v = publish_src[i];
       sum += v.x;
+      gsum += v.w;
       kmax = max(kmax, v.y);
       kinv = max(kinv, v.z);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
       sum += __shfl_xor(sum, d, 64);
+      gsum += __shfl_xor(gsum, d, 64);
       kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
       kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, d, 64));
     }
     if (lane_id() == 0) {
       psum[threadIdx.x >> 6] = sum;
+      pgrp[threadIdx.x >> 6] = gsum;
       pmax[threadIdx.x >> 6] = kmax;
       pinv[threadIdx.x >> 6] = kinv;
     }
@@ -74,6 +89,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __rest
     if (threadIdx.x == 0) {
       for (int w = 1; w < SORT_THREADS / 64; ++w) {
         sum += psum[w];
+        gsum += pgrp[w];
         kmax = max(kmax, pmax[w]);
         kinv = max(kinv, pinv[w]);
       }
@@ -81,6 +97,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __rest
       publish_dst[1] = (uint32_t)(sum >> 32);
       publish_dst[GEOM_HDR_KEYMAX] = kmax;
       publish_dst[GEOM_HDR_KEYINVMAX] = kinv;
+      publish_dst[GEOM_HDR_GROUPS] = (uint32_t)gsum;
+      publish_dst[GEOM_HDR_GROUPS + 1] = (uint32_t)(gsum >> 32);
       __threadfence_system();
       // the host spins on this word (fine-grained pinned memory): no event, hence no barrier packet in the stream
       __hip_atomic_store(publish_dst + GEOM_HDR_FINAL, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -268,22 +286,32 @@ static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const va
 // ----------------------------------------------------------------------------------
 // Depth order of the Gaussians + prefix of tiles_touched in that order.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, int gx, const uint32_t* __restrict__ order,
+// `sgx` != 0: the rectangle is reduced to the rectangle of 8x8-tile GROUPS it reaches (row stride sgx) -- what the grouped
+// path emits; sgx == 0: the tile rectangle itself (row stride gx), for the legacy pair sort.
+__global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, int gx, int sgx, const uint32_t* __restrict__ order,
                                                                        const uint2* __restrict__ rect,
                                                                        uint32_t* __restrict__ wh_sorted,
                                                                        uint32_t* __restrict__ org_sorted,
                                                                        uint32_t* __restrict__ block_sums,
                                                                        uint32_t* __restrict__ hdr, uint32_t final_buf) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[GEOM_HDR_FINAL] = final_buf;  // for emit_keys_kernel (gsr_bin)
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr[GEOM_HDR_FINAL] = final_buf;  // for the emit kernels (gsr_bin)
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  // THE gather of the binning: the tile rectangle of the i-th Gaussian in depth order (8 bytes; its area is the tile count).
-  // It is left in depth order for the emit kernel, which then reads everything coalesced.
+  // THE gather of the binning's first half: the tile rectangle of the i-th Gaussian in depth order (8 bytes).
+  // What the emit kernel needs of it is left in depth order, so that it reads everything coalesced.
   const uint2 rc = i < P ? rect[order[i]] : make_uint2(0u, 0u);
-  const uint32_t n = (rc.y & 0xffffu) * (rc.y >> 16);
+  const uint32_t w = rc.y & 0xffffu, h = rc.y >> 16, x0 = rc.x & 0xffffu, y0 = rc.x >> 16;
+  uint32_t n = w * h, wh = rc.y, org = y0 * (uint32_t)gx + x0;
+  if (sgx != 0 && n != 0) {
+    const uint32_t g0x = x0 >> GROUP_SHIFT, g0y = y0 >> GROUP_SHIFT;
+    const uint32_t nsx = ((x0 + w - 1u) >> GROUP_SHIFT) - g0x + 1u, nsy = ((y0 + h - 1u) >> GROUP_SHIFT) - g0y + 1u;
+    n = nsx * nsy;
+    wh = nsx | (nsy << 16);
+    org = g0y * (uint32_t)sgx + g0x;
+  }
   if (i < P) {
-    wh_sorted[i] = rc.y;                                            // width | height << 16
-    org_sorted[i] = (rc.x >> 16) * (uint32_t)gx + (rc.x & 0xffffu);  // tile id of the rectangle's first tile
+    wh_sorted[i] = wh;    // width | height << 16 of the rectangle (tiles, or groups)
+    org_sorted[i] = org;  // id of its first tile / group
   }
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
@@ -320,12 +348,12 @@ hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int 
   return hipGetLastError();
 }
 // After `passes` passes: tile counts gathered into depth order (+ their per-block sums and the prefix of those).
-hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx) {
+hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx, int sgx) {
   const int fin = passes & 1;
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   // dkey[fin ^ 1] / dval[fin ^ 1] (the input of the last pass) are dead: reuse them for the depth-ordered rectangles
-  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, gx, g.dval[fin], g.rect, g.dkey[fin ^ 1],
-                     g.dval[fin ^ 1], g.block_sums, reinterpret_cast<uint32_t*>(g.total), (uint32_t)fin);
+  hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, gx, sgx, g.dval[fin], g.rect,
+                     g.dkey[fin ^ 1], g.dval[fin ^ 1], g.block_sums, reinterpret_cast<uint32_t*>(g.total), (uint32_t)fin);
   hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, g.block_offs, nb);
   return hipGetLastError();
 }
@@ -339,16 +367,17 @@ hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, 
 // inside its rectangle gives the tile, rows first as the reference's loops do.
 // Only the tile id is written as key (the depth is implied by the position).
 // ----------------------------------------------------------------------------------
+// The same kernel emits the GROUP instances of the grouped path: the depth-ordered rectangles sorted_block_sums_kernel
+// left are then rectangles of groups, `gx` the number of groups per row and `ranges` null.
 template <class K>
-__global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int gy, const int32_t* __restrict__ radii,
-                                                               const Geom g, K* __restrict__ tkeys,
+__global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int nclear, const Geom g, K* __restrict__ tkeys,
                                                                uint32_t* __restrict__ vals, uint2* __restrict__ ranges) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_org[GAUSS_BLOCK], s_w[GAUSS_BLOCK];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  // the ranges of tiles no instance falls into stay (0,0) (reference: cudaMemset, rasterizer_impl.cu:263-265);
+  // legacy path: the ranges of tiles no instance falls into stay (0,0) (reference: cudaMemset, rasterizer_impl.cu:263-265);
   // cleared here, two launches ahead of tile_ranges_kernel, instead of by a memset of its own
-  if (i < gx * gy) ranges[i] = make_uint2(0u, 0u);
+  if (ranges != nullptr && i < nclear) ranges[i] = make_uint2(0u, 0u);
   if ((int)blockIdx.x * GAUSS_BLOCK >= P) return;  // (extra blocks only clear ranges)
   const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
   const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
@@ -430,9 +459,14 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t L, const K* __
 // The order inside a bucket depends on LDS-atomic timing: it only affects scheduling,
 // never results.
 // ----------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2* __restrict__ ranges,
+// Grouped path (`tile_total` != null): K5 happens here first -- the exclusive prefix of the tiles' instance counts in tile-id
+// order gives every tile's [begin, end) (identifyTileRanges, rasterizer_impl.cu:105-125; (0, 0) for a tile without
+// instances, as the reference's memset leaves it, :263-265) and `tile_start`, where the chunk waves start their runs.
+__global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
-                                                            uint32_t* __restrict__ queues, uint32_t* __restrict__ est) {
+                                                            uint32_t* __restrict__ queues, uint32_t* __restrict__ est,
+                                                            const uint32_t* __restrict__ tile_total,
+                                                            uint32_t* __restrict__ tile_start) {
   // Counting sort of the tiles by bucket.  Most tiles of an image fall into a handful of buckets, and LDS atomics on one
   // address serialise, so every bucket has WORK_SUB counters (chosen by the thread's lane): the order inside a bucket is
   // free anyway, and the sort's time stops growing with the number of tiles per bucket.
@@ -448,7 +482,32 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
     queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // (second word of the line: spare)
   }
   for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
-  __syncthreads();
+  if (tile_total != nullptr) {
+    constexpr int PER = 8;  // consecutive tiles per thread and round
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += 1024 * PER) {
+      const int i0 = base + (int)threadIdx.x * PER;
+      uint32_t v[PER], sum = 0;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        v[j] = i0 + j < T ? tile_total[i0 + j] : 0u;
+        sum += v[j];
+      }
+      uint32_t chunk;
+      uint32_t run = carry + block_excl_scan_u32<1024>(sum, &chunk, smem);
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (i0 + j < T) {
+          tile_start[i0 + j] = run;
+          ranges[i0 + j] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
+        }
+        run += v[j];
+      }
+      carry += chunk;
+    }
+    if (threadIdx.x == 0) tile_start[T] = carry;
+  }
+  __syncthreads();  // (the block reads its own `ranges` stores below)
   const uint32_t sub = threadIdx.x & (WORK_SUB - 1);
   auto bucket_of = [](uint32_t len) -> uint32_t {
     if (len == 0) return WORK_BUCKETS;  // empty tiles: last
@@ -480,31 +539,380 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, const uint2*
   }
 }
 
-hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
-                          const Binning& b, const Image& im) {
+// ----------------------------------------------------------------------------------
+// Grouped path, step 2: ONE stable radix pass over the group instances (key = group id, < 2^BITS), whose output leaves
+// each group's segment padded to whole chunks: segment s starts at chunk * (number of chunks of the groups before it).
+// ----------------------------------------------------------------------------------
+// histogram of the pass + the padding value into every slot of the output side (the scatter overwrites the real ones:
+// what remains are the padding slots between the segments and behind the last one)
+template <int BITS>
+__global__ void __launch_bounds__(SORT_THREADS) group_hist_kernel(const uint16_t* __restrict__ keys, int64_t n,
+                                                                 uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                                 uint32_t* __restrict__ fill_dst, int64_t fill_n) {
+  constexpr int NB = 1 << BITS;
+  __shared__ uint32_t h[NB];
+  for (int i = threadIdx.x; i < NB; i += SORT_THREADS) h[i] = 0;
+  {
+    const int64_t per = (fill_n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(lo + per, fill_n);
+    for (int64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) fill_dst[i] = GROUP_PAD;
+  }
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
+  uint32_t kv[SORT_ITEMS];
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+    kv[i] = (uint32_t)keys[k < n ? k : n - 1];
+  }
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+    if (k < n) atomicAdd(&h[kv[i] & (NB - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NB; i += SORT_THREADS) hist[(size_t)i * nblocks + blockIdx.x] = h[i];
+}
+
+// sort_scatter_kernel with 2^BITS bins and padded segment starts; ranks from BITS ballots per key (stable).
+template <int BITS>
+__global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint16_t* __restrict__ keys_in,
+                                                                    const uint32_t* __restrict__ vals_in,
+                                                                    uint16_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ vals_out, int64_t n,
+                                                                    const uint32_t* __restrict__ hist,
+                                                                    const uint32_t* __restrict__ bin_total,
+                                                                    uint32_t nblocks, uint32_t chunk) {
+  constexpr int NB = 1 << BITS, NW = SORT_THREADS / 64, BPT = NB / SORT_THREADS;  // bins per thread (consecutive)
+  __shared__ uint16_t cnt[NW][NB];     // per-wave digit counts -> per-wave local bases
+  __shared__ uint32_t gbase[NB];       // global position of the block's first key of each digit
+  __shared__ uint16_t lexcl[NB];       // position of each digit's run inside the block-sorted order
+  __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
+  __shared__ uint16_t skey[SORT_KPB];
+  __shared__ uint32_t sval[SORT_KPB];
+  const int w = (int)(threadIdx.x >> 6), l = lane_id();
+  const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
+  const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
+  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+  uint16_t rank[SORT_ITEMS];
+  const uint64_t lt_mask = (1ull << l) - 1ull;
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
+    key[i] = (uint32_t)keys_in[kc] & (NB - 1);
+    val[i] = vals_in[kc];
+  }
+  {
+    // padded start of every digit's segment: exclusive prefix of the bin totals rounded up to whole chunks
+    uint32_t padded[BPT], mine[BPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const uint32_t d = threadIdx.x * BPT + j;
+      const uint32_t tot = bin_total[d];
+      padded[j] = (tot + chunk - 1u) / chunk * chunk;
+      mine[j] = hist[(size_t)d * nblocks + blockIdx.x];
+      sum += padded[j];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32<SORT_THREADS>(sum, &tot, smem);
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      gbase[threadIdx.x * BPT + j] = run + mine[j];
+      run += padded[j];
+    }
+  }
+  for (int i = threadIdx.x; i < NW * NB; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+  __syncthreads();
+
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    const bool valid = k < n;
+    const uint32_t d = key[i];
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < BITS; ++b) {
+      const uint64_t bb = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bb : ~bb;
+    }
+    const uint32_t before = (uint32_t)__popcll(m & lt_mask);
+    uint32_t old = 0;
+    if (valid) old = cnt[w][d];
+    // all reads of this iteration precede the leader's write (one wave, program order)
+    if (valid && before == 0) cnt[w][d] = (uint16_t)(old + (uint32_t)__popcll(m));
+    rank[i] = (uint16_t)(old + before);
+  }
+  __syncthreads();
+  {
+    // per digit: block total, exclusive prefix over the waves, and the digit's offset in block-sorted order
+    uint32_t tot_d[BPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      const uint32_t d = threadIdx.x * BPT + j;
+      uint32_t run = 0;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t c = cnt[i][d];
+        cnt[i][d] = (uint16_t)run;
+        run += c;
+      }
+      tot_d[j] = run;
+      sum += run;
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32<SORT_THREADS>(sum, &tot, smem);
+#pragma unroll
+    for (int j = 0; j < BPT; ++j) {
+      lexcl[threadIdx.x * BPT + j] = (uint16_t)run;
+      run += tot_d[j];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    if (k < n) {
+      const uint32_t d = key[i];
+      const uint32_t lp = (uint32_t)lexcl[d] + (uint32_t)cnt[w][d] + rank[i];
+      skey[lp] = (uint16_t)d;
+      sval[lp] = val[i];
+    }
+  }
+  __syncthreads();
+  const int nvalid = (int)min((int64_t)SORT_KPB, n - bbase);
+#pragma unroll
+  for (int i = 0; i < SORT_ITEMS; ++i) {
+    const int j = i * SORT_THREADS + (int)threadIdx.x;
+    if (j < nvalid) {
+      const uint32_t d = skey[j];
+      const uint32_t pos = gbase[d] + ((uint32_t)j - (uint32_t)lexcl[d]);
+      keys_out[pos] = (uint16_t)d;
+      vals_out[pos] = sval[j];
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------
+// Grouped path, step 3: chunks.  A chunk is `chunk` consecutive slots of the sorted, padded group-instance array; all its
+// items belong to one group (its first slot is always a real item, padding only follows the last item of a group).  One
+// wave per chunk, lane t = tile t of the group.
+// ----------------------------------------------------------------------------------
+struct GroupArgs {
+  int gx, gy, sgx, chunk;
+  const uint16_t* gkey;      // sorted + padded group ids
+  const uint32_t* gval;      // sorted + padded Gaussian indices (GROUP_PAD in padding slots)
+  const uint2* rect;         // (P) tile rectangles (Geom::rect)
+  uint16_t* chunk_cnt;       // (chunks, 64)
+  const uint32_t* chunk_pre; // (chunks, 64)
+  const uint32_t* tile_start;
+  uint32_t* point_list;
+};
+
+// The tiles of the group at tile origin (gx0, gy0) that the tile rectangle rc = (x | y << 16, w | h << 16) covers:
+// bit (ty & 7) * 8 + (tx & 7), rows 0..3 in `lo`, rows 4..7 in `hi`.
+__device__ __forceinline__ void group_mask(uint2 rc, uint32_t gx0, uint32_t gy0, uint32_t& lo, uint32_t& hi) {
+  const int x0 = (int)(rc.x & 0xffffu) - (int)gx0, y0 = (int)(rc.x >> 16) - (int)gy0;
+  const int x1 = x0 + (int)(rc.y & 0xffffu), y1 = y0 + (int)(rc.y >> 16);
+  const int cx0 = max(x0, 0), cx1 = min(x1, GROUP_EDGE), cy0 = max(y0, 0), cy1 = min(y1, GROUP_EDGE);
+  lo = hi = 0u;
+  if (cx1 <= cx0 || cy1 <= cy0) return;
+  const uint32_t cols = ((1u << (cx1 - cx0)) - 1u) << cx0;  // the covered columns, 8 bits
+  // rows [a, b) of a 4-row half -> one 0x01 per covered row byte, times the column bits (no carries between bytes)
+  auto half = [cols](int a, int b) -> uint32_t {
+    if (b <= a) return 0u;
+    const uint32_t ones = (b - a) >= 4 ? 0xffffffffu : ((1u << (8 * (b - a))) - 1u);
+    return ((ones << (8 * a)) & 0x01010101u) * cols;
+  };
+  lo = half(min(cy0, 4), min(cy1, 4));
+  hi = half(max(cy0 - 4, 0), max(cy1 - 4, 0));
+}
+
+// 64 x 64 bit transpose across the wave: in: lane j holds the tile mask of batch item j; out: lane t holds the set of
+// items that touch tile t.  One ballot per tile, its 64-bit result written into lane t with v_writelane_b32 (clang exposes
+// no builtin for it; the lane select is an inline constant, the data a plain SGPR).
+// HAZARD (measured, profiles/r03_a: bits 30 / 62 / 63 came out wrong, exactly the three places where hipcc had scheduled
+// nothing between the compare and the write): v_writelane_b32 does NOT interlock on an SGPR a VALU instruction has just
+// written -- the ISA manual lists 4 wait states for the lane-select operand, the data operand behaves the same.  The
+// hazard recogniser does not look into inline assembly, so four ballots are formed first and ONE block issues
+// `s_nop 3` followed by their eight writes: every SGPR read is at least 4 wait states behind the compare that wrote it.
+template <int T0>
+__device__ __forceinline__ void transpose_four(uint32_t src, uint32_t& a, uint32_t& b) {
+  const uint64_t b0 = __ballot((src >> ((T0 + 0) & 31)) & 1u), b1 = __ballot((src >> ((T0 + 1) & 31)) & 1u);
+  const uint64_t b2 = __ballot((src >> ((T0 + 2) & 31)) & 1u), b3 = __ballot((src >> ((T0 + 3) & 31)) & 1u);
+  const uint32_t l0 = (uint32_t)b0, h0 = (uint32_t)(b0 >> 32), l1 = (uint32_t)b1, h1 = (uint32_t)(b1 >> 32);
+  const uint32_t l2 = (uint32_t)b2, h2 = (uint32_t)(b2 >> 32), l3 = (uint32_t)b3, h3 = (uint32_t)(b3 >> 32);
+  asm volatile(
+      "s_nop 3\n\t"
+      "v_writelane_b32 %0, %2, %10\n\t"
+      "v_writelane_b32 %1, %3, %10\n\t"
+      "v_writelane_b32 %0, %4, %11\n\t"
+      "v_writelane_b32 %1, %5, %11\n\t"
+      "v_writelane_b32 %0, %6, %12\n\t"
+      "v_writelane_b32 %1, %7, %12\n\t"
+      "v_writelane_b32 %0, %8, %13\n\t"
+      "v_writelane_b32 %1, %9, %13"
+      : "+v"(a), "+v"(b)
+      : "s"(l0), "s"(h0), "s"(l1), "s"(h1), "s"(l2), "s"(h2), "s"(l3), "s"(h3), "n"(T0), "n"(T0 + 1), "n"(T0 + 2), "n"(T0 + 3));
+}
+template <int T0>
+__device__ __forceinline__ void transpose_from(uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b) {
+  if constexpr (T0 < 64) {
+    transpose_four<T0>(T0 < 32 ? lo : hi, a, b);
+    transpose_from<T0 + 4>(lo, hi, a, b);
+  }
+}
+__device__ __forceinline__ void transpose_masks(uint32_t lo, uint32_t hi, uint32_t& wlo, uint32_t& whi) {
+  uint32_t a = 0, b = 0;
+  transpose_from<0>(lo, hi, a, b);
+  wlo = a;
+  whi = b;
+}
+
+// SCATTER = false: count pass (chunk_cnt[c][t] = instances of tile t in chunk c).
+// SCATTER = true:  lane t appends the Gaussians of its tile, batch by batch in item order, at
+//                  tile_start[tile] + chunk_pre[c][t]: the reference's point_list.
+template <bool SCATTER>
+__global__ void __launch_bounds__(64) group_chunk_kernel(const GroupArgs a) {
+  const size_t c = blockIdx.x;
+  const int lane = (int)threadIdx.x;
+  const size_t base = c * (size_t)a.chunk;
+  if (a.gval[base] == GROUP_PAD) return;  // behind the last chunk (the grid is an upper bound)
+  const uint32_t s = (uint32_t)a.gkey[base];
+  const uint32_t gx0 = (s % (uint32_t)a.sgx) << GROUP_SHIFT, gy0 = (s / (uint32_t)a.sgx) << GROUP_SHIFT;
+  uint32_t cnt = 0;
+  uint32_t* dst = nullptr;
+  if (SCATTER) {
+    const uint32_t tx = gx0 + (uint32_t)(lane & 7), ty = gy0 + (uint32_t)(lane >> 3);
+    const bool tile_ok = tx < (uint32_t)a.gx && ty < (uint32_t)a.gy;  // (a lane without a tile never sees a set bit)
+    dst = a.point_list + (tile_ok ? a.tile_start[ty * (uint32_t)a.gx + tx] + a.chunk_pre[c * GROUP_TILES + lane] : 0u);
+  }
+  for (int b = 0; b < a.chunk; b += 64) {
+    const uint32_t idx = a.gval[base + b + lane];
+    const bool valid = idx != GROUP_PAD;
+    if (__ballot(valid) == 0ull) break;  // padding only follows the items
+    uint32_t lo = 0u, hi = 0u;
+    if (valid) group_mask(a.rect[idx], gx0, gy0, lo, hi);
+    uint32_t wlo, whi;
+    transpose_masks(lo, hi, wlo, whi);
+    if (!SCATTER) {
+      cnt += (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
+    } else {
+      uint64_t W = ((uint64_t)whi << 32) | wlo;
+      while (__ballot(W != 0ull) != 0ull) {
+        const int j = W ? (int)__builtin_ctzll(W) : 0;
+        const uint32_t v = (uint32_t)__shfl((int)idx, j, 64);
+        if (W) {
+          *dst++ = v;
+          W &= W - 1ull;
+        }
+      }
+    }
+  }
+  if (!SCATTER) a.chunk_cnt[c * GROUP_TILES + lane] = (uint16_t)cnt;
+}
+
+// Column scan: one workgroup per group; its chunks are consecutive rows [first, first + n) of the count table.  The
+// waves take contiguous slabs of rows: slab sums -> exclusive prefix over the slabs (LDS) -> rescan with the offsets.
+constexpr int COLSCAN_WAVES = 8;
+__global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int gx, int gy, int sgx, int groups, uint32_t chunk,
+                                                                          const uint32_t* __restrict__ bin_total,
+                                                                          const uint16_t* __restrict__ chunk_cnt,
+                                                                          uint32_t* __restrict__ chunk_pre,
+                                                                          uint32_t* __restrict__ tile_total) {
+  constexpr int NT = COLSCAN_WAVES * 64;
+  __shared__ uint32_t red[COLSCAN_WAVES];
+  __shared__ uint32_t slab[COLSCAN_WAVES][GROUP_TILES];
+  const uint32_t s = blockIdx.x;
+  const int w = (int)(threadIdx.x >> 6), lane = lane_id();
+  // rows of the groups before this one
+  uint32_t before = 0;
+  for (uint32_t g = threadIdx.x; g < s; g += NT) before += (bin_total[g] + chunk - 1u) / chunk;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
+  if (lane == 0) red[w] = before;
+  __syncthreads();
+  uint32_t first = 0;
+#pragma unroll
+  for (int i = 0; i < COLSCAN_WAVES; ++i) first += red[i];
+  const uint32_t n = (bin_total[s] + chunk - 1u) / chunk;
+  const uint32_t per = (n + COLSCAN_WAVES - 1) / COLSCAN_WAVES;
+  const uint32_t r0 = min(n, (uint32_t)w * per), r1 = min(n, r0 + per);
+  uint32_t sum = 0;
+  for (uint32_t r = r0; r < r1; ++r) sum += chunk_cnt[(size_t)(first + r) * GROUP_TILES + lane];
+  slab[w][lane] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int i = 0; i < COLSCAN_WAVES; ++i) {
+    const uint32_t v = slab[i][lane];
+    run += i < w ? v : 0u;
+    total += v;
+  }
+  for (uint32_t r = r0; r < r1; ++r) {
+    const size_t o = (size_t)(first + r) * GROUP_TILES + lane;
+    chunk_pre[o] = run;
+    run += chunk_cnt[o];
+  }
+  if (w == 0) {
+    const uint32_t tx = ((s % (uint32_t)sgx) << GROUP_SHIFT) + (uint32_t)(lane & 7);
+    const uint32_t ty = ((s / (uint32_t)sgx) << GROUP_SHIFT) + (uint32_t)(lane >> 3);
+    if (tx < (uint32_t)gx && ty < (uint32_t)gy) tile_total[ty * (uint32_t)gx + tx] = total;
+  }
+}
+
+template <int BITS>
+static void launch_grouped(hipStream_t s, int P, int gx, int gy, const Geom& g, const Binning& b, const Image& im) {
+  const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
+  const int64_t padded = b.chunks * (int64_t)b.chunk;
+  hipLaunchKernelGGL(emit_keys_kernel<uint16_t>, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, 0, g, b.gkey[0], b.gval[0],
+                     (uint2*)nullptr);
+  hipLaunchKernelGGL(group_hist_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint16_t*)b.gkey[0], b.G,
+                     b.ghist, b.sort_blocks, b.gval[1], padded);
+  hipLaunchKernelGGL(sort_scan_kernel, dim3(1 << BITS), dim3(SORT_THREADS), 0, s, b.ghist, b.gbin_total, b.sort_blocks);
+  hipLaunchKernelGGL(group_scatter_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint16_t*)b.gkey[0],
+                     (const uint32_t*)b.gval[0], b.gkey[1], b.gval[1], b.G, (const uint32_t*)b.ghist,
+                     (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk);
+  GroupArgs a;
+  a.gx = gx; a.gy = gy; a.sgx = b.sgx; a.chunk = b.chunk;
+  a.gkey = b.gkey[1]; a.gval = b.gval[1]; a.rect = g.rect;
+  a.chunk_cnt = b.chunk_cnt; a.chunk_pre = b.chunk_pre; a.tile_start = b.tile_start; a.point_list = b.point_list;
+  hipLaunchKernelGGL(group_chunk_kernel<false>, dim3((unsigned)b.chunks), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(group_colscan_kernel, dim3(b.groups), dim3(COLSCAN_WAVES * 64), 0, s, gx, gy, b.sgx, b.groups,
+                     (uint32_t)b.chunk, (const uint32_t*)b.gbin_total, (const uint16_t*)b.chunk_cnt, b.chunk_pre, b.tile_total);
+  hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
+                     im.queue_heads, im.work_est, (const uint32_t*)b.tile_total, b.tile_start);
+  hipLaunchKernelGGL(group_chunk_kernel<true>, dim3((unsigned)b.chunks), dim3(64), 0, s, a);
+}
+
+hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   if (R <= 0) {
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                       im.queue_heads, im.work_est);
+                       im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    return hipGetLastError();
+  }
+  if (!b.legacy) {
+    if (b.group_bits == 8) launch_grouped<8>(s, P, gx, gy, g, b, im);
+    else launch_grouped<11>(s, P, gx, gy, g, b, im);
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   const dim3 ge(max(nbg, (gx * gy + GAUSS_BLOCK - 1) / GAUSS_BLOCK)), gr((unsigned)((R + 256 * RANGE_PER - 1) / (256 * RANGE_PER)));
   if (b.key_bytes == 2) {  // tile ids fit 16 bits: 6 instead of 8 bytes per sorted pair
     uint16_t* const tk[2] = {(uint16_t*)b.tkey[0], (uint16_t*)b.tkey[1]};
-    hipLaunchKernelGGL(emit_keys_kernel<uint16_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, tk[0], b.vals[0], im.ranges);
+    hipLaunchKernelGGL(emit_keys_kernel<uint16_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gx * gy, g, tk[0], b.vals[0], im.ranges);
     radix_sort_pairs<uint16_t>(s, tk, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
     hipLaunchKernelGGL(tile_ranges_kernel<uint16_t>, gr, dim3(256), 0, s, R, (const uint16_t*)tk[b.final_buf], im.ranges);
   } else {
     uint32_t* const tk[2] = {(uint32_t*)b.tkey[0], (uint32_t*)b.tkey[1]};
-    hipLaunchKernelGGL(emit_keys_kernel<uint32_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gy, radii, g, tk[0], b.vals[0], im.ranges);
+    hipLaunchKernelGGL(emit_keys_kernel<uint32_t>, ge, dim3(GAUSS_BLOCK), 0, s, P, gx, gx * gy, g, tk[0], b.vals[0], im.ranges);
     radix_sort_pairs<uint32_t>(s, tk, b.vals, R, b.passes, b.digit_bits, b.hist, b.bin_total, false);
     hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, gr, dim3(256), 0, s, R, (const uint32_t*)tk[b.final_buf], im.ranges);
   }
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                     im.queue_heads, im.work_est);
+                     im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr);
   return hipGetLastError();
 }
 
@@ -517,13 +925,32 @@ __global__ void __launch_bounds__(256) export_keys_kernel(int64_t R, const K* __
   if (i >= R) return;
   keys[i] = ((uint64_t)tkeys[i] << 32) | (uint64_t)__float_as_uint(rec1[vals[i]].z);
 }
-hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys) {
-  if (b.key_bytes == 2)
-    hipLaunchKernelGGL(export_keys_kernel<uint16_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
-                       (const uint16_t*)b.tkey[b.final_buf], b.vals[b.final_buf], g.rec1, keys);
-  else
-    hipLaunchKernelGGL(export_keys_kernel<uint32_t>, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s, R,
-                       (const uint32_t*)b.tkey[b.final_buf], b.vals[b.final_buf], g.rec1, keys);
+// grouped path: the tile of instance i is the last one whose run starts at or before i (tile_start is monotone)
+__global__ void __launch_bounds__(256) export_keys_grouped_kernel(int64_t R, uint32_t T, const uint32_t* __restrict__ tile_start,
+                                                                 const uint32_t* __restrict__ vals,
+                                                                 const float4* __restrict__ rec1, uint64_t* __restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  uint32_t lo = 0, hi = T;  // invariant: tile_start[lo] <= i < tile_start[hi]
+  while (hi - lo > 1u) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((int64_t)tile_start[mid] <= i) lo = mid; else hi = mid;
+  }
+  keys[i] = ((uint64_t)lo << 32) | (uint64_t)__float_as_uint(rec1[vals[i]].z);
+}
+hipError_t launch_export_keys(hipStream_t s, int64_t R, int W, int H, const Binning& b, const Geom& g, uint64_t* keys) {
+  const dim3 grid((unsigned)((R + 255) / 256));
+  if (!b.legacy) {
+    const uint32_t T = (uint32_t)(((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE));
+    hipLaunchKernelGGL(export_keys_grouped_kernel, grid, dim3(256), 0, s, R, T, (const uint32_t*)b.tile_start,
+                       (const uint32_t*)b.point_list, g.rec1, keys);
+  } else if (b.key_bytes == 2) {
+    hipLaunchKernelGGL(export_keys_kernel<uint16_t>, grid, dim3(256), 0, s, R, (const uint16_t*)b.tkey[b.final_buf],
+                       b.vals[b.final_buf], g.rec1, keys);
+  } else {
+    hipLaunchKernelGGL(export_keys_kernel<uint32_t>, grid, dim3(256), 0, s, R, (const uint32_t*)b.tkey[b.final_buf],
+                       b.vals[b.final_buf], g.rec1, keys);
+  }
   return hipGetLastError();
 }
 

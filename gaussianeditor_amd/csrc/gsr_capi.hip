@@ -2,6 +2,7 @@
 // kernel sequencing.  No device memory is allocated here and no option state is kept (behaviour flags arrive with every
 // call); the only state is the pool of pinned readback slots (host_slot).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <chrono>
@@ -54,13 +55,16 @@ struct ThreadSlots {
 
 // The slot of the calling thread for the device `stream` belongs to (NOT the thread's current device: a C-ABI caller
 // may hand over a stream of another device).
-HostSlot* host_slot(hipStream_t stream) {
+// On failure *err tells why: hipSuccess = the device ordinal is outside the pool (an argument problem), otherwise the
+// failing runtime call's error.
+HostSlot* host_slot(hipStream_t stream, hipError_t* err) {
   static thread_local ThreadSlots mine;
   int dev = 0;
   hipDevice_t sdev = 0;
+  *err = hipSuccess;
   if (stream != nullptr && hipStreamGetDevice(stream, &sdev) == hipSuccess)
     dev = (int)sdev;  // (hipDevice_t is the ordinal)
-  else if (hipGetDevice(&dev) != hipSuccess)
+  else if ((*err = hipGetDevice(&dev)) != hipSuccess)
     return nullptr;
   if (dev < 0 || dev >= MAX_DEV) return nullptr;
   if (mine.held[dev] != nullptr) return mine.held[dev];
@@ -79,8 +83,8 @@ HostSlot* host_slot(hipStream_t stream) {
   void* p = nullptr;
   void* dp = nullptr;
   HostSlot* h = nullptr;
-  if (hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
-    if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) {
+  if ((*err = hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped)) == hipSuccess) {
+    if ((*err = hipHostGetDevicePointer(&dp, p, 0)) == hipSuccess) {
       memset(p, 0, GEOM_HDR_BYTES);
       h = new HostSlot();
       h->words = (uint32_t*)p;
@@ -94,6 +98,23 @@ HostSlot* host_slot(hipStream_t stream) {
   if (switched) (void)hipSetDevice(cur);
   return h;
 }
+
+// Which binning path an image takes (gsr_binning.hip): a function of the image size only, so that gsr_scratch_sizes,
+// gsr_preprocess, gsr_bin and the blend entry points of one view agree.  GSR_BIN_LEGACY=1 (tests) forces the pair sort.
+inline int bin_legacy(int W, int H) {
+  static const bool forced = [] {
+    const char* e = getenv("GSR_BIN_LEGACY");
+    return e != nullptr && e[0] == '1';
+  }();
+  return (forced || group_count(W, H) > GROUP_MAX) ? 1 : 0;
+}
+// What the blend / export entry points need of the binning scratch sits in front of everything sized by the number of
+// group instances, so they carve with G = 0.
+inline Binning carve_binning_view(const void* binning, int64_t R, int W, int H) {
+  return carve_binning(const_cast<void*>(binning), R, 0, W, H, bin_legacy(W, H));
+}
+// Scratch buffers are accessed with 16-byte vector loads at 256-byte aligned section offsets.
+inline bool misaligned(const void* p) { return ((uintptr_t)p & 255u) != 0; }
 
 inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
                                  int queue_kind) {
@@ -109,7 +130,7 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.bwd_order = im.bwd_order;
   a.bwd_meta = im.bwd_meta;
   a.ranges = im.ranges;
-  a.point_list = b.vals[b.final_buf];
+  a.point_list = b.point_list;
   a.rec0 = g.rec0;
   a.rec1 = g.rec1;
   a.rec2 = g.rec2;
@@ -132,7 +153,6 @@ const char* gsr_status_string(int status) {
     case GSR_ERR_BAD_CHANNELS: return "unsupported number of channels (apply_weights supports 1, 2 or 3)";
     case GSR_ERR_TOO_MANY: return "number of rendered instances exceeds the 31-bit index space";
     case GSR_ERR_HIP: return "HIP runtime error";
-    case GSR_ERR_PREFILTERED: return "point culled although prefiltered is set";
     default: return "unknown status";
   }
 }
@@ -141,10 +161,10 @@ int gsr_last_hip_error(void) { return g_last_hip_error; }
 
 int gsr_sort_key_bits(int W, int H) { return sort_key_bits(W, H); }
 
-int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]) {
-  if (P < 0 || R < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
+int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]) {
+  if (P < 0 || R < 0 || G < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
   sizes[0] = carve_geom(nullptr, P).bytes;
-  sizes[1] = carve_binning(nullptr, R, W, H).bytes;
+  sizes[1] = carve_binning(nullptr, R, G, W, H, bin_legacy(W, H)).bytes;
   sizes[2] = carve_image(nullptr, W, H).bytes;
   return GSR_OK;
 }
@@ -153,13 +173,16 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
                    const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
                    int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, unsigned flags,
-                   int32_t* radii, void* geom, int64_t* num_rendered_host) {
-  (void)prefiltered;  // the reference only uses it to trap on an impossible condition (auxiliary.h:156-160)
-  if (num_rendered_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
-  *num_rendered_host = 0;
+                   int32_t* radii, void* geom, int64_t counts_host[2]) {
+  // `prefiltered`: the reference promises with it that no point fails the frustum test and TRAPS the device when one
+  // does (auxiliary.h:156-160).  No caller sets it (render() passes False, gaussian_renderer/__init__.py:83); a culled
+  // point is simply culled here, which is what the flag's absence does.
+  (void)prefiltered;
+  if (counts_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
+  counts_host[0] = counts_host[1] = 0;
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3 || (flags & ~GSR_FLAG_ALL)) return GSR_ERR_BAD_ARGUMENT;
-  if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
+  if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geom || misaligned(geom)) return GSR_ERR_BAD_ARGUMENT;
   if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr)) return GSR_ERR_BAD_ARGUMENT;
   if (!skip_color) {
     // the reference throws std::runtime_error for "non-RGB without precomputed colours"
@@ -186,8 +209,9 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   // num_rendered (and the range of the depth keys); the first kernel behind it -- the histogram of the first depth-sort
   // pass -- writes those words into pinned, device-mapped host memory, a generation word last.  The first two passes of
   // the depth sort are enqueued at once and run while the host waits.
-  HostSlot* slot = host_slot(s);
-  if (slot == nullptr) return hip_fail(hipErrorOutOfMemory);
+  hipError_t slot_err = hipSuccess;
+  HostSlot* slot = host_slot(s, &slot_err);
+  if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT /* device ordinal beyond the pool */ : hip_fail(slot_err);
   const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
   GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
   // Poll the generation word (an event would put a barrier packet into the stream -- a 6 us bubble -- and sleeping on
@@ -221,21 +245,24 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   for (uint32_t d = total ? (kmax ^ kmin) : 0u; d; d >>= 1) ++nbits;
   const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
   if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
-  GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx));
+  const int legacy = bin_legacy(W, H);
+  GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx, legacy ? 0 : (a.gx + GROUP_EDGE - 1) >> GROUP_SHIFT));
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
-  *num_rendered_host = (int64_t)total;
+  counts_host[0] = (int64_t)total;
+  counts_host[1] = legacy ? 0 : (int64_t)((uint64_t)w[GEOM_HDR_GROUPS] | ((uint64_t)w[GEOM_HDR_GROUPS + 1] << 32));
   return GSR_OK;
 }
 
-int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, const void* geom, void* binning,
-            void* image) {
-  if (P < 0 || R < 0 || W <= 0 || H <= 0 || !image) return GSR_ERR_BAD_ARGUMENT;
-  if (R >= (1ll << 31)) return GSR_ERR_TOO_MANY;
-  if (R > 0 && (!radii || !geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
+int gsr_bin(void* stream, int P, int64_t R, int64_t G, int W, int H, const void* geom, void* binning, void* image) {
+  if (P < 0 || R < 0 || G < 0 || W <= 0 || H <= 0 || !image || misaligned(image)) return GSR_ERR_BAD_ARGUMENT;
+  if (R >= (1ll << 31) || G >= (1ll << 31)) return GSR_ERR_TOO_MANY;
+  if (R > 0 && (!geom || !binning || misaligned(geom) || misaligned(binning))) return GSR_ERR_BAD_ARGUMENT;
+  const int legacy = bin_legacy(W, H);
+  if (R > 0 && !legacy && (G <= 0 || G > R)) return GSR_ERR_BAD_ARGUMENT;  // every group instance holds >= 1 tile instance
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(binning, R, W, H);
+  const Binning b = carve_binning(binning, R, G, W, H, legacy);
   const Image im = carve_image(image, W, H);
-  GSR_HIP(launch_binning((hipStream_t)stream, P, R, W, H, radii, g, b, im));
+  GSR_HIP(launch_binning((hipStream_t)stream, P, R, W, H, g, b, im));
   return GSR_OK;
 }
 
@@ -245,7 +272,7 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
     return GSR_ERR_BAD_ARGUMENT;
   if (R > 0 && (!geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
   a.out_color = out_color;
@@ -261,7 +288,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || (flags & ~GSR_FLAG_ALL)) return GSR_ERR_BAD_ARGUMENT;
   if (R > 0 && (!geom || !binning || !colors)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
   a.colors3 = colors;
@@ -286,7 +313,7 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth) return GSR_ERR_BAD_ARGUMENT;
   if (R > 0 && (!geom || !binning)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
   a.out_color = out_color;
@@ -307,7 +334,7 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
     return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Image im = carve_image(const_cast<void*>(image), W, H);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
   a.dL_dpix = dL_dpix;
   a.dL_dmean2D = dL_dmeans2D;
@@ -365,7 +392,7 @@ int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int 
   if (P < 0 || R <= 0 || W <= 0 || H <= 0 || !bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
   if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
   a.dL_dpix = dL_dpix;
@@ -517,7 +544,7 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   if (R == 0) return GSR_OK;
   if (!geom || !binning) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, nullptr, 2);
   a.C = C;
@@ -611,10 +638,7 @@ int gsr_debug_export_geom(void* stream, int P, const void* geom, float* means2D,
   if (P <= 0) return GSR_OK;
   if (!geom) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  GSR_HIP(launch_export_geom((hipStream_t)stream, P, g, means2D, depths, rgb, conic_opacity, clamped));
-  hipStream_t s = (hipStream_t)stream;
-  if (tiles_touched)
-    GSR_HIP(hipMemcpyAsync(tiles_touched, g.tiles, sizeof(uint32_t) * (size_t)P, hipMemcpyDeviceToDevice, s));
+  GSR_HIP(launch_export_geom((hipStream_t)stream, P, g, means2D, depths, rgb, conic_opacity, tiles_touched, clamped));
   return GSR_OK;
 }
 
@@ -623,11 +647,11 @@ int gsr_debug_export_binning(void* stream, int P, int64_t R, int W, int H, const
   if (R <= 0) return GSR_OK;
   if (!binning || !geom) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
-  const Binning b = carve_binning(const_cast<void*>(binning), R, W, H);
+  const Binning b = carve_binning_view(binning, R, W, H);
   hipStream_t s = (hipStream_t)stream;
-  if (keys) GSR_HIP(launch_export_keys(s, R, b, g, keys));
+  if (keys) GSR_HIP(launch_export_keys(s, R, W, H, b, g, keys));
   if (point_list)
-    GSR_HIP(hipMemcpyAsync(point_list, b.vals[b.final_buf], sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
+    GSR_HIP(hipMemcpyAsync(point_list, b.point_list, sizeof(uint32_t) * (size_t)R, hipMemcpyDeviceToDevice, s));
   return GSR_OK;
 }
 

@@ -16,6 +16,13 @@ constexpr int TILE = 16;        // tile edge in pixels (reference: BLOCK_X/BLOCK
 constexpr int QUAD = 8;         // one wave = 8x8 pixels
 constexpr int WAVE = 64;
 constexpr int GAUSS_BLOCK = 256;  // Gaussians per block in the per-Gaussian kernels
+// Binning works on GROUPS of 8 x 8 tiles (128 x 128 pixels): a Gaussian's tile rectangle inside one group is a 64-bit
+// mask, one bit per tile, bit = (tile_y & 7) * 8 + (tile_x & 7) (gsr_binning.hip).
+constexpr int GROUP_SHIFT = 3;
+constexpr int GROUP_EDGE = 1 << GROUP_SHIFT;
+constexpr int GROUP_TILES = GROUP_EDGE * GROUP_EDGE;  // 64 = one wave: lane t owns tile t of the group
+constexpr int GROUP_MAX = 2048;                // images with more groups (> 131 072 tiles) take the two-pass tile sort
+constexpr uint32_t GROUP_PAD = 0xffffffffu;    // Gaussian index held by the padding slots between the groups' segments
 
 // ----------------------------------------------------------------------------------
 // Opaque scratch layouts.  Every section is 256-byte aligned.
@@ -32,12 +39,11 @@ struct Geom {
   float4* rec1;
   float4* rec2;
   uint2* rect;           // (P)     tile rectangle, written for every Gaussian: x = minx | miny << 16, y = width | height << 16 (0 if culled)
-  uint32_t* tiles;       // (P)     tiles_touched
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
   uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order
   uint32_t* block_offs;  // (nb)    exclusive prefix of block_sums
   uint64_t* total;       // header (GEOM_HDR_BYTES): word GEOM_HDR_FINAL only, written before it is read -- never cleared
-  uint4* k1_partials;    // (nb)    per K1 block: sum of tiles_touched, max depth key, max complemented key, 0
+  uint4* k1_partials;    // (nb)    per K1 block: sum of tiles_touched, max depth key, max complemented key, sum of groups touched
   // depth ordering of the Gaussians (stable LSD radix sort of (depth bits, index); culled Gaussians last)
   uint32_t* dkey[2];     // (P)     ping-pong depth keys
   uint32_t* dval[2];     // (P)     ping-pong Gaussian indices; dval[header FINAL] holds the final order
@@ -54,6 +60,7 @@ constexpr int GEOM_HDR_SLOT_WORDS = 32;
 constexpr int GEOM_HDR_KEYMAX = 2;     // [0..1] num_rendered (u64); max depth key over the visible Gaussians
 constexpr int GEOM_HDR_KEYINVMAX = 3;  // max of the complemented key (= ~min key)
 constexpr int GEOM_HDR_FINAL = 4;      // device header only: which ping-pong side (dval[]) holds the depth order
+constexpr int GEOM_HDR_GROUPS = 5;     // host slot only: [5..6] number of group instances (u64)
 constexpr int GEOM_HDR_BYTES = GEOM_HDR_SLOTS * GEOM_HDR_SLOT_WORDS * 4;
 
 __host__ __device__ inline Geom carve_geom(void* base, int P) {
@@ -67,7 +74,6 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   g.rec1 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec2 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rect = (uint2*)(p + off);          off += align_up(sizeof(uint2) * (size_t)P);
-  g.tiles = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * (size_t)P);
   g.clamped = (uint8_t*)(p + off);     off += align_up((size_t)P);
   g.block_sums = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
   g.block_offs = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);
@@ -124,13 +130,36 @@ constexpr int SORT_ITEMS = 16;                          // keys per thread
 constexpr int SORT_KPB = SORT_THREADS * SORT_ITEMS;     // keys per block (4096)
 constexpr int SORT_MAX_BINS = 512;                      // 9-bit digits at most
 
-// Per-instance state ("binningBuffer"): ping-pong (tile id, Gaussian index) arrays + histograms.
-// Instances are emitted in depth order of their Gaussians, so only the tile id remains to be sorted
-// (stably): getHigherMsb(T) bits in ceil(bits/8) passes.
+// Per-instance state ("binningBuffer").  Everything the blend kernels read -- the reference's point_list -- comes FIRST,
+// so its address depends on nothing but the buffer's base.
+//
+// Grouped path (images of up to GROUP_MAX groups): one GROUP INSTANCE per (Gaussian, 8x8-tile group) pair is emitted in
+// depth order, stably sorted by group id in ONE radix pass whose output leaves every group's segment padded to whole
+// CHUNKS, and each chunk (one wave) then turns its 64-item batches into per-tile lists with a 64 x 64 bit transpose:
+// lane t ends up with the set of batch items that touch tile t of the group, in order.
+// Legacy path (more groups): (tile id, Gaussian) pairs, stable radix sort on the tile id in ceil(bits / 8) passes.
 struct Binning {
+  uint32_t* point_list;   // (R) Gaussian indices, tile by tile, each tile's in depth order: the reference's point_list
+  int legacy;
+  // --- grouped path
+  int sgx, sgy, groups;   // groups per row / column, S = sgx * sgy
+  int group_bits;         // 8 (S <= 256) or 11: digit width of the one radix pass
+  int chunk;              // group instances per chunk (a multiple of 64)
+  int64_t G;              // group instances
+  int64_t chunks;         // upper bound of the number of chunks: floor(G / chunk) + S
+  uint32_t sort_blocks;   // ceil(G / SORT_KPB)
+  uint16_t* gkey[2];      // [0]: (G) group ids in emission (= depth) order; [1]: (chunks * chunk) sorted + padded
+  uint32_t* gval[2];      // the Gaussian index of each group instance, same shapes; padding slots hold GROUP_PAD
+  uint32_t* ghist;        // (bins * sort_blocks), bin-major
+  uint32_t* gbin_total;   // (bins)
+  uint16_t* chunk_cnt;    // (chunks, 64) instances of tile t in chunk c
+  uint32_t* chunk_pre;    // (chunks, 64) the same summed over the earlier chunks of the chunk's group
+  uint32_t* tile_total;   // (T) instances per tile
+  uint32_t* tile_start;   // (T + 1) exclusive prefix of tile_total in tile-id order
+  // --- legacy path
   void* tkey[2];        // (R) tile ids, uint16 when they fit (key_bytes == 2: images of up to 65535 tiles), else uint32
   int key_bytes;
-  uint32_t* vals[2];    // (R) Gaussian indices; vals[final_buf] is the reference's point_list
+  uint32_t* vals[2];    // (R) Gaussian indices; vals[final_buf] is point_list
   uint32_t* hist;       // (bins * nblocks), bin-major
   uint32_t* bin_total;  // (bins)
   uint32_t nblocks;
@@ -153,9 +182,26 @@ __host__ __device__ inline int sort_key_bits(int W, int H) {
   const uint32_t T = (uint32_t)((W + TILE - 1) / TILE) * (uint32_t)((H + TILE - 1) / TILE);
   return 32 + (int)higher_msb(T);
 }
-__host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, int H) {
+__host__ __device__ inline int64_t group_count(int W, int H) {
+  const int64_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  return ((gx + GROUP_EDGE - 1) >> GROUP_SHIFT) * ((gy + GROUP_EDGE - 1) >> GROUP_SHIFT);
+}
+// Group instances per chunk: one 64-item batch per wave while that still gives every SIMD of the chip work (4096 chunks),
+// then longer chunks (fewer rows in the per-chunk count tables), at most 8 batches.
+__host__ __device__ inline int group_chunk_items(int64_t G) {
+  const int64_t batches = (G + 63) / 64;
+  int64_t per = (batches + 4095) / 4096;
+  per = per < 1 ? 1 : (per > 8 ? 8 : per);
+  return (int)(64 * per);
+}
+// `legacy`: the caller's choice of path (capi: image size, GSR_BIN_LEGACY); G is ignored on the legacy path.
+__host__ __device__ inline Binning carve_binning(void* base, int64_t R, int64_t G, int W, int H, int legacy) {
   char* p = (char*)base;
   Binning b;
+  const int64_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE, T = gx * gy;
+  b.legacy = legacy;
+  size_t off = 0;
+  // legacy fields
   b.nblocks = (uint32_t)((R + SORT_KPB - 1) / SORT_KPB);
   b.tile_bits = sort_key_bits(W, H) - 32;
   b.passes = (b.tile_bits + 7) / 8;
@@ -167,11 +213,42 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int W, i
   }
   b.final_buf = b.passes & 1;
   b.key_bytes = b.tile_bits <= 16 ? 2 : 4;  // a third less traffic per sorted pair, half for the histogram / range kernels
-  size_t off = 0;
-  for (int i = 0; i < 2; ++i) { b.tkey[i] = (void*)(p + off); off += align_up((size_t)b.key_bytes * (size_t)R); }
-  for (int i = 0; i < 2; ++i) { b.vals[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)R); }
-  b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_MAX_BINS * (size_t)b.nblocks);
-  b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_MAX_BINS);
+  // grouped fields
+  b.sgx = (int)((gx + GROUP_EDGE - 1) >> GROUP_SHIFT);
+  b.sgy = (int)((gy + GROUP_EDGE - 1) >> GROUP_SHIFT);
+  b.groups = b.sgx * b.sgy;
+  b.group_bits = b.groups <= 256 ? 8 : 11;
+  b.G = legacy ? 0 : G;
+  b.chunk = group_chunk_items(b.G);
+  b.chunks = b.G / b.chunk + b.groups;
+  b.sort_blocks = (uint32_t)((b.G + SORT_KPB - 1) / SORT_KPB);
+  if (legacy) {
+    // point_list = vals[final_buf]: the side is a function of the image size only
+    b.vals[b.final_buf] = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * (size_t)R);
+    b.vals[b.final_buf ^ 1] = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (size_t)R);
+    b.point_list = b.vals[b.final_buf];
+    for (int i = 0; i < 2; ++i) { b.tkey[i] = (void*)(p + off); off += align_up((size_t)b.key_bytes * (size_t)R); }
+    b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_MAX_BINS * (size_t)b.nblocks);
+    b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_MAX_BINS);
+    b.gkey[0] = b.gkey[1] = nullptr; b.gval[0] = b.gval[1] = nullptr;
+    b.ghist = b.gbin_total = b.chunk_pre = b.tile_total = b.tile_start = nullptr;
+    b.chunk_cnt = nullptr;
+  } else {
+    const size_t bins = (size_t)1 << b.group_bits, padded = (size_t)b.chunks * (size_t)b.chunk;
+    // (everything that does not depend on G first: the blend kernels and the debug exports carve with G = 0)
+    b.point_list = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (size_t)R);
+    b.tile_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (size_t)T);
+    b.tile_start = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (size_t)(T + 1));
+    b.gval[0] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * (size_t)b.G);
+    b.gval[1] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * padded);
+    b.gkey[0] = (uint16_t*)(p + off);     off += align_up(sizeof(uint16_t) * (size_t)b.G);
+    b.gkey[1] = (uint16_t*)(p + off);     off += align_up(sizeof(uint16_t) * padded);
+    b.ghist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * bins * (size_t)b.sort_blocks);
+    b.gbin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * bins);
+    b.chunk_cnt = (uint16_t*)(p + off);   off += align_up(sizeof(uint16_t) * GROUP_TILES * (size_t)b.chunks);
+    b.chunk_pre = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * GROUP_TILES * (size_t)b.chunks);
+    b.tkey[0] = b.tkey[1] = nullptr; b.vals[0] = b.vals[1] = nullptr; b.hist = b.bin_total = nullptr;
+  }
   b.bytes = R > 0 ? off : 0;
   return b;
 }

@@ -114,13 +114,14 @@ const uint32_t* compact_block_off_ptr(void* workspace, int64_t P);
 hipError_t launch_export_cov3d(hipStream_t s, int P, const float* scales, float scale_modifier, const float* rotations,
                                float* cov3D);
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
-                              float* conic_opacity, uint8_t* clamped);
+                              float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped);
 hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int p1, uint32_t* publish_dst = nullptr,
                                uint32_t publish_seq = 0);
-hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx);
-hipError_t launch_export_keys(hipStream_t s, int64_t R, const Binning& b, const Geom& g, uint64_t* keys);
-hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const int32_t* radii, const Geom& g,
-                          const Binning& b, const Image& im);
+// sgx: groups per row when the grouped binning path follows (the depth-ordered rectangles are then group rectangles), 0 for
+// the legacy pair sort
+hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx, int sgx);
+hipError_t launch_export_keys(hipStream_t s, int64_t R, int W, int H, const Binning& b, const Geom& g, uint64_t* keys);
+hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im);
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out);
 size_t compact_workspace_bytes(int64_t P);

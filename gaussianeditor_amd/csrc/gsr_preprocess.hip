@@ -160,11 +160,11 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s
 // (70 VGPRs would allow 7 waves per SIMD; with one 192-byte SH row per thread that many waves thrash the caches --
 //  tools/microbench/rows192.hip: 4.55 TB/s at 2-4 waves per SIMD, 4.16 at 6, 3.24 at 8 -- so the kernel is held at 4: -3 us)
 __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_kernel(const PreArgs a) {
-  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1], ssum[GAUSS_BLOCK / 64];
   __shared__ uint32_t skmax[2];
   if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
-  uint32_t my_tiles = 0;
+  uint32_t my_tiles = 0, my_groups = 0;  // tiles touched; 8x8-tile groups touched (gsr_binning.hip: group instances)
   uint32_t kmax = 0u, kinv = 0u;  // max of the depth key / of its complement over the visible Gaussians of the wave
   if (idx < a.P) {
     Cam cam;
@@ -267,7 +267,10 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
           ntiles = (maxx > minx && maxy > miny) ? (maxx - minx) * (maxy - miny) : 0u;
         }
       }
-      if (ntiles != 0) my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
+      if (ntiles != 0) {
+        my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
+        my_groups = (((maxx - 1u) >> GROUP_SHIFT) - (minx >> GROUP_SHIFT) + 1u) * (((maxy - 1u) >> GROUP_SHIFT) - (miny >> GROUP_SHIFT) + 1u);
+      }
 
       // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -317,7 +320,6 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       my_tiles = ntiles;
     } while (false);
     a.radii[idx] = my_radius_i;
-    a.g.tiles[idx] = my_tiles;
     a.g.rect[idx] = my_tiles ? my_rect : make_uint2(0u, 0u);  // written for every Gaussian: the binning reads nothing else of it
     // key of the depth ordering (gsr_binning.hip): depth bits, culled Gaussians after every live one
     a.g.dkey[0][idx] = my_tiles ? __float_as_uint(my_depth) : 0xffffffffu;
@@ -331,17 +333,34 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
     kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
     kinv = max(kinv, (uint32_t)__shfl_xor((int)kinv, d, 64));
   }
-  // num_rendered = sum of tiles_touched
-  uint32_t total;
-  (void)block_excl_scan_u32<GAUSS_BLOCK>(my_tiles, &total, smem);  // (its barriers also order the skmax init)
+  // num_rendered = sum of tiles_touched; the number of group instances = sum of the groups touched
+  uint32_t tsum = my_tiles, gsum = my_groups;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    tsum += (uint32_t)__shfl_xor((int)tsum, d, 64);
+    gsum += (uint32_t)__shfl_xor((int)gsum, d, 64);
+  }
+  if (lane_id() == 0) {
+    smem[threadIdx.x >> 6] = tsum;
+    ssum[threadIdx.x >> 6] = gsum;
+  }
+  __syncthreads();  // (also orders the skmax init)
   if (lane_id() == 0 && kinv) {
     atomicMax(&skmax[0], kmax);
     atomicMax(&skmax[1], kinv);
   }
   __syncthreads();
-  // this block's share of num_rendered and of the range of the depth keys (max, and max of the complement = ~min:
-  // the host sizes the depth sort with it); reduced by the first depth-sort kernel (sort_hist_kernel, publish)
-  if (threadIdx.x == 0) a.g.k1_partials[blockIdx.x] = make_uint4(total, skmax[0], skmax[1], 0u);
+  // this block's share of num_rendered, of the group instances and of the range of the depth keys (max, and max of the
+  // complement = ~min: the host sizes the depth sort with it); reduced by the first depth-sort kernel (sort_hist_kernel, publish)
+  if (threadIdx.x == 0) {
+    uint32_t total = 0, gtotal = 0;
+#pragma unroll
+    for (int w = 0; w < GAUSS_BLOCK / 64; ++w) {
+      total += smem[w];
+      gtotal += ssum[w];
+    }
+    a.g.k1_partials[blockIdx.x] = make_uint4(total, skmax[0], skmax[1], gtotal);
+  }
 }
 
 // ----------------------------------------------------------------------------------
@@ -903,10 +922,13 @@ hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
 }
 // Test-only introspection: unpack the gather records into the reference's separate arrays.
 __global__ void __launch_bounds__(GAUSS_BLOCK) export_geom_kernel(int P, const Geom g, float* means2D, float* depths,
-                                                                 float* rgb, float* conic_opacity, uint8_t* clamped) {
+                                                                 float* rgb, float* conic_opacity, uint32_t* tiles_touched,
+                                                                 uint8_t* clamped) {
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   if (idx >= P) return;
-  const bool live = g.tiles[idx] != 0;  // records of culled Gaussians are uninitialised
+  const uint32_t wh = g.rect[idx].y;  // width | height << 16 of the tile rectangle: its area is tiles_touched
+  const bool live = wh != 0;          // records of culled Gaussians are uninitialised
+  if (tiles_touched) tiles_touched[idx] = (wh & 0xffffu) * (wh >> 16);
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 r0 = live ? g.rec0[idx] : z, r1 = live ? g.rec1[idx] : z, r2 = live ? g.rec2[idx] : z;
   if (means2D) { means2D[2 * idx] = r1.x; means2D[2 * idx + 1] = r1.y; }
@@ -934,10 +956,10 @@ hipError_t launch_export_cov3d(hipStream_t s, int P, const float* scales, float 
   return hipGetLastError();
 }
 hipError_t launch_export_geom(hipStream_t s, int P, const Geom& g, float* means2D, float* depths, float* rgb,
-                              float* conic_opacity, uint8_t* clamped) {
+                              float* conic_opacity, uint32_t* tiles_touched, uint8_t* clamped) {
   const int nb = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   hipLaunchKernelGGL(export_geom_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, P, g, means2D, depths, rgb, conic_opacity,
-                     clamped);
+                     tiles_touched, clamped);
   return hipGetLastError();
 }
 hipError_t launch_mark_visible(hipStream_t s, int P, const float* means3D, const float* view, uint8_t* present) {

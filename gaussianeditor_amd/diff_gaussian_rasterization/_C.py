@@ -79,15 +79,15 @@ def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations
     gbytes, _, ibytes = _native.scratch_sizes(P, 0, W, H)
     geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
     img = torch.empty(ibytes, dtype=torch.uint8, device=dev)
-    R = ctypes.c_int64(0)
+    counts = (ctypes.c_int64 * 2)()  # num_rendered, and the number of tile-group instances the binning works on
     _native.check("gsr_preprocess", L.gsr_preprocess(
         s, P, D, M, _ptr(means3D), _ptr(scales), scale_modifier, _ptr(rotations), _ptr(opacity), _ptr(sh),
         _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H, tan_fovx, tan_fovy,
-        int(bool(prefiltered)), int(skip_color), flags, radii.data_ptr(), geom.data_ptr(), ctypes.byref(R)))
-    R = int(R.value)
-    _, bbytes, _ = _native.scratch_sizes(P, R, W, H)
+        int(bool(prefiltered)), int(skip_color), flags, radii.data_ptr(), geom.data_ptr(), counts))
+    R, G = int(counts[0]), int(counts[1])
+    _, bbytes, _ = _native.scratch_sizes(P, R, W, H, G)
     binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
-    _native.check("gsr_bin", L.gsr_bin(s, P, R, W, H, radii.data_ptr(), geom.data_ptr(), _ptr(binning), img.data_ptr()))
+    _native.check("gsr_bin", L.gsr_bin(s, P, R, G, W, H, geom.data_ptr(), _ptr(binning), img.data_ptr()))
     return R, geom, binning, img
 
 

@@ -25,6 +25,11 @@ def current_flags() -> int:
     return _default if f is None else f
 
 
+def default_flags() -> int:
+    """The process-wide default, whatever `override` the calling thread is inside of."""
+    return _default
+
+
 def set_default_flags(flags: int) -> None:
     global _default
     if flags & ~FLAG_ALL:

@@ -21,10 +21,16 @@
  *     buffers are opaque bytes that the caller keeps alive between forward and
  *     backward (the reference's geomBuffer / binningBuffer / imgBuffer,
  *     rasterize_points.cu:64-69, diff_gaussian_rasterization/__init__.py:122-133).
+ *   - scratch buffers (geom / binning / image) must be 256-byte aligned (torch's allocations are): their sections are
+ *     read with 16-byte vector loads.  A misaligned one is rejected with GSR_ERR_BAD_ARGUMENT.
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it.
- *     The library is re-entrant and keeps no option state (behaviour switches travel with every call as
- *     `flags`); the only thing it owns is a small pool of 8 KiB pinned host buffers, one checked out per host thread
- *     and device, through which gsr_preprocess receives num_rendered (the device writes it, the host polls it).
+ *     The library is re-entrant and keeps no BEHAVIOUR state (the switches that can change a result travel with every
+ *     call as `flags`); the only thing it owns is a small pool of 8 KiB pinned host buffers, one checked out per host
+ *     thread and device, through which gsr_preprocess receives its counts (the device writes them, the host polls).
+ *   - tuning / experiment knobs are environment variables read ONCE per process, none of which changes any result
+ *     (launch geometry of the persistent blend kernels, work-list ordering, ablation switches, and GSR_BIN_LEGACY=1,
+ *     which sends every image down the tile-pair sort that otherwise only images beyond 131 072 tiles take); they are
+ *     listed in DESIGN.md section 3.3 and are not part of this ABI.
  *   - an absent optional input is a NULL pointer (the reference uses empty
  *     tensors for the same purpose, diff_gaussian_rasterization/__init__.py:285-295).
  *   - return value: GSR_OK (0) or a negative gsr_status; never exit()/abort().
@@ -42,15 +48,14 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 typedef enum gsr_status {
   GSR_OK = 0,
   GSR_ERR_BAD_ARGUMENT = -1,   /* NULL where a pointer is required, negative sizes, ... */
   GSR_ERR_BAD_CHANNELS = -2,   /* apply_weights with C outside {1,2,3} (reference: exit(-1), apply_weights.cu:377-380) */
   GSR_ERR_TOO_MANY = -3,       /* num_rendered does not fit the 31-bit index space */
-  GSR_ERR_HIP = -4,            /* a HIP runtime call failed; see gsr_last_hip_error() */
-  GSR_ERR_PREFILTERED = -5     /* reserved: prefiltered point culled (reference traps, auxiliary.h:156-160) */
+  GSR_ERR_HIP = -4             /* a HIP runtime call failed; see gsr_last_hip_error() */
 } gsr_status;
 
 /* Version of this ABI (== GSR_ABI_VERSION of the header the library was built from). */
@@ -61,11 +66,12 @@ const char* gsr_status_string(int status);
 int gsr_last_hip_error(void);
 
 /* Byte sizes of the three opaque scratch buffers for P Gaussians, R rendered
- * instances and a W x H image.  Pass R = 0 before R is known (sizes[1] is then 0).
+ * instances, G group instances (both returned by gsr_preprocess) and a W x H image.  Pass R = G = 0 before they are
+ * known (sizes[1] is then 0).
  * sizes[0] = geometry (per Gaussian), sizes[1] = binning (per instance),
  * sizes[2] = image (per pixel / tile).
  * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
-int gsr_scratch_sizes(int P, int64_t R, int W, int H, size_t sizes[3]);
+int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]);
 
 /* Per-call behaviour flags (ABI 2; ABI 1 had a process-wide gsr_set_option instead).  The library keeps no option
  * state: every entry point below that takes `flags` receives them with the call, and the calls that belong to one view
@@ -94,10 +100,15 @@ int gsr_sort_key_bits(int W, int H);
 
 /* K1 + K2: per-Gaussian preprocessing (SH -> RGB, 3D -> 2D covariance, conic,
  * radius, tile rectangle), the depth ordering of the Gaussians (first half of K4, see gsr_bin) and the
- * prefix sum over tiles_touched in that order; then the ONE
- * blocking device->host readback of the path: *num_rendered_host = total number
- * of (Gaussian, tile) instances.  Reference: FORWARD::preprocess + InclusiveSum +
- * cudaMemcpy, rasterizer_impl.cu:217-239 (and :381-403 for apply_weights).
+ * prefix sums the emission in that order needs; then the ONE
+ * blocking device->host readback of the path: counts_host[0] = num_rendered, the total number
+ * of (Gaussian, tile) instances, counts_host[1] = the number of (Gaussian, 8x8-tile group) instances gsr_bin works on
+ * (0 for images that take the tile-pair sort).  Both size the binning scratch.  Reference: FORWARD::preprocess +
+ * InclusiveSum + cudaMemcpy, rasterizer_impl.cu:217-239 (and :381-403 for apply_weights).
+ * The host normally waits ~80 us for the counts, spinning on a pinned word the device writes; if nothing arrives within
+ * 5 ms (earlier work queued on the stream, or a failed launch) the call blocks in hipStreamSynchronize instead and
+ * reports what that returns.  `prefiltered` is accepted for signature compatibility and has no effect (the reference
+ * uses it only to trap the device when a point it was promised to be visible is culled, auxiliary.h:156-160).
  *
  *   P, D, M          #Gaussians, active SH degree (0..3), SH coefficients per Gaussian (0 if shs == NULL)
  *   means3D (P,3); scales (P,3)|NULL; rotations (P,4)|NULL; opacities (P); shs (P,M,3)|NULL;
@@ -110,16 +121,16 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                    const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                    int prefiltered, int skip_color, unsigned flags, int32_t* radii, void* geom,
-                   int64_t* num_rendered_host);
+                   int64_t counts_host[2]);
 
-/* K3 + K4 + K5: emit one (tile, Gaussian) pair per touched tile in depth order of the Gaussians, stable
- * radix sort on the tile id (together with the depth ordering done in gsr_preprocess this yields exactly the
- * order of the reference's stable sort on the low gsr_sort_key_bits() bits of (tile << 32 | depth bits)),
- * and per-tile [begin,end) ranges.
+/* K3 + K4 + K5: the per-tile instance lists (the reference's point_list) and their [begin,end) ranges, in exactly the
+ * order of the reference's stable sort on the low gsr_sort_key_bits() bits of (tile << 32 | depth bits): the Gaussians
+ * were depth-ordered by gsr_preprocess; here one (group, Gaussian) pair per 8x8-tile group a Gaussian reaches is emitted
+ * in that order, stably sorted by group in one radix pass, and expanded group by group into the tiles' lists
+ * (gsr_binning.hip).  R and G are the two counts gsr_preprocess returned.
  * Reference: duplicateWithKeys + cub::DeviceRadixSort::SortPairs + identifyTileRanges,
- * rasterizer_impl.cu:248-271.  `binning` holds sizes[1] bytes for this R. */
-int gsr_bin(void* stream, int P, int64_t R, int W, int H, const int32_t* radii, const void* geom, void* binning,
-            void* image);
+ * rasterizer_impl.cu:248-271.  `binning` holds sizes[1] bytes for this (R, G). */
+int gsr_bin(void* stream, int P, int64_t R, int64_t G, int W, int H, const void* geom, void* binning, void* image);
 
 /* K6: per-tile front-to-back alpha compositing.  Reference: FORWARD::render,
  * forward.cu:261-409.  out_color (3,H,W), out_depth (1,H,W) are fully written

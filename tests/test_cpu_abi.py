@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_typed():
     # the Python binding types every declared symbol, and nothing that is not declared
     assert sorted(_native.SIGNATURES) == syms
     L = _native.lib()
-    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 2
+    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 3
     assert L.gsr_status_string(0) == b"ok" and b"channels" in L.gsr_status_string(-2)
 
 
@@ -38,10 +38,12 @@ def test_scratch_sizes_and_sort_bits():
     assert L.gsr_sort_key_bits(512, 512) == 43
     assert L.gsr_sort_key_bits(1920, 1080) == 45
     g0, b0, i0 = _native.scratch_sizes(1000, 0, 640, 480)
-    g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480)
-    # per instance: ping-pong tile ids (uint16 while an image has at most 65535 tiles, uint32 beyond) + ping-pong indices
-    assert b0 == 0 and b1 > 5000 * 12 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
-    assert _native.scratch_sizes(2000, 5000, 4112, 4112)[1] > 5000 * 16
+    g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480, 1500)
+    # grouped binning: 4 bytes per tile instance (the point list) + 12 per group instance (ping-pong group ids and indices)
+    assert b0 == 0 and b1 > 5000 * 4 + 1500 * 12 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
+    assert _native.scratch_sizes(2000, 5000, 640, 480, 3000)[1] > b1
+    # beyond 131 072 tiles (2048 groups of 8 x 8) the tile-pair sort: ping-pong tile ids (uint32 there) + ping-pong indices
+    assert _native.scratch_sizes(2000, 5000, 5808, 5808)[1] > 5000 * 16
     with pytest.raises(_native.GsrError):
         _native.scratch_sizes(-1, 0, 640, 480)
 
@@ -61,16 +63,18 @@ def test_argument_validation_needs_no_gpu():
     sz = ctypes.c_size_t(0)
     assert L.gsr_compact_workspace_size(1_000_000, ctypes.byref(sz)) == 0 and sz.value >= 2 * 4 * 977
     assert L.gsr_knn_workspace_size(1000, ctypes.byref(sz)) == 0 and sz.value > 0
-    r = ctypes.c_int64(7)
+    r = (ctypes.c_int64 * 2)(7, 7)
     # (P = 0 is a valid empty call everywhere; no pointer is dereferenced)
     assert L.gsr_preprocess(None, 0, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
-                            0, 0, 0, None, None, ctypes.byref(r)) == 0 and r.value == 0
+                            0, 0, 0, None, None, r) == 0 and r[0] == 0 and r[1] == 0
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
-                            0, 0, 0, None, None, ctypes.byref(r)) == -1
+                            0, 0, 0, None, None, r) == -1
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
                             0, 0, 0, None, None, None) == -1
-    assert L.gsr_bin(None, 10, -1, 64, 64, None, None, None, None) == -1
-    assert L.gsr_bin(None, 10, 1 << 31, 64, 64, None, None, None, ctypes.c_void_p(16)) == -3  # GSR_ERR_TOO_MANY
+    assert L.gsr_bin(None, 10, -1, 0, 64, 64, None, None, None) == -1
+    assert L.gsr_bin(None, 10, 1 << 31, 5, 64, 64, None, None, ctypes.c_void_p(256)) == -3  # GSR_ERR_TOO_MANY
+    assert L.gsr_bin(None, 10, 100, 5, 64, 64, None, None, ctypes.c_void_p(16)) == -1  # scratch must be 256-byte aligned
+    assert L.gsr_bin(None, 10, 100, 101, 64, 64, ctypes.c_void_p(256), ctypes.c_void_p(256), ctypes.c_void_p(256)) == -1  # G <= R
     assert L.gsr_debug_cov3d(None, 10, None, 1.0, None, None) == -1
     assert L.gsr_sh_grad_compose(None, 10, 4, 16, 1, None, None, None, None) == -1  # degree > 3
     assert L.gsr_view_message_plan(None, 10, None, None, None, None, None) == -1
@@ -84,9 +88,9 @@ def test_argument_validation_needs_no_gpu():
     assert b"31-bit" in L.gsr_status_string(-3)
     # per-call flags (ABI 2): unknown bits are rejected before anything else is looked at; the library has no option state
     assert not hasattr(L, "gsr_set_option")
-    one = ctypes.c_void_p(16)
+    one = ctypes.c_void_p(256)
     assert L.gsr_preprocess(None, 10, 3, 16, one, one, 1.0, one, one, one, None, None, one, one, one, 64, 64, 1.0, 1.0,
-                            0, 0, 4, one, one, ctypes.byref(r)) == -1
+                            0, 0, 4, one, one, r) == -1
     assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 8) == -1
     assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, one, one, one, 4) == -1
     assert L.gsr_trace_weights(None, 10, 5, 64, 64, 1, one, one, one, one, one, one, 16) == -1

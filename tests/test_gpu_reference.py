@@ -85,7 +85,11 @@ def test_product_vs_reference_fma(P, W, H, s0, seed):
           f"colour max {float(dc.max()):.2e} p99.99 {float(torch.quantile(dc.flatten()[:4_000_000], 0.9999)):.2e}")
     assert rad_mism <= max(2, P // 2000)
     assert float(torch.quantile(dc.flatten()[:4_000_000], 0.9999)) <= 1e-5
-    assert rel_err(_np(depth), _np(r["depth"])) < 1e-3
+    # depth image (forward.cu:359, 377), same bar as the colour: the FMA build flips a few threshold decisions
+    dd = (depth.detach() - r["depth"]).abs().flatten() / max(1.0, float(r["depth"].abs().max()))
+    print(f"depth max {float(dd.max()):.2e} p99.99 {float(torch.quantile(dd[:4_000_000], 0.9999)):.2e}")
+    assert float(torch.quantile(dd[:4_000_000], 0.9999)) <= 1e-5
+    assert float(dd.max()) < 1e-2
     # gradients
     G = (seed_gradient(H, W, seed) * (H * W)).to(DEV)
     (color * G).sum().backward()

@@ -98,17 +98,35 @@ def _gaussians_under(pixels, W, f, nc_other):
     return mask
 
 
+ROW_REL, ROW_FLOOR, ROW_FRACTION = 1e-3, 1e-7, 1e-3
+
+
 def _assert_grads(tag, got, want, masked, tol=1e-5):
+    """Two bars per gradient tensor (rows = Gaussians, `masked` rows reported but not asserted):
+      1. max |a - b| <= tol * max|b|                      -- the tensor-wide bar of north_star (1e-5);
+      2. per ROW: |a - b| <= ROW_FLOOR * max|b| + ROW_REL * |b_row|  -- so that a Gaussian whose own gradient is a tiny
+         fraction of the tensor's largest cannot be grossly wrong and hide under bar 1.  A row is a
+         cancelling sum over pixels whose binary32 value depends on the summation order (wave reductions + atomics here,
+         per-pixel atomics in the reference), so a FEW rows may exceed the per-row bar by rounding alone: at most
+         ROW_FRACTION of the rows may, and none of them by more than bar 1."""
     worst = 0.0
     for k in GRADS:
         a = got[k].reshape(got[k].shape[0], -1).astype(np.float64)
         b = want[k].reshape(a.shape).astype(np.float64)
         scale = max(np.abs(b).max(), 1e-30)
-        err = np.abs(a - b).max(axis=1) / scale
+        d = np.abs(a - b).max(axis=1)
+        err = d / scale
         e_all, e_kept = float(err.max()), float(err[~masked].max()) if (~masked).any() else 0.0
         worst = max(worst, e_kept)
-        print(f"  {tag} {k}: max err {e_kept:.2e} outside the masked rows ({e_all:.2e} with them)")
+        row = np.abs(b).max(axis=1)
+        bad = (d > ROW_FLOOR * scale + ROW_REL * row) & ~masked
+        live = (row > 0) & ~masked
+        rel = d[live] / np.maximum(row[live], ROW_FLOOR * scale) if live.any() else np.zeros(1)
+        print(f"  {tag} {k}: max err {e_kept:.2e} outside the masked rows ({e_all:.2e} with them); per-row relative error "
+              f"median {np.median(rel):.1e} p99.9 {np.quantile(rel, 0.999):.1e}; rows over the per-row bar {int(bad.sum())} "
+              f"of {int(live.sum())}")
         assert e_kept <= tol, (tag, k, e_kept)
+        assert bad.sum() <= ROW_FRACTION * max(1, int(live.sum())) + 2, (tag, k, int(bad.sum()))
     return worst
 
 
@@ -161,6 +179,7 @@ def test_three_way_parity_forward_and_backward(oracle, P, W, H, s0, seed, D):
     # product vs oracle forward: bit exact (same exp by specification)
     assert np.array_equal(st["n_contrib"], f["n_contrib"]) and np.array_equal(st["final_T"], f["final_T"])
     assert np.array_equal(color, f["color"])
+    assert np.array_equal(depth, f["depth"])  # out_depth, forward.cu:359, 377: the same accumulation as the colour's
 
     # reference vs oracle images: identical decisions except at exp-rounding ties
     flips = _flipped_pixels(r_np["n_contrib"].view(np.uint32), r_np["final_T"], f["n_contrib"], f["final_T"])
@@ -173,6 +192,12 @@ def test_three_way_parity_forward_and_backward(oracle, P, W, H, s0, seed, D):
     assert dc[:, keep].max() <= 1e-5
     cmax = max(1.0, float(np.abs(f["rgb"][vis]).max()))
     assert dc.max() <= 2.1 * cmax / 255.0 + 1e-5  # a flipped 1/255 decision moves a pixel by at most ~alpha (c + C_behind)
+    # the depth image (north_star: "RGB/depth ... within 1e-5"; forward.cu:359, 377) against the reference's own, same bar,
+    # relative to the largest depth of the view (depths are O(distance to the scene), colours O(1))
+    dd = np.abs(r_np["depth"].reshape(-1) - f["depth"].reshape(-1))
+    dscale = max(1.0, float(np.abs(r_np["depth"]).max()))
+    print(f"  depth image: max diff outside the flipped pixels {dd[keep].max():.2e} (with them {dd.max():.2e}), scale {dscale:.2f}")
+    assert dd[keep].max() <= 1e-5 * dscale
 
     # gradients: max error, flipped pixels' Gaussians masked (their rows are reported, not hidden)
     masked = _gaussians_under(flips, W, f, r_np["n_contrib"].view(np.uint32))
