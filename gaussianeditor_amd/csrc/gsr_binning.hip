@@ -286,8 +286,8 @@ static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const va
 // ----------------------------------------------------------------------------------
 // Depth order of the Gaussians + prefix of tiles_touched in that order.
 // ----------------------------------------------------------------------------------
-// `sgx` != 0: the rectangle is reduced to the rectangle of 8x8-tile GROUPS it reaches (row stride sgx) -- what the grouped
-// path emits; sgx == 0: the tile rectangle itself (row stride gx), for the legacy pair sort.
+// `sgx` != 0 (grouped path): block sums of the number of 8x8-tile GROUPS a rectangle reaches; sgx == 0 (legacy pair sort):
+// of its tiles.
 __global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, int gx, int sgx, const uint32_t* __restrict__ order,
                                                                        const uint2* __restrict__ rect,
                                                                        uint32_t* __restrict__ wh_sorted,
@@ -301,17 +301,14 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) sorted_block_sums_kernel(int P, i
   // What the emit kernel needs of it is left in depth order, so that it reads everything coalesced.
   const uint2 rc = i < P ? rect[order[i]] : make_uint2(0u, 0u);
   const uint32_t w = rc.y & 0xffffu, h = rc.y >> 16, x0 = rc.x & 0xffffu, y0 = rc.x >> 16;
-  uint32_t n = w * h, wh = rc.y, org = y0 * (uint32_t)gx + x0;
-  if (sgx != 0 && n != 0) {
-    const uint32_t g0x = x0 >> GROUP_SHIFT, g0y = y0 >> GROUP_SHIFT;
-    const uint32_t nsx = ((x0 + w - 1u) >> GROUP_SHIFT) - g0x + 1u, nsy = ((y0 + h - 1u) >> GROUP_SHIFT) - g0y + 1u;
-    n = nsx * nsy;
-    wh = nsx | (nsy << 16);
-    org = g0y * (uint32_t)sgx + g0x;
+  uint32_t n = w * h, org = y0 * (uint32_t)gx + x0;
+  if (sgx != 0 && n != 0) {  // grouped path: the emit kernel gets the tile rectangle as it is and counts GROUPS
+    n = (((x0 + w - 1u) >> GROUP_SHIFT) - (x0 >> GROUP_SHIFT) + 1u) * (((y0 + h - 1u) >> GROUP_SHIFT) - (y0 >> GROUP_SHIFT) + 1u);
+    org = rc.x;
   }
   if (i < P) {
-    wh_sorted[i] = wh;    // width | height << 16 of the rectangle (tiles, or groups)
-    org_sorted[i] = org;  // id of its first tile / group
+    wh_sorted[i] = rc.y;  // width | height << 16 of the tile rectangle
+    org_sorted[i] = org;  // legacy path: id of its first tile; grouped path: x | y << 16 of its first tile
   }
   uint32_t total;
   (void)block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
@@ -367,8 +364,6 @@ hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, 
 // inside its rectangle gives the tile, rows first as the reference's loops do.
 // Only the tile id is written as key (the depth is implied by the position).
 // ----------------------------------------------------------------------------------
-// The same kernel emits the GROUP instances of the grouped path: the depth-ordered rectangles sorted_block_sums_kernel
-// left are then rectangles of groups, `gx` the number of groups per row and `ranges` null.
 template <class K>
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, int nclear, const Geom g, K* __restrict__ tkeys,
                                                                uint32_t* __restrict__ vals, uint2* __restrict__ ranges) {
@@ -409,6 +404,60 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_keys_kernel(int P, int gx, i
     if ((row + 1u) * wj <= k) row++;
     const uint32_t col = k - row * wj;
     tkeys[boff + s] = (K)(s_org[lo] + row * (uint32_t)gx + col);
+    vals[boff + s] = s_idx[lo];
+  }
+}
+
+// Grouped path: one GROUP INSTANCE per (Gaussian, 8x8-tile group) pair, in depth order, slot-parallel exactly like
+// emit_keys_kernel.  An instance is (key, Gaussian index) with key = group id | local rectangle << 16: the part of the
+// Gaussian's tile rectangle inside the group as x0 | (x1 - 1) << 3 | y0 << 6 | (y1 - 1) << 9 (tile coordinates relative
+// to the group, 0..7) -- all the chunk kernels need to rebuild the 64-bit tile mask, so they never gather anything.
+__device__ __forceinline__ uint32_t group_local_rect(uint32_t x0, uint32_t y0, uint32_t w, uint32_t h, uint32_t gxi, uint32_t gyi) {
+  const uint32_t bx = gxi << GROUP_SHIFT, by = gyi << GROUP_SHIFT;
+  const uint32_t lx0 = max(x0, bx) - bx, lx1 = min(x0 + w, bx + GROUP_EDGE) - bx;  // [lx0, lx1) within 0..8, non-empty
+  const uint32_t ly0 = max(y0, by) - by, ly1 = min(y0 + h, by + GROUP_EDGE) - by;
+  return lx0 | ((lx1 - 1u) << 3) | (ly0 << 6) | ((ly1 - 1u) << 9);
+}
+__global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx, const Geom g, uint32_t* __restrict__ gkeys,
+                                                                 uint32_t* __restrict__ vals) {
+  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
+  __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_xy[GAUSS_BLOCK], s_wh[GAUSS_BLOCK];
+  const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
+  const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
+  // the tile rectangle of the Gaussian in depth order, left there by sorted_block_sums_kernel: no gather in this kernel
+  const uint32_t wh = i < P ? g.dkey[fin ^ 1u][i] : 0u;
+  const uint32_t xy = i < P ? g.dval[fin ^ 1u][i] : 0u;
+  const uint32_t w = wh & 0xffffu, h = wh >> 16, x0 = xy & 0xffffu, y0 = xy >> 16;
+  uint32_t n = 0;
+  if (w * h != 0u)
+    n = (((x0 + w - 1u) >> GROUP_SHIFT) - (x0 >> GROUP_SHIFT) + 1u) * (((y0 + h - 1u) >> GROUP_SHIFT) - (y0 >> GROUP_SHIFT) + 1u);
+  uint32_t total;
+  const uint32_t boff = g.block_offs[blockIdx.x];
+  const uint32_t off = block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
+  s_off[threadIdx.x] = off;
+  s_idx[threadIdx.x] = idx;
+  s_xy[threadIdx.x] = xy;
+  s_wh[threadIdx.x] = wh;
+  if (threadIdx.x == 0) s_off[GAUSS_BLOCK] = total;
+  __syncthreads();
+  for (uint32_t s = threadIdx.x; s < total; s += GAUSS_BLOCK) {
+    // the last j with s_off[j] <= s: s_off[j + 1] > s, so Gaussian j owns at least one slot
+    uint32_t lo = 0, hi = GAUSS_BLOCK;
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {  // GAUSS_BLOCK == 256
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= s) lo = mid; else hi = mid;
+    }
+    const uint32_t k = s - s_off[lo], jxy = s_xy[lo], jwh = s_wh[lo];
+    const uint32_t jx = jxy & 0xffffu, jy = jxy >> 16, jw = jwh & 0xffffu, jh = jwh >> 16;
+    const uint32_t g0x = jx >> GROUP_SHIFT, nsx = ((jx + jw - 1u) >> GROUP_SHIFT) - g0x + 1u;
+    // row = k / nsx without an integer division (k, nsx < 2^24), one correction step each way
+    uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)nsx));
+    if (row * nsx > k) row--;
+    if ((row + 1u) * nsx <= k) row++;
+    const uint32_t gxi = g0x + (k - row * nsx), gyi = (jy >> GROUP_SHIFT) + row;
+    gkeys[boff + s] = (gyi * (uint32_t)sgx + gxi) | (group_local_rect(jx, jy, jw, jh, gxi, gyi) << 16);
     vals[boff + s] = s_idx[lo];
   }
 }
@@ -470,9 +519,103 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
   // Counting sort of the tiles by bucket.  Most tiles of an image fall into a handful of buckets, and LDS atomics on one
   // address serialise, so every bucket has WORK_SUB counters (chosen by the thread's lane): the order inside a bucket is
   // free anyway, and the sort's time stops growing with the number of tiles per bucket.
-  constexpr int WORK_SUB = 16, NCNT = (WORK_BUCKETS + 1) * WORK_SUB;
+  // The kernel is one block on the critical path between the binning and the forward blend, i.e. a chain of dependent
+  // memory round trips: the list lengths are fetched ONCE and kept in LDS (images of up to WORK_LDS_TILES tiles), and
+  // everything nothing waits for (clearing the queue cursors and the forward's work counters) is stored last.
+  constexpr int WORK_SUB = 16, NCNT = (WORK_BUCKETS + 1) * WORK_SUB, WORK_LDS_TILES = 8192;
   __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];
+  __shared__ uint32_t s_len[WORK_LDS_TILES];
+  const bool cached = T <= WORK_LDS_TILES;
+  for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
+  if (tile_total != nullptr) {
+    constexpr int PER = 8;  // consecutive tiles per thread and round: two 16-byte loads, six 16-byte stores
+    uint32_t carry = 0;
+    for (int base = 0; base < T; base += 1024 * PER) {
+      const int i0 = base + (int)threadIdx.x * PER;
+      const bool full = i0 + PER <= T;  // (tile_total / tile_start / ranges are 256-byte aligned, i0 a multiple of 8)
+      uint32_t v[PER], sum = 0;
+      if (full) {
+        const uint4 a0 = reinterpret_cast<const uint4*>(tile_total + i0)[0], a1 = reinterpret_cast<const uint4*>(tile_total + i0)[1];
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = i0 + j < T ? tile_total[i0 + j] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j) sum += v[j];
+      uint32_t chunk;
+      uint32_t run = carry + block_excl_scan_u32<1024>(sum, &chunk, smem);
+      uint32_t st[PER];
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        st[j] = run;
+        run += v[j];
+      }
+      if (full) {
+        reinterpret_cast<uint4*>(tile_start + i0)[0] = make_uint4(st[0], st[1], st[2], st[3]);
+        reinterpret_cast<uint4*>(tile_start + i0)[1] = make_uint4(st[4], st[5], st[6], st[7]);
+#pragma unroll
+        for (int j = 0; j < PER; j += 2)
+          reinterpret_cast<uint4*>(ranges + i0)[j / 2] = make_uint4(v[j] ? st[j] : 0u, v[j] ? st[j] + v[j] : 0u,
+                                                                   v[j + 1] ? st[j + 1] : 0u, v[j + 1] ? st[j + 1] + v[j + 1] : 0u);
+      }
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        if (i0 + j < T) {
+          if (!full) {
+            tile_start[i0 + j] = st[j];
+            ranges[i0 + j] = v[j] ? make_uint2(st[j], st[j] + v[j]) : make_uint2(0u, 0u);
+          }
+          if (cached) s_len[i0 + j] = v[j];
+        }
+      }
+      carry += chunk;
+    }
+    if (threadIdx.x == 0) tile_start[T] = carry;
+  } else if (cached) {
+    for (int t = threadIdx.x; t < T; t += 1024) {
+      const uint2 r = ranges[t];
+      s_len[t] = r.y - r.x;
+    }
+  }
+  __syncthreads();  // (s_len; without the cache the block reads its own `ranges` stores below)
+  auto len_of = [&](int t) -> uint32_t {
+    if (cached) return s_len[t];
+    const uint2 r = ranges[t];
+    return r.y - r.x;
+  };
+  const uint32_t sub = threadIdx.x & (WORK_SUB - 1);
+  auto bucket_of = [](uint32_t len) -> uint32_t {
+    if (len == 0) return WORK_BUCKETS;  // empty tiles: last
+    const uint32_t c = (len + 63u) / 64u;
+    return (uint32_t)(WORK_BUCKETS - 1) - min(c - 1u, (uint32_t)(WORK_BUCKETS - 1));
+  };
+  for (int t = threadIdx.x; t < T; t += 1024) atomicAdd(&cnt[bucket_of(len_of(t)) * WORK_SUB + sub], 1u);
+  __syncthreads();
+  {  // exclusive scan over the NCNT counters in (bucket, sub) order: counts -> cursors (one block scan, 3 counters a thread)
+    constexpr int CPT = (NCNT + 1023) / 1024;
+    const int i0 = (int)threadIdx.x * CPT;
+    uint32_t v[CPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      v[j] = i0 + j < NCNT ? cnt[i0 + j] : 0u;
+      sum += v[j];
+    }
+    uint32_t all;
+    uint32_t run = block_excl_scan_u32<1024>(sum, &all, smem);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      if (i0 + j < NCNT) cnt[i0 + j] = run;
+      if (i0 + j == WORK_BUCKETS * WORK_SUB) meta[0] = run;  // number of non-empty tiles
+      run += v[j];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < T; t += 1024) {
+    const uint32_t pos = atomicAdd(&cnt[bucket_of(len_of(t)) * WORK_SUB + sub], 1u);
+    order[pos] = (uint32_t)t;
+  }
   // per-quadrant work counters of the forward blend (the items of a quadrant combine their counts with atomicMax)
   for (int i = threadIdx.x; i < 4 * T; i += 1024) est[i] = 0u;
   // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
@@ -481,72 +624,17 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
     queues[(size_t)i * QUEUE_STRIDE] = 0u;      // taken from the front / counter
     queues[(size_t)i * QUEUE_STRIDE + 1] = 0u;  // (second word of the line: spare)
   }
-  for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
-  if (tile_total != nullptr) {
-    constexpr int PER = 8;  // consecutive tiles per thread and round
-    uint32_t carry = 0;
-    for (int base = 0; base < T; base += 1024 * PER) {
-      const int i0 = base + (int)threadIdx.x * PER;
-      uint32_t v[PER], sum = 0;
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        v[j] = i0 + j < T ? tile_total[i0 + j] : 0u;
-        sum += v[j];
-      }
-      uint32_t chunk;
-      uint32_t run = carry + block_excl_scan_u32<1024>(sum, &chunk, smem);
-#pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        if (i0 + j < T) {
-          tile_start[i0 + j] = run;
-          ranges[i0 + j] = v[j] ? make_uint2(run, run + v[j]) : make_uint2(0u, 0u);
-        }
-        run += v[j];
-      }
-      carry += chunk;
-    }
-    if (threadIdx.x == 0) tile_start[T] = carry;
-  }
-  __syncthreads();  // (the block reads its own `ranges` stores below)
-  const uint32_t sub = threadIdx.x & (WORK_SUB - 1);
-  auto bucket_of = [](uint32_t len) -> uint32_t {
-    if (len == 0) return WORK_BUCKETS;  // empty tiles: last
-    const uint32_t c = (len + 63u) / 64u;
-    return (uint32_t)(WORK_BUCKETS - 1) - min(c - 1u, (uint32_t)(WORK_BUCKETS - 1));
-  };
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint2 r = ranges[t];
-    atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
-  }
-  __syncthreads();
-  {  // exclusive scan over the NCNT counters in (bucket, sub) order: counts -> cursors
-    uint32_t carry = 0;
-    for (int base = 0; base < NCNT; base += 1024) {
-      const int i = base + (int)threadIdx.x;
-      const uint32_t v = i < NCNT ? cnt[i] : 0u;
-      uint32_t chunk;
-      const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
-      if (i < NCNT) cnt[i] = carry + ex;
-      if (i == WORK_BUCKETS * WORK_SUB) meta[0] = carry + ex;  // number of non-empty tiles
-      carry += chunk;
-    }
-  }
-  __syncthreads();
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint2 r = ranges[t];
-    const uint32_t pos = atomicAdd(&cnt[bucket_of(r.y - r.x) * WORK_SUB + sub], 1u);
-    order[pos] = (uint32_t)t;
-  }
 }
 
 // ----------------------------------------------------------------------------------
 // Grouped path, step 2: ONE stable radix pass over the group instances (key = group id, < 2^BITS), whose output leaves
 // each group's segment padded to whole chunks: segment s starts at chunk * (number of chunks of the groups before it).
 // ----------------------------------------------------------------------------------
-// histogram of the pass + the padding value into every slot of the output side (the scatter overwrites the real ones:
-// what remains are the padding slots between the segments and behind the last one)
+// histogram of the pass + the padding value into every KEY slot of the output side (the scatter overwrites the real ones:
+// what remains are the padding slots between the segments and behind the last one; a real key never equals GROUP_PAD,
+// its local rectangle has 12 bits)
 template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) group_hist_kernel(const uint16_t* __restrict__ keys, int64_t n,
+__global__ void __launch_bounds__(SORT_THREADS) group_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
                                                                  uint32_t* __restrict__ hist, uint32_t nblocks,
                                                                  uint32_t* __restrict__ fill_dst, int64_t fill_n) {
   constexpr int NB = 1 << BITS;
@@ -575,31 +663,32 @@ __global__ void __launch_bounds__(SORT_THREADS) group_hist_kernel(const uint16_t
 
 // sort_scatter_kernel with 2^BITS bins and padded segment starts; ranks from BITS ballots per key (stable).
 template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint16_t* __restrict__ keys_in,
+__global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
-                                                                    uint16_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out, int64_t n,
                                                                     const uint32_t* __restrict__ hist,
                                                                     const uint32_t* __restrict__ bin_total,
-                                                                    uint32_t nblocks, uint32_t chunk) {
+                                                                    uint32_t nblocks, uint32_t chunk,
+                                                                    uint32_t* __restrict__ group_first) {
   constexpr int NB = 1 << BITS, NW = SORT_THREADS / 64, BPT = NB / SORT_THREADS;  // bins per thread (consecutive)
   __shared__ uint16_t cnt[NW][NB];     // per-wave digit counts -> per-wave local bases
   __shared__ uint32_t gbase[NB];       // global position of the block's first key of each digit
   __shared__ uint16_t lexcl[NB];       // position of each digit's run inside the block-sorted order
   __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
-  __shared__ uint16_t skey[SORT_KPB];
+  __shared__ uint32_t skey[SORT_KPB];
   __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
   const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
   const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
-  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
+  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];  // key: group id (the digit) | local rectangle << 16 (payload)
   uint16_t rank[SORT_ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
 #pragma unroll
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
-    key[i] = (uint32_t)keys_in[kc] & (NB - 1);
+    key[i] = keys_in[kc];
     val[i] = vals_in[kc];
   }
   {
@@ -618,8 +707,11 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint1
 #pragma unroll
     for (int j = 0; j < BPT; ++j) {
       gbase[threadIdx.x * BPT + j] = run + mine[j];
+      // row of the group's first chunk in the per-chunk tables (+ one entry behind the last group), for group_colscan_kernel
+      if (blockIdx.x == 0) group_first[threadIdx.x * BPT + j] = run / chunk;
       run += padded[j];
     }
+    if (blockIdx.x == 0 && threadIdx.x == SORT_THREADS - 1) group_first[NB] = run / chunk;
   }
   for (int i = threadIdx.x; i < NW * NB; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
   __syncthreads();
@@ -628,7 +720,7 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint1
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const bool valid = k < n;
-    const uint32_t d = key[i];
+    const uint32_t d = key[i] & (NB - 1);
     uint64_t m = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < BITS; ++b) {
@@ -672,9 +764,9 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint1
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     if (k < n) {
-      const uint32_t d = key[i];
+      const uint32_t d = key[i] & (NB - 1);
       const uint32_t lp = (uint32_t)lexcl[d] + (uint32_t)cnt[w][d] + rank[i];
-      skey[lp] = (uint16_t)d;
+      skey[lp] = key[i];
       sval[lp] = val[i];
     }
   }
@@ -684,9 +776,9 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint1
   for (int i = 0; i < SORT_ITEMS; ++i) {
     const int j = i * SORT_THREADS + (int)threadIdx.x;
     if (j < nvalid) {
-      const uint32_t d = skey[j];
+      const uint32_t kk = skey[j], d = kk & (NB - 1);
       const uint32_t pos = gbase[d] + ((uint32_t)j - (uint32_t)lexcl[d]);
-      keys_out[pos] = (uint16_t)d;
+      keys_out[pos] = kk;
       vals_out[pos] = sval[j];
     }
   }
@@ -698,160 +790,231 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint1
 // wave per chunk, lane t = tile t of the group.
 // ----------------------------------------------------------------------------------
 struct GroupArgs {
-  int gx, gy, sgx, chunk;
-  const uint16_t* gkey;      // sorted + padded group ids
-  const uint32_t* gval;      // sorted + padded Gaussian indices (GROUP_PAD in padding slots)
-  const uint2* rect;         // (P) tile rectangles (Geom::rect)
+  int gx, gy, sgx;
+  size_t chunks;             // upper bound of the number of chunks (Binning::chunks)
+  uint32_t stage_cap;        // scatter pass: entries of the LDS stage (1024 or 2048; + 1 dump slot)
+  const uint32_t* gkey;      // sorted + padded keys: group id | local rectangle << 16; GROUP_PAD in the padding slots
+  const uint32_t* gval;      // sorted + padded Gaussian indices
   uint16_t* chunk_cnt;       // (chunks, 64)
   const uint32_t* chunk_pre; // (chunks, 64)
   const uint32_t* tile_start;
   uint32_t* point_list;
 };
 
-// The tiles of the group at tile origin (gx0, gy0) that the tile rectangle rc = (x | y << 16, w | h << 16) covers:
+// The tiles of its group a group instance covers, from the local rectangle group_local_rect packed:
 // bit (ty & 7) * 8 + (tx & 7), rows 0..3 in `lo`, rows 4..7 in `hi`.
-__device__ __forceinline__ void group_mask(uint2 rc, uint32_t gx0, uint32_t gy0, uint32_t& lo, uint32_t& hi) {
-  const int x0 = (int)(rc.x & 0xffffu) - (int)gx0, y0 = (int)(rc.x >> 16) - (int)gy0;
-  const int x1 = x0 + (int)(rc.y & 0xffffu), y1 = y0 + (int)(rc.y >> 16);
-  const int cx0 = max(x0, 0), cx1 = min(x1, GROUP_EDGE), cy0 = max(y0, 0), cy1 = min(y1, GROUP_EDGE);
-  lo = hi = 0u;
-  if (cx1 <= cx0 || cy1 <= cy0) return;
-  const uint32_t cols = ((1u << (cx1 - cx0)) - 1u) << cx0;  // the covered columns, 8 bits
-  // rows [a, b) of a 4-row half -> one 0x01 per covered row byte, times the column bits (no carries between bytes)
-  auto half = [cols](int a, int b) -> uint32_t {
-    if (b <= a) return 0u;
-    const uint32_t ones = (b - a) >= 4 ? 0xffffffffu : ((1u << (8 * (b - a))) - 1u);
-    return ((ones << (8 * a)) & 0x01010101u) * cols;
-  };
-  lo = half(min(cy0, 4), min(cy1, 4));
-  hi = half(max(cy0 - 4, 0), max(cy1 - 4, 0));
+__device__ __forceinline__ void group_mask(uint32_t lr, uint32_t& lo, uint32_t& hi) {
+  const uint32_t x0 = lr & 7u, x1 = (lr >> 3) & 7u, y0 = (lr >> 6) & 7u, y1 = (lr >> 9) & 7u;  // inclusive bounds
+  const uint32_t cols = ((2u << (x1 - x0)) - 1u) << x0;                                      // the covered columns, 8 bits
+  // one 0x01 byte per covered row, times the column bits (no carries between the bytes)
+  const uint64_t rows = ((~0ull >> (56u - 8u * (y1 - y0))) << (8u * y0)) & 0x0101010101010101ull;
+  lo = (uint32_t)rows * cols;
+  hi = (uint32_t)(rows >> 32) * cols;
 }
 
-// 64 x 64 bit transpose across the wave: in: lane j holds the tile mask of batch item j; out: lane t holds the set of
-// items that touch tile t.  One ballot per tile, its 64-bit result written into lane t with v_writelane_b32 (clang exposes
-// no builtin for it; the lane select is an inline constant, the data a plain SGPR).
-// HAZARD (measured, profiles/r03_a: bits 30 / 62 / 63 came out wrong, exactly the three places where hipcc had scheduled
-// nothing between the compare and the write): v_writelane_b32 does NOT interlock on an SGPR a VALU instruction has just
-// written -- the ISA manual lists 4 wait states for the lane-select operand, the data operand behaves the same.  The
-// hazard recogniser does not look into inline assembly, so four ballots are formed first and ONE block issues
-// `s_nop 3` followed by their eight writes: every SGPR read is at least 4 wait states behind the compare that wrote it.
-template <int T0>
-__device__ __forceinline__ void transpose_four(uint32_t src, uint32_t& a, uint32_t& b) {
-  const uint64_t b0 = __ballot((src >> ((T0 + 0) & 31)) & 1u), b1 = __ballot((src >> ((T0 + 1) & 31)) & 1u);
-  const uint64_t b2 = __ballot((src >> ((T0 + 2) & 31)) & 1u), b3 = __ballot((src >> ((T0 + 3) & 31)) & 1u);
-  const uint32_t l0 = (uint32_t)b0, h0 = (uint32_t)(b0 >> 32), l1 = (uint32_t)b1, h1 = (uint32_t)(b1 >> 32);
-  const uint32_t l2 = (uint32_t)b2, h2 = (uint32_t)(b2 >> 32), l3 = (uint32_t)b3, h3 = (uint32_t)(b3 >> 32);
-  asm volatile(
-      "s_nop 3\n\t"
-      "v_writelane_b32 %0, %2, %10\n\t"
-      "v_writelane_b32 %1, %3, %10\n\t"
-      "v_writelane_b32 %0, %4, %11\n\t"
-      "v_writelane_b32 %1, %5, %11\n\t"
-      "v_writelane_b32 %0, %6, %12\n\t"
-      "v_writelane_b32 %1, %7, %12\n\t"
-      "v_writelane_b32 %0, %8, %13\n\t"
-      "v_writelane_b32 %1, %9, %13"
-      : "+v"(a), "+v"(b)
-      : "s"(l0), "s"(h0), "s"(l1), "s"(h1), "s"(l2), "s"(h2), "s"(l3), "s"(h3), "n"(T0), "n"(T0 + 1), "n"(T0 + 2), "n"(T0 + 3));
-}
-template <int T0>
-__device__ __forceinline__ void transpose_from(uint32_t lo, uint32_t hi, uint32_t& a, uint32_t& b) {
-  if constexpr (T0 < 64) {
-    transpose_four<T0>(T0 < 32 ? lo : hi, a, b);
-    transpose_from<T0 + 4>(lo, hi, a, b);
+// 64 x 64 bit transpose across the wave: in: lane j holds the tile mask of batch item j (lo: tiles 0..31, hi: 32..63);
+// out: lane t holds the set of items that touch tile t.  Recursive block transpose in six butterfly stages: at distance d
+// (32, 16, ..., 1) lane l and lane l ^ d exchange the off-diagonal d x d blocks -- the lane with bit d clear keeps its bits
+// whose index has bit d clear and receives its partner's such bits d places higher; the other lane the mirror image.
+//   d = 32  one v_permlane32_swap of the two halves;
+//   d < 32  per 32-bit half: the partner's word (ds_swizzle xor 16 / 4, DPP row_ror:8 / quad_perm for 8 / 2 / 1), rotated
+//           into place (v_alignbit_b32) and merged under a per-lane mask (v_bfi_b32);
+// 31 instructions for the 4096 bits.  (The first version formed one ballot per tile and wrote it into lane t with
+// v_writelane_b32: 272 instructions, and v_writelane_b32 turned out NOT to interlock on an SGPR a VALU instruction has
+// just written -- three tile columns came out wrong exactly where hipcc had scheduled nothing in between.)
+struct TransposeLane {
+  uint32_t keep[5], rot[5];  // stages d = 16, 8, 4, 2, 1
+};
+__device__ __forceinline__ TransposeLane transpose_lane_consts(int lane) {
+  constexpr uint32_t LOW[5] = {0x0000ffffu, 0x00ff00ffu, 0x0f0f0f0fu, 0x33333333u, 0x55555555u};
+  TransposeLane c;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const int d = 16 >> i;
+    const bool up = (lane & d) != 0;
+    c.keep[i] = up ? ~LOW[i] : LOW[i];
+    c.rot[i] = up ? (uint32_t)d : (uint32_t)(32 - d);  // rotate right: the partner's bits move d places down / up
   }
+  return c;
 }
-__device__ __forceinline__ void transpose_masks(uint32_t lo, uint32_t hi, uint32_t& wlo, uint32_t& whi) {
-  uint32_t a = 0, b = 0;
-  transpose_from<0>(lo, hi, a, b);
-  wlo = a;
-  whi = b;
+template <int STAGE>
+__device__ __forceinline__ uint32_t transpose_partner(uint32_t x) {
+  const int v = (int)x;
+  if constexpr (STAGE == 0) return (uint32_t)__builtin_amdgcn_ds_swizzle(v, 0x401f);              // lane ^ 16
+  else if constexpr (STAGE == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);  // row_ror:8 = lane ^ 8
+  else if constexpr (STAGE == 2) return (uint32_t)__builtin_amdgcn_ds_swizzle(v, 0x101f);         // lane ^ 4
+  else if constexpr (STAGE == 3) return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  else return (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, false);                  // quad_perm [1,0,3,2]
+}
+template <int STAGE>
+__device__ __forceinline__ void transpose_stage(const TransposeLane& c, uint32_t& lo, uint32_t& hi) {
+  const uint32_t pl = transpose_partner<STAGE>(lo), ph = transpose_partner<STAGE>(hi);
+  const uint32_t rl = __builtin_amdgcn_alignbit(pl, pl, c.rot[STAGE]), rh = __builtin_amdgcn_alignbit(ph, ph, c.rot[STAGE]);
+  lo = (c.keep[STAGE] & lo) | (~c.keep[STAGE] & rl);  // v_bfi_b32
+  hi = (c.keep[STAGE] & hi) | (~c.keep[STAGE] & rh);
+}
+__device__ __forceinline__ void transpose_masks(const TransposeLane& c, uint32_t lo, uint32_t hi, uint32_t& wlo, uint32_t& whi) {
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);  // [lo.lower | hi.lower], [lo.upper | hi.upper]
+    lo = r[0];
+    hi = r[1];
+  }
+  transpose_stage<0>(c, lo, hi);
+  transpose_stage<1>(c, lo, hi);
+  transpose_stage<2>(c, lo, hi);
+  transpose_stage<3>(c, lo, hi);
+  transpose_stage<4>(c, lo, hi);
+  wlo = lo;
+  whi = hi;
 }
 
 // SCATTER = false: count pass (chunk_cnt[c][t] = instances of tile t in chunk c).
 // SCATTER = true:  lane t appends the Gaussians of its tile, batch by batch in item order, at
 //                  tile_start[tile] + chunk_pre[c][t]: the reference's point_list.
-template <bool SCATTER>
+// NB = 64-item batches per chunk; all of a chunk's loads are issued before anything is used.
+// The appended indices do not leave the wave one by one -- 64 lanes storing 4 bytes each to 64 different lists is one
+// L2 request per element (measured: 47 us for 4.8 M elements, 10x the time of everything else in the kernel) -- but
+// through an LDS stage of (index, destination) pairs: lane t deposits its tile's new entries in consecutive slots, and
+// when the stage is full (or the chunk done) the wave writes the slots out with consecutive lanes on consecutive slots,
+// so a tile's run leaves as one or two requests.  The stage (dynamic LDS) holds `stage_cap` entries + one dump slot;
+// a batch with more entries than that (64 items x up to 64 tiles) is taken in halves or quarters of its items (a
+// quarter, 16 items, never exceeds 1024 entries <= stage_cap).
+template <bool SCATTER, int NB>
 __global__ void __launch_bounds__(64) group_chunk_kernel(const GroupArgs a) {
-  const size_t c = blockIdx.x;
+  extern __shared__ __align__(8) unsigned char stage_raw[];
+  uint2* const stage = reinterpret_cast<uint2*>(stage_raw);
+  // Workgroup b runs on XCD b % 8 (tools/microbench/placement.hip), and the XCDs' L2s are separate: the chunks are dealt so
+  // that every XCD gets a CONTIGUOUS eighth of them.  Consecutive chunks append to the same tiles' lists; written through
+  // one L2 the pieces of a list merge into whole lines there instead of reaching memory as eight XCDs' partial lines.
+  const size_t c = (size_t)(blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);  // (the grid is a multiple of 8)
+  if (c >= a.chunks) return;
   const int lane = (int)threadIdx.x;
-  const size_t base = c * (size_t)a.chunk;
-  if (a.gval[base] == GROUP_PAD) return;  // behind the last chunk (the grid is an upper bound)
-  const uint32_t s = (uint32_t)a.gkey[base];
-  const uint32_t gx0 = (s % (uint32_t)a.sgx) << GROUP_SHIFT, gy0 = (s / (uint32_t)a.sgx) << GROUP_SHIFT;
-  uint32_t cnt = 0;
-  uint32_t* dst = nullptr;
-  if (SCATTER) {
-    const uint32_t tx = gx0 + (uint32_t)(lane & 7), ty = gy0 + (uint32_t)(lane >> 3);
-    const bool tile_ok = tx < (uint32_t)a.gx && ty < (uint32_t)a.gy;  // (a lane without a tile never sees a set bit)
-    dst = a.point_list + (tile_ok ? a.tile_start[ty * (uint32_t)a.gx + tx] + a.chunk_pre[c * GROUP_TILES + lane] : 0u);
+  const size_t base = c * (size_t)(64 * NB);
+  uint32_t key[NB], idx[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    key[b] = a.gkey[base + (size_t)b * 64 + lane];
+    idx[b] = SCATTER ? a.gval[base + (size_t)b * 64 + lane] : 0u;
   }
-  for (int b = 0; b < a.chunk; b += 64) {
-    const uint32_t idx = a.gval[base + b + lane];
-    const bool valid = idx != GROUP_PAD;
-    if (__ballot(valid) == 0ull) break;  // padding only follows the items
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)key[0]);
+  if (first == GROUP_PAD) return;  // behind the last chunk (the grid is an upper bound)
+  const TransposeLane tc = transpose_lane_consts(lane);
+  const uint32_t cap = a.stage_cap;
+  uint32_t cnt = 0, g = 0, staged = 0;  // g: where in point_list this lane's tile continues
+  if (SCATTER) {
+    const uint32_t s = first & 0xffffu;
+    const uint32_t tx = ((s % (uint32_t)a.sgx) << GROUP_SHIFT) + (uint32_t)(lane & 7);
+    const uint32_t ty = ((s / (uint32_t)a.sgx) << GROUP_SHIFT) + (uint32_t)(lane >> 3);
+    const bool tile_ok = tx < (uint32_t)a.gx && ty < (uint32_t)a.gy;  // (a lane without a tile never sees a set bit)
+    g = tile_ok ? a.tile_start[ty * (uint32_t)a.gx + tx] + a.chunk_pre[c * GROUP_TILES + lane] : 0u;
+  }
+  auto flush = [&]() {
+    __syncthreads();  // (one wave: orders the LDS writes of all lanes before the reads)
+    for (uint32_t e = (uint32_t)lane; e < staged; e += 64u) {
+      const uint2 x = stage[e];
+      a.point_list[x.y] = x.x;
+    }
+    __syncthreads();
+    staged = 0;
+  };
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const bool valid = key[b] != GROUP_PAD;
+    if (b > 0 && __ballot(valid) == 0ull) break;  // padding only follows the items
     uint32_t lo = 0u, hi = 0u;
-    if (valid) group_mask(a.rect[idx], gx0, gy0, lo, hi);
-    uint32_t wlo, whi;
-    transpose_masks(lo, hi, wlo, whi);
+    if (valid) group_mask(key[b] >> 16, lo, hi);
+    uint32_t wlo, whi;  // lane t: the batch items (bit j = item j) that touch tile t
+    transpose_masks(tc, lo, hi, wlo, whi);
     if (!SCATTER) {
       cnt += (uint32_t)__popc(wlo) + (uint32_t)__popc(whi);
     } else {
-      uint64_t W = ((uint64_t)whi << 32) | wlo;
-      while (__ballot(W != 0ull) != 0ull) {
-        const int j = W ? (int)__builtin_ctzll(W) : 0;
-        const uint32_t v = (uint32_t)__shfl((int)idx, j, 64);
-        if (W) {
-          *dst++ = v;
-          W &= W - 1ull;
+      const uint32_t nl = (uint32_t)__popc(wlo), nh = (uint32_t)__popc(whi);
+      const uint32_t tot_l = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(nl), 63);
+      const uint32_t tot_h = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_dpp(nh), 63);
+      const int nparts = tot_l + tot_h <= cap ? 1 : (max(tot_l, tot_h) <= cap ? 2 : 4);  // (uniform)
+      for (int part = 0; part < nparts; ++part) {
+        // this part's items as two 32-bit streams: A = items 0..31, B = items 32..63; A's entries precede B's
+        uint32_t wa = wlo, wb = whi;
+        if (nparts == 2) {
+          wa = part == 0 ? wlo : 0u;
+          wb = part == 0 ? 0u : whi;
+        } else if (nparts == 4) {
+          const uint32_t m = 0xffffu << (16 * (part & 1));
+          wa = part < 2 ? (wlo & m) : 0u;
+          wb = part < 2 ? 0u : (whi & m);
         }
+        const uint32_t na = (uint32_t)__popc(wa), np = na + (uint32_t)__popc(wb);
+        const uint32_t incl = wave_incl_scan_dpp(np);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (staged + total > cap) flush();
+        uint32_t curA = staged + incl - np, curB = curA + na, gA = g, gB = g + na;
+        // one entry of each stream per round: the two cross-lane reads (ds_bpermute) travel together; a lane whose
+        // stream is exhausted writes into the dump slot behind the stage instead of branching
+        while (__ballot((wa | wb) != 0u) != 0ull) {
+          const bool va = wa != 0u, vb = wb != 0u;
+          const int ja = va ? __builtin_ctz(wa) : 0, jb = vb ? 32 + __builtin_ctz(wb) : 0;
+          const uint32_t xa = (uint32_t)__shfl((int)idx[b], ja, 64), xb = (uint32_t)__shfl((int)idx[b], jb, 64);
+          stage[va ? curA : cap] = make_uint2(xa, gA);
+          stage[vb ? curB : cap] = make_uint2(xb, gB);
+          curA += va ? 1u : 0u;
+          gA += va ? 1u : 0u;
+          curB += vb ? 1u : 0u;
+          gB += vb ? 1u : 0u;
+          wa &= wa - 1u;
+          wb &= wb - 1u;
+        }
+        staged += total;
+        g += np;
       }
     }
   }
+  if (SCATTER) flush();
   if (!SCATTER) a.chunk_cnt[c * GROUP_TILES + lane] = (uint16_t)cnt;
 }
 
 // Column scan: one workgroup per group; its chunks are consecutive rows [first, first + n) of the count table.  The
-// waves take contiguous slabs of rows: slab sums -> exclusive prefix over the slabs (LDS) -> rescan with the offsets.
-constexpr int COLSCAN_WAVES = 8;
-__global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int gx, int gy, int sgx, int groups, uint32_t chunk,
-                                                                          const uint32_t* __restrict__ bin_total,
+// waves take contiguous slabs of rows: slab sums -> exclusive prefix over the slabs (LDS) -> the rows' prefixes.  A wave
+// keeps up to COLSCAN_REG rows in registers between the two steps (all loads of a slab in flight together; longer slabs
+// are read twice).
+constexpr int COLSCAN_WAVES = 16, COLSCAN_REG = 16;
+__global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int gx, int gy, int sgx,
+                                                                          const uint32_t* __restrict__ group_first,
                                                                           const uint16_t* __restrict__ chunk_cnt,
                                                                           uint32_t* __restrict__ chunk_pre,
                                                                           uint32_t* __restrict__ tile_total) {
-  constexpr int NT = COLSCAN_WAVES * 64;
-  __shared__ uint32_t red[COLSCAN_WAVES];
   __shared__ uint32_t slab[COLSCAN_WAVES][GROUP_TILES];
   const uint32_t s = blockIdx.x;
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
-  // rows of the groups before this one
-  uint32_t before = 0;
-  for (uint32_t g = threadIdx.x; g < s; g += NT) before += (bin_total[g] + chunk - 1u) / chunk;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) before += (uint32_t)__shfl_xor((int)before, d, 64);
-  if (lane == 0) red[w] = before;
-  __syncthreads();
-  uint32_t first = 0;
-#pragma unroll
-  for (int i = 0; i < COLSCAN_WAVES; ++i) first += red[i];
-  const uint32_t n = (bin_total[s] + chunk - 1u) / chunk;
+  const uint32_t first = group_first[s], n = group_first[s + 1] - first;  // (left by the group sort's scatter kernel)
   const uint32_t per = (n + COLSCAN_WAVES - 1) / COLSCAN_WAVES;
   const uint32_t r0 = min(n, (uint32_t)w * per), r1 = min(n, r0 + per);
+  const uint16_t* __restrict__ src = chunk_cnt + (size_t)(first + r0) * GROUP_TILES + lane;
+  uint32_t* __restrict__ out = chunk_pre + (size_t)(first + r0) * GROUP_TILES + lane;
+  const uint32_t rows = r1 - r0;
+  uint32_t v[COLSCAN_REG];
   uint32_t sum = 0;
-  for (uint32_t r = r0; r < r1; ++r) sum += chunk_cnt[(size_t)(first + r) * GROUP_TILES + lane];
+#pragma unroll
+  for (int i = 0; i < COLSCAN_REG; ++i) v[i] = (uint32_t)i < rows ? (uint32_t)src[(size_t)i * GROUP_TILES] : 0u;
+#pragma unroll
+  for (int i = 0; i < COLSCAN_REG; ++i) sum += v[i];
+  for (uint32_t r = COLSCAN_REG; r < rows; ++r) sum += src[(size_t)r * GROUP_TILES];
   slab[w][lane] = sum;
   __syncthreads();
   uint32_t run = 0, total = 0;
 #pragma unroll
   for (int i = 0; i < COLSCAN_WAVES; ++i) {
-    const uint32_t v = slab[i][lane];
-    run += i < w ? v : 0u;
-    total += v;
+    const uint32_t x = slab[i][lane];
+    run += i < w ? x : 0u;
+    total += x;
   }
-  for (uint32_t r = r0; r < r1; ++r) {
-    const size_t o = (size_t)(first + r) * GROUP_TILES + lane;
-    chunk_pre[o] = run;
-    run += chunk_cnt[o];
+#pragma unroll
+  for (int i = 0; i < COLSCAN_REG; ++i) {
+    if ((uint32_t)i < rows) out[(size_t)i * GROUP_TILES] = run;
+    run += v[i];
+  }
+  for (uint32_t r = COLSCAN_REG; r < rows; ++r) {
+    out[(size_t)r * GROUP_TILES] = run;
+    run += src[(size_t)r * GROUP_TILES];
   }
   if (w == 0) {
     const uint32_t tx = ((s % (uint32_t)sgx) << GROUP_SHIFT) + (uint32_t)(lane & 7);
@@ -860,28 +1023,41 @@ __global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int g
   }
 }
 
+template <bool SCATTER>
+static void launch_chunks(hipStream_t s, const Binning& b, const GroupArgs& a) {
+  const dim3 grid((unsigned)((b.chunks + 7) / 8 * 8)), block(64);  // a multiple of 8: see the chunk -> XCD dealing in the kernel
+  const size_t lds = SCATTER ? sizeof(uint2) * ((size_t)a.stage_cap + 1) : 0;
+  switch (b.chunk / 64) {
+    case 1: hipLaunchKernelGGL((group_chunk_kernel<SCATTER, 1>), grid, block, lds, s, a); break;
+    case 2: hipLaunchKernelGGL((group_chunk_kernel<SCATTER, 2>), grid, block, lds, s, a); break;
+    case 4: hipLaunchKernelGGL((group_chunk_kernel<SCATTER, 4>), grid, block, lds, s, a); break;
+    default: hipLaunchKernelGGL((group_chunk_kernel<SCATTER, 8>), grid, block, lds, s, a); break;
+  }
+}
+
 template <int BITS>
-static void launch_grouped(hipStream_t s, int P, int gx, int gy, const Geom& g, const Binning& b, const Image& im) {
+static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, const Geom& g, const Binning& b, const Image& im) {
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   const int64_t padded = b.chunks * (int64_t)b.chunk;
-  hipLaunchKernelGGL(emit_keys_kernel<uint16_t>, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, 0, g, b.gkey[0], b.gval[0],
-                     (uint2*)nullptr);
-  hipLaunchKernelGGL(group_hist_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint16_t*)b.gkey[0], b.G,
-                     b.ghist, b.sort_blocks, b.gval[1], padded);
+  hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0]);
+  hipLaunchKernelGGL(group_hist_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint32_t*)b.gkey[0], b.G,
+                     b.ghist, b.sort_blocks, b.gkey[1], padded);
   hipLaunchKernelGGL(sort_scan_kernel, dim3(1 << BITS), dim3(SORT_THREADS), 0, s, b.ghist, b.gbin_total, b.sort_blocks);
-  hipLaunchKernelGGL(group_scatter_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint16_t*)b.gkey[0],
+  hipLaunchKernelGGL(group_scatter_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint32_t*)b.gkey[0],
                      (const uint32_t*)b.gval[0], b.gkey[1], b.gval[1], b.G, (const uint32_t*)b.ghist,
-                     (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk);
+                     (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk, b.group_first);
   GroupArgs a;
-  a.gx = gx; a.gy = gy; a.sgx = b.sgx; a.chunk = b.chunk;
-  a.gkey = b.gkey[1]; a.gval = b.gval[1]; a.rect = g.rect;
+  a.gx = gx; a.gy = gy; a.sgx = b.sgx; a.chunks = (size_t)b.chunks;
+  // stage of the scatter pass: a whole chunk's entries when they fit 1024 (8 KB of LDS: 20 waves per CU), else 2048
+  a.stage_cap = (R / b.G + 1) * (int64_t)b.chunk <= 820 ? 1024u : 2048u;
+  a.gkey = b.gkey[1]; a.gval = b.gval[1];
   a.chunk_cnt = b.chunk_cnt; a.chunk_pre = b.chunk_pre; a.tile_start = b.tile_start; a.point_list = b.point_list;
-  hipLaunchKernelGGL(group_chunk_kernel<false>, dim3((unsigned)b.chunks), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(group_colscan_kernel, dim3(b.groups), dim3(COLSCAN_WAVES * 64), 0, s, gx, gy, b.sgx, b.groups,
-                     (uint32_t)b.chunk, (const uint32_t*)b.gbin_total, (const uint16_t*)b.chunk_cnt, b.chunk_pre, b.tile_total);
+  launch_chunks<false>(s, b, a);
+  hipLaunchKernelGGL(group_colscan_kernel, dim3(b.groups), dim3(COLSCAN_WAVES * 64), 0, s, gx, gy, b.sgx,
+                     (const uint32_t*)b.group_first, (const uint16_t*)b.chunk_cnt, b.chunk_pre, b.tile_total);
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
                      im.queue_heads, im.work_est, (const uint32_t*)b.tile_total, b.tile_start);
-  hipLaunchKernelGGL(group_chunk_kernel<true>, dim3((unsigned)b.chunks), dim3(64), 0, s, a);
+  launch_chunks<true>(s, b, a);
 }
 
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im) {
@@ -894,8 +1070,8 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const G
     return hipGetLastError();
   }
   if (!b.legacy) {
-    if (b.group_bits == 8) launch_grouped<8>(s, P, gx, gy, g, b, im);
-    else launch_grouped<11>(s, P, gx, gy, g, b, im);
+    if (b.group_bits == 8) launch_grouped<8>(s, P, R, gx, gy, g, b, im);
+    else launch_grouped<11>(s, P, R, gx, gy, g, b, im);
     return hipGetLastError();
   }
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;

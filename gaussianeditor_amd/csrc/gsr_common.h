@@ -22,7 +22,7 @@ constexpr int GROUP_SHIFT = 3;
 constexpr int GROUP_EDGE = 1 << GROUP_SHIFT;
 constexpr int GROUP_TILES = GROUP_EDGE * GROUP_EDGE;  // 64 = one wave: lane t owns tile t of the group
 constexpr int GROUP_MAX = 2048;                // images with more groups (> 131 072 tiles) take the two-pass tile sort
-constexpr uint32_t GROUP_PAD = 0xffffffffu;    // Gaussian index held by the padding slots between the groups' segments
+constexpr uint32_t GROUP_PAD = 0xffffffffu;    // key held by the padding slots between the groups' segments
 
 // ----------------------------------------------------------------------------------
 // Opaque scratch layouts.  Every section is 256-byte aligned.
@@ -148,10 +148,12 @@ struct Binning {
   int64_t G;              // group instances
   int64_t chunks;         // upper bound of the number of chunks: floor(G / chunk) + S
   uint32_t sort_blocks;   // ceil(G / SORT_KPB)
-  uint16_t* gkey[2];      // [0]: (G) group ids in emission (= depth) order; [1]: (chunks * chunk) sorted + padded
-  uint32_t* gval[2];      // the Gaussian index of each group instance, same shapes; padding slots hold GROUP_PAD
+  uint32_t* gkey[2];      // [0]: (G) group id | local rectangle << 16, in emission (= depth) order; [1]: (chunks * chunk)
+                          //      sorted by group and padded: padding slots hold GROUP_PAD
+  uint32_t* gval[2];      // the Gaussian index of each group instance, same shapes
   uint32_t* ghist;        // (bins * sort_blocks), bin-major
   uint32_t* gbin_total;   // (bins)
+  uint32_t* group_first;  // (bins + 1) row of each group's first chunk in the per-chunk tables
   uint16_t* chunk_cnt;    // (chunks, 64) instances of tile t in chunk c
   uint32_t* chunk_pre;    // (chunks, 64) the same summed over the earlier chunks of the chunk's group
   uint32_t* tile_total;   // (T) instances per tile
@@ -186,13 +188,18 @@ __host__ __device__ inline int64_t group_count(int W, int H) {
   const int64_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return ((gx + GROUP_EDGE - 1) >> GROUP_SHIFT) * ((gy + GROUP_EDGE - 1) >> GROUP_SHIFT);
 }
-// Group instances per chunk: one 64-item batch per wave while that still gives every SIMD of the chip work (4096 chunks),
-// then longer chunks (fewer rows in the per-chunk count tables), at most 8 batches.
+// Group instances per chunk: 1, 2, 4 or 8 batches of 64.  A chunk is one wave and one row of the per-chunk count tables.
+// A chunk wave's time is the sum of its memory and LDS round trips (measured: the kernels are latency bound at any
+// occupancy they reach), so chunks are short while the launch stays within ~16 waves per SIMD.
+#ifndef GSR_GROUP_CHUNKS_TARGET
+#define GSR_GROUP_CHUNKS_TARGET 16384  // (A/B builds override it)
+#endif
+constexpr int GROUP_CHUNKS_TARGET = GSR_GROUP_CHUNKS_TARGET;
 __host__ __device__ inline int group_chunk_items(int64_t G) {
   const int64_t batches = (G + 63) / 64;
-  int64_t per = (batches + 4095) / 4096;
-  per = per < 1 ? 1 : (per > 8 ? 8 : per);
-  return (int)(64 * per);
+  int per = 1;
+  while (per < 8 && batches > (int64_t)GROUP_CHUNKS_TARGET * per) per *= 2;
+  return 64 * per;
 }
 // `legacy`: the caller's choice of path (capi: image size, GSR_BIN_LEGACY); G is ignored on the legacy path.
 __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int64_t G, int W, int H, int legacy) {
@@ -231,7 +238,7 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int64_t 
     b.hist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * SORT_MAX_BINS * (size_t)b.nblocks);
     b.bin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * SORT_MAX_BINS);
     b.gkey[0] = b.gkey[1] = nullptr; b.gval[0] = b.gval[1] = nullptr;
-    b.ghist = b.gbin_total = b.chunk_pre = b.tile_total = b.tile_start = nullptr;
+    b.ghist = b.gbin_total = b.group_first = b.chunk_pre = b.tile_total = b.tile_start = nullptr;
     b.chunk_cnt = nullptr;
   } else {
     const size_t bins = (size_t)1 << b.group_bits, padded = (size_t)b.chunks * (size_t)b.chunk;
@@ -241,10 +248,11 @@ __host__ __device__ inline Binning carve_binning(void* base, int64_t R, int64_t 
     b.tile_start = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (size_t)(T + 1));
     b.gval[0] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * (size_t)b.G);
     b.gval[1] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * padded);
-    b.gkey[0] = (uint16_t*)(p + off);     off += align_up(sizeof(uint16_t) * (size_t)b.G);
-    b.gkey[1] = (uint16_t*)(p + off);     off += align_up(sizeof(uint16_t) * padded);
+    b.gkey[0] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * (size_t)b.G);
+    b.gkey[1] = (uint32_t*)(p + off);     off += align_up(sizeof(uint32_t) * padded);
     b.ghist = (uint32_t*)(p + off);       off += align_up(sizeof(uint32_t) * bins * (size_t)b.sort_blocks);
     b.gbin_total = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * bins);
+    b.group_first = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (bins + 1));
     b.chunk_cnt = (uint16_t*)(p + off);   off += align_up(sizeof(uint16_t) * GROUP_TILES * (size_t)b.chunks);
     b.chunk_pre = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * GROUP_TILES * (size_t)b.chunks);
     b.tkey[0] = b.tkey[1] = nullptr; b.vals[0] = b.vals[1] = nullptr; b.hist = b.bin_total = nullptr;
@@ -350,17 +358,32 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
 
 // Exclusive scan of one value per thread across a block of NT threads (NT multiple of 64, <= 1024).
 // Returns the exclusive prefix; *block_total receives the block sum (valid in all threads).
+// The same with DPP row shifts / row broadcasts: 6 VALU instructions, no LDS round trip.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);  // lanes without a source add 0
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+  v = dpp_add_u32<0x111>(v);       // row_shr:1
+  v = dpp_add_u32<0x112>(v);       // row_shr:2
+  v = dpp_add_u32<0x114>(v);       // row_shr:4
+  v = dpp_add_u32<0x118>(v);       // row_shr:8  -> inclusive scan inside each row of 16
+  v = dpp_add_u32<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+  v = dpp_add_u32<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+  return v;
+}
+
 template <int NT>
 __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t* block_total, uint32_t* smem /* NT/64 + 1 */) {
   constexpr int NW = NT / 64;
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
-  const uint32_t incl = wave_incl_scan_u32(v);
+  const uint32_t incl = wave_incl_scan_dpp(v);
   __syncthreads();  // protect smem reuse across calls
   if (l == 63) smem[w] = incl;
   __syncthreads();
   if (w == 0) {
     uint32_t t = (l < NW) ? smem[l] : 0u;
-    const uint32_t ti = wave_incl_scan_u32(t);
+    const uint32_t ti = wave_incl_scan_dpp(t);
     if (l < NW) smem[l] = ti - t;
     if (l == NW - 1) smem[NW] = ti;
   }

@@ -46,7 +46,9 @@ sgx, sgy = (gx + 7) // 8, (gy + 7) // 8
 S = sgx * sgy
 al = lambda v: (v + 255) // 256 * 256  # noqa: E731
 batches = (G + 63) // 64
-per = min(8, max(1, (batches + 4095) // 4096))
+per = 1
+while per < 8 and batches > 8192 * per:
+    per *= 2
 chunk = 64 * per
 chunks = G // chunk + S
 padded = chunks * chunk
@@ -67,8 +69,8 @@ tile_total = take(4 * T, np.uint32)
 tile_start = take(4 * (T + 1), np.uint32)
 gval0 = take(4 * G, np.uint32)
 gval1 = take(4 * padded, np.uint32)
-gkey0 = take(2 * G, np.uint16)
-gkey1 = take(2 * padded, np.uint16)
+gkey0 = take(4 * G, np.uint32)
+gkey1 = take(4 * padded, np.uint32)
 ghist = take(4 * bins * sort_blocks, np.uint32)
 gbin_total = take(4 * bins, np.uint32)
 chunk_cnt = take(2 * 64 * chunks, np.uint16).reshape(chunks, 64)
@@ -80,15 +82,15 @@ exp_total = rng[:, 1] - rng[:, 0]
 print("tile_total ok:", np.array_equal(tile_total, exp_total), "sum", int(tile_total.sum()), "expected", int(exp_total.sum()))
 bad = np.nonzero(tile_total != exp_total)[0]
 print("  tiles differing:", bad[:20], tile_total[bad[:20]], exp_total[bad[:20]])
-print("gkey0 histogram:", np.bincount(gkey0, minlength=S)[:S], "gbin_total:", gbin_total[:S], "sum", int(gbin_total.sum()))
-real = gval1 != 0xFFFFFFFF
+print("gkey0 histogram:", np.bincount(gkey0 & 0xFFFF, minlength=S)[:S], "gbin_total:", gbin_total[:S], "sum", int(gbin_total.sum()))
+real = gkey1 != 0xFFFFFFFF
 print("real slots in the sorted side:", int(real.sum()), "of", padded)
 cf = 0
 for g in range(S):
     n = int(gbin_total[g])
     nch = (n + chunk - 1) // chunk
     seg = slice(cf * chunk, (cf + nch) * chunk)
-    ok_keys = bool(np.all(gkey1[seg][real[seg]] == g))
+    ok_keys = bool(np.all((gkey1[seg][real[seg]] & 0xFFFF) == g))
     print(f"  group {g}: len {n}, chunks [{cf},{cf + nch}), real in segment {int(real[seg].sum())}, keys ok {ok_keys}, "
           f"count rows sum {int(chunk_cnt[cf:cf + nch].sum())}")
     cf += nch
