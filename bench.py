@@ -71,6 +71,19 @@ def percentile(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
 
 
+def csrc_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: what profiles/traffic_latest.json is stamped with."""
+    import hashlib
+
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaussianeditor_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,20 +174,10 @@ def main():
         return radii
 
     exchange = bucket.sh_exchange
-    try:
-        for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
-            train_step()
-        sync_all()
-    except Exception as e:  # the colour-gradient exchange has only ever run on gloo: keep the run alive if RCCL objects
-        if world == 1 or bucket.sh_exchange != "rgb":
-            raise
-        print(f"[bench] rank {rank}: 'rgb' gradient exchange failed ({type(e).__name__}: {e}); falling back to the dense "
-              "all-reduce of the SH gradient", file=sys.stderr, flush=True)
-        bucket = GradBucket(P, M, dev, sh_exchange="direct")
-        exchange = "direct(fallback)"
-        for _ in range(max(args.warmup, 1)):
-            train_step()
-        sync_all()
+    # (a failing exchange fails the benchmark: it must never silently measure another workload)
+    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+        train_step()
+    sync_all()
     # Timed region: exactly `steps` steps between barrier + synchronize on both sides (the contract's number).  An event
     # per step on the launch stream additionally gives the distribution of the GPU-side step time (median / p10 / p90,
     # SURVEY.md section 8(d)) without adding any synchronisation.
@@ -322,11 +325,17 @@ def main():
 
     # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself; it reports the per-launch value
     # measured with rocprofv3 on this same workload and committed under profiles/ (null for any other workload).
+    # The file is stamped with a hash of the kernel sources it was measured on (tools/stamp_traffic.py); when the sources
+    # have changed since, the number is stale: `traffic` is then null and `traffic_source` says so.
     traffic, traffic_src = None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
         if tj["workload"] == {"gaussians": P, "width": W, "height": H} and dominant in tj["per_launch_bytes"]:
-            traffic, traffic_src = tj["per_launch_bytes"][dominant], tj["source"]
+            if tj.get("csrc_sha16") == csrc_sha16():
+                traffic, traffic_src = tj["per_launch_bytes"][dominant], tj["source"]
+            else:
+                traffic_src = (f"stale: profiles/traffic_latest.json was measured on kernel sources {tj.get('csrc_sha16')}, "
+                               f"this build is {csrc_sha16()}")
     except Exception:
         pass
 

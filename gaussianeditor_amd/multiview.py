@@ -39,7 +39,8 @@ import torch.distributed as dist
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 
-__all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step"]
+__all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step", "batch_loss_scale",
+           "densify_synchronized", "replicas_identical"]
 
 #: bucket layout per Gaussian: name -> number of floats (3M for the SH block is filled in at construction)
 _SLOTS = ("means3D", "sh", "scales", "rotations", "means2D", "opacities")
@@ -297,3 +298,95 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
         work.wait()
         radii = batch_max
     return color, radii, depth, grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Keeping the sharded loop equal to the reference's single-process loop
+# ----------------------------------------------------------------------------------------------------------------------
+def batch_loss_scale(world_size: int, rank: int = 0, per_step: str = "split") -> Dict[str, float]:
+    """Factors for a rank's LOCAL loss terms (its one view) such that the SUM over the ranks -- which is what the gradient
+    exchange forms -- is the batch loss the reference computes in one process over K = world_size views:
+
+      "mean"      a term the reference takes as a MEAN over the stacked batch, e.g. `torch.nn.functional.l1_loss(images,
+                  gt_images)` with images (K,H,W,3) (threestudio/systems/GassuianEditorEdit.py:100): local value x 1/K;
+      "sum"       a term the reference SUMS over the batch, e.g. the perceptual loss `.sum()` (:101-104): x 1;
+      "per_step"  a term computed once per step from the parameters alone, e.g. `gaussian.anchor_loss()` (:133-145,
+                  gaussiansplatting/scene/gaussian_model.py:152-184): every rank holds the same parameters, so either
+                  every rank adds 1/K of it (per_step="split", the default: all replicas run the same code) or rank 0 adds
+                  all of it (per_step="rank0").
+
+    Multiply before backward(); the exchanged gradients are then those of the reference's loss."""
+    K = int(world_size)
+    if K < 1 or not 0 <= int(rank) < K:
+        raise ValueError("batch_loss_scale: need world_size >= 1 and 0 <= rank < world_size")
+    if per_step not in ("split", "rank0"):
+        raise ValueError('per_step must be "split" or "rank0"')
+    return {"mean": 1.0 / K, "sum": 1.0,
+            "per_step": (1.0 / K) if per_step == "split" else (1.0 if int(rank) == 0 else 0.0)}
+
+
+def replicas_identical(tensors, group=None) -> bool:
+    """True iff every rank of `group` holds bit-identical copies of `tensors` (shapes included).  One MAX and one MIN
+    all-reduce over a small per-tensor fingerprint (element count + wrapping sums of the raw 32-bit words, which any
+    single differing word changes).  Collective: every rank must call it."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return True
+    fp = []
+    for t in tensors:
+        raw = t.detach().contiguous().reshape(-1)
+        if raw.element_size() == 4:
+            w = raw.view(torch.int32).to(torch.int64)
+        elif raw.element_size() == 1:
+            w = raw.view(torch.uint8).to(torch.int64)
+        else:
+            w = raw.to(torch.float64).view(torch.int64)
+        pos = torch.arange(1, w.numel() + 1, dtype=torch.int64, device=w.device)
+        fp += [torch.tensor(float(w.numel()), dtype=torch.float64, device=w.device).view(1),
+               w.sum().to(torch.float64).view(1), ((w * (pos % 65521)).sum() % (1 << 52)).to(torch.float64).view(1)]
+    mine = torch.cat(fp) if fp else torch.zeros(1, dtype=torch.float64)
+    hi, lo = mine.clone(), mine.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    return bool(torch.equal(hi, lo))
+
+
+def densify_synchronized(densify_fn, replicated=None, group=None, src: int = 0, check: bool = True):
+    """Run a densification step so that the replicas stay bit-identical.
+
+    `densify_and_split` draws `torch.normal` samples from the process RNG (gaussiansplatting/scene/gaussian_model.py:
+    685-687), and the launcher seeds every rank differently (`pl.seed_everything(cfg.seed + get_rank())`, launch.py:
+    102-103), so unsynchronised replicas diverge at the first split: different new positions, and from then on different
+    gradients, selections and Gaussian counts -- the next gradient exchange would add rows of different Gaussians.
+    Everything else in `densify_and_prune` (:768-809) is a deterministic function of state the exchange already keeps
+    identical on all ranks (parameters, Adam moments, the summed view-space gradient, the batch-max radii).
+
+    So: rank `src` draws one 62-bit seed from its process RNG (its own stream advances by that one draw, so successive
+    densifications get different seeds), broadcasts it, every rank seeds its CPU and device generators with it, runs
+    `densify_fn()` and restores the generators it had before (so the rest of the loop keeps its per-rank randomness, e.g.
+    camera sampling).  With `check` the tensors `replicated()` returns afterwards (parameters, moments, masks, ...) are
+    verified identical on all ranks with `replicas_identical` -- it raises rather than let a diverged replica train on.
+    Returns what `densify_fn` returns."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if multi:
+        seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64) if dist.get_rank(group) == src else torch.zeros(1, dtype=torch.int64)
+        if dist.get_backend(group) == "nccl":
+            seed = seed.cuda()
+        dist.broadcast(seed, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+        seed = int(seed.item())
+    else:
+        seed = None
+    cpu_state = torch.random.get_rng_state()
+    cuda_state = torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None
+    try:
+        if seed is not None:
+            torch.manual_seed(seed)  # seeds the CPU generator and every device generator
+        out = densify_fn()
+    finally:
+        torch.random.set_rng_state(cpu_state)
+        if cuda_state is not None:
+            torch.cuda.set_rng_state_all(cuda_state)
+    if multi and check and replicated is not None:
+        if not replicas_identical(list(replicated()), group=group):
+            raise RuntimeError("densify_synchronized: the replicas differ after the densification step "
+                               "(was the state identical before it? is densify_fn deterministic apart from the RNG?)")
+    return out

@@ -266,3 +266,146 @@ def test_grad_allocator_rides_on_the_autograd_node(oracle, monkeypatch):
     assert "means3D" in calls["a"] and "sh" in calls["a"] and calls["b"] == []
     with pytest.raises(RuntimeError, match="not the output"):
         _C.attach_grad_allocator(torch.zeros(3, requires_grad=True) * 2, None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: what keeps the sharded loop equal to the reference's one-process loop besides the gradient exchange
+# (SURVEY.md section 8(e)): the batch-loss scaling and replica-identical densification.
+# ---------------------------------------------------------------------------------------------------------------------
+def _toy_images(params, views):
+    """A differentiable stand-in for `render` on CPU: (K,H,W,3) images from (P,3) parameters and per-view phases."""
+    base = torch.tanh(params).sum(dim=0)  # (3,)
+    return torch.stack([torch.sin(base * (1.0 + v)).view(1, 1, 3).expand(4, 5, 3) * (0.5 + 0.1 * v) for v in views], 0)
+
+
+def _reference_batch_loss(params, anchor, views, gts):
+    """The reference's loss over a batch in ONE process, GassuianEditorEdit.py:100-104 (L1 = mean over the stacked batch,
+    perceptual stand-in = .sum() over the batch) + :133-145 (the anchor term, once per step)."""
+    images = _toy_images(params, views)
+    l1 = torch.nn.functional.l1_loss(images, gts)
+    perceptual = ((images - gts) ** 2).mean(dim=(1, 2, 3)).sum()
+    return 10.0 * l1 + 10.0 * perceptual + 5.0 * ((params - anchor) ** 2).mean()
+
+
+def _worker_loss_scale(rank, world, port, out_dir, per_step):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussianeditor_amd.multiview import batch_loss_scale
+
+        g = torch.Generator().manual_seed(3)
+        params0 = torch.randn(50, 3, generator=g)
+        anchor = params0 + 0.1 * torch.randn(50, 3, generator=g)
+        gts = torch.rand(world, 4, 5, 3, generator=g)
+        views = [float(v) for v in range(world)]
+        p = params0.clone().requires_grad_(True)
+        sc = batch_loss_scale(world, rank, per_step=per_step)
+        img = _toy_images(p, [views[rank]])
+        local = (sc["mean"] * 10.0 * torch.nn.functional.l1_loss(img, gts[rank:rank + 1])
+                 + sc["sum"] * 10.0 * ((img - gts[rank:rank + 1]) ** 2).mean(dim=(1, 2, 3)).sum()
+                 + sc["per_step"] * 5.0 * ((p - anchor) ** 2).mean())
+        local.backward()
+        grad, loss = p.grad.clone(), local.detach().clone().view(1)
+        dist.all_reduce(grad)  # what the gradient exchange forms
+        dist.all_reduce(loss)
+        q = params0.clone().requires_grad_(True)
+        ref = _reference_batch_loss(q, anchor, views, gts)
+        ref.backward()
+        np.savez(os.path.join(out_dir, f"ls_{per_step}_{rank}.npz"), grad=grad.numpy(), ref_grad=q.grad.numpy(),
+                 loss=loss.numpy(), ref_loss=ref.detach().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("per_step", ["split", "rank0"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_batch_loss_scale_reproduces_the_single_process_loss(tmp_path, world, per_step):
+    """L1 is a batch MEAN, the perceptual term a batch SUM, the anchor loss once per step
+    (threestudio/systems/GassuianEditorEdit.py:100-104, 133-145): with batch_loss_scale the summed local losses and the
+    all-reduced gradients equal the reference's one-process batch loss and its gradients."""
+    mp.spawn(_worker_loss_scale, args=(world, _free_port(), str(tmp_path), per_step), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"ls_{per_step}_{r}.npz")
+        assert abs(float(z["loss"][0]) - float(z["ref_loss"])) <= 1e-6 * abs(float(z["ref_loss"]))
+        assert np.abs(z["grad"] - z["ref_grad"]).max() <= 1e-6 * np.abs(z["ref_grad"]).max()
+    from gaussianeditor_amd.multiview import batch_loss_scale
+
+    assert batch_loss_scale(1) == {"mean": 1.0, "sum": 1.0, "per_step": 1.0}
+    with pytest.raises(ValueError):
+        batch_loss_scale(0)
+    with pytest.raises(ValueError):
+        batch_loss_scale(2, 2)
+
+
+class _ToyModel:
+    """The tensor side of GaussianModel.densify_and_split (gaussiansplatting/scene/gaussian_model.py:673-728) on CPU."""
+
+    def __init__(self):
+        g = torch.Generator().manual_seed(11)
+        self.xyz = torch.randn(200, 3, generator=g)
+        self.scaling = torch.rand(200, 3, generator=g) * 0.1
+        self.grads = torch.rand(200, generator=g)
+
+    def densify_and_split(self, N=2):
+        sel = self.grads >= 0.7
+        stds = self.scaling[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3)), std=stds)  # :685-687: the process RNG
+        new_xyz = samples + self.xyz[sel].repeat(N, 1)
+        keep = ~sel
+        self.xyz = torch.cat((self.xyz[keep], new_xyz))
+        self.scaling = torch.cat((self.scaling[keep], stds / (0.8 * N)))
+        self.grads = torch.zeros(self.xyz.shape[0])
+        return int(sel.sum())
+
+
+def _worker_densify(rank, world, port, out_dir, synchronized):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussianeditor_amd.multiview import densify_synchronized, replicas_identical
+
+        torch.manual_seed(1000 + rank)  # launch.py:102-103: pl.seed_everything(cfg.seed + get_rank())
+        m = _ToyModel()
+        assert replicas_identical([m.xyz, m.scaling])
+        before = torch.rand(1)  # the rank's own stream of random numbers ...
+        torch.manual_seed(1000 + rank)
+        _ = torch.rand(1)
+        if synchronized:
+            n = densify_synchronized(m.densify_and_split, replicated=lambda: [m.xyz, m.scaling, m.grads])
+        else:
+            n = m.densify_and_split()
+        after = torch.rand(1)  # ... continues where it was: the synchronised step leaves the generators untouched
+        torch.manual_seed(1000 + rank)
+        _ = torch.rand(1)
+        if synchronized and rank == 0:  # the source rank's stream advances by the one seed it draws
+            _ = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64)
+        expected_after = torch.rand(1)
+        same = replicas_identical([m.xyz, m.scaling])
+        np.savez(os.path.join(out_dir, f"dz_{int(synchronized)}_{rank}.npz"), xyz=m.xyz.numpy(), n=np.array([n]),
+                 same=np.array([same]), rng_kept=np.array([bool(torch.equal(after, expected_after)) or not synchronized]),
+                 before=before.numpy())
+        if synchronized:  # a diverged replica is refused, not trained on
+            m.xyz[0, 0] += float(rank)
+            try:
+                densify_synchronized(lambda: None, replicated=lambda: [m.xyz])
+                raised = False
+            except RuntimeError:
+                raised = True
+            np.savez(os.path.join(out_dir, f"dzr_{rank}.npz"), raised=np.array([raised]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_densify_synchronized_keeps_replicas_bit_identical(tmp_path):
+    """densify_and_split draws torch.normal from the process RNG (gaussian_model.py:685-687) and every rank is seeded
+    differently (launch.py:102-103): unsynchronised replicas differ after one split, synchronised ones are bit-identical,
+    and the per-rank RNG streams continue undisturbed."""
+    world = 2
+    mp.spawn(_worker_densify, args=(world, _free_port(), str(tmp_path), False), nprocs=world, join=True)
+    a, b = (np.load(tmp_path / f"dz_0_{r}.npz") for r in range(world))
+    assert a["n"][0] == b["n"][0] > 0 and not a["same"][0] and not np.array_equal(a["xyz"], b["xyz"])  # the problem
+    mp.spawn(_worker_densify, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    a, b = (np.load(tmp_path / f"dz_1_{r}.npz") for r in range(world))
+    assert a["same"][0] and b["same"][0] and np.array_equal(a["xyz"], b["xyz"]) and a["xyz"].shape[0] > 200
+    assert a["rng_kept"][0] and b["rng_kept"][0] and not np.array_equal(a["before"], b["before"])
+    assert all(np.load(tmp_path / f"dzr_{r}.npz")["raised"][0] for r in range(world))
