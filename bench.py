@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--s0", type=float, default=0.01, help="synth-v1 median scale (0.01 = headline; 0.03-0.05 = deep tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=15, help="oracle train iterations timed for cpu_baseline")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="development: on ONE GPU, run the multi-rank gradient exchange anyway (an RCCL group of one rank, "
+                         "touched-rows route, every collective issued): what a rank's step costs locally before a byte "
+                         "crosses xGMI.  The line is marked; it is not the benchmark.")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -123,6 +127,10 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)
+    elif args.force_exchange:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 
     import gaussianeditor_amd
     from gaussianeditor_amd import _native
@@ -147,7 +155,7 @@ def main():
     G = seed_gradient(H, W, 0).to(dev)
     rs = GaussianRasterizationSettings(H, W, tfx, tfy, sc["bg"].to(dev), 1.0, cam.world_view_transform.to(dev),
                                        cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
-    bucket = GradBucket(P, M, dev)
+    bucket = GradBucket(P, M, dev, sh_exchange="rgb" if args.force_exchange else "auto")
 
     def sync_all():
         if world > 1:
@@ -169,7 +177,8 @@ def main():
 
     def train_step():
         # forward, radii MAX all-reduce started, backward, gradient exchange (gaussianeditor_amd/multiview.py)
-        color, radii, depth, grads = multiview_step(rs, params, G, bucket, rows=rows_mode)
+        color, radii, depth, grads = multiview_step(rs, params, G, bucket, rows=True if args.force_exchange else rows_mode,
+                                                    force_exchange=args.force_exchange)
         route["last"] = bucket.last_route
         return radii
 
@@ -363,7 +372,8 @@ def main():
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
                        "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
                        "synth_s0": args.s0,
-                       "grad_exchange": exchange, "grad_exchange_route": route["last"],
+                       "grad_exchange": exchange + (" (forced on one rank: development run)" if args.force_exchange else ""),
+                       "grad_exchange_route": route["last"],
                        "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
             "forward_renders_per_s": renders_per_s,
@@ -377,7 +387,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_view_message_words": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
     "gsr_view_message_plan": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, POINTER(c_int64)]),
+    "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gsr_view_message_pack": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, _P, c_int64, _P]),
     "gsr_view_messages_accumulate": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads)]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),

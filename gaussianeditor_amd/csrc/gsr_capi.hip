@@ -474,6 +474,18 @@ int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local,
   return GSR_OK;
 }
 
+int gsr_view_message_plan_blend(void* stream, int64_t P, const float* dL_dmeans2D, const float* dL_dconic,
+                                const float* dL_dopacity, const float* dL_dcolors, uint8_t* mask, void* workspace) {
+  if (P == 0) return GSR_OK;
+  if (P < 0 || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  hipStream_t s = (hipStream_t)stream;
+  const float* data[4] = {dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors};
+  const int row_len[4] = {3, 4, 1, 3};
+  GSR_HIP(launch_touched_rows(s, P, 4, data, row_len, mask));
+  GSR_HIP(launch_compact_plan(s, P, mask, workspace));
+  return GSR_OK;
+}
+
 int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
                           const uint8_t* mask, void* workspace, int64_t cap, float* message) {
   if (P < 0 || cap < 0 || !message || !campos) return GSR_ERR_BAD_ARGUMENT;
@@ -493,7 +505,9 @@ int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local,
                                    {local->means2D, rows + 11 * cap, 12},
                                    {local->opacities, rows + 14 * cap, 4},
                                    {rgb, rows + 15 * cap, 12}};
-  GSR_HIP(launch_compact_apply(s, P, mask, workspace, 7, t));
+  // (a message speculatively sized below this view's row count -- multiview.py -- keeps its first `cap` rows: its header
+  //  still carries the true count, the receivers' host code sees the overflow and has the message sent again)
+  GSR_HIP(launch_compact_apply(s, P, mask, workspace, 7, t, cap));
   GSR_HIP(launch_view_message_header(s, P, campos, compact_block_off_ptr(workspace, P), compact_total_ptr(workspace, P), message));
   return GSR_OK;
 }

@@ -70,6 +70,7 @@ struct CompactArgs {
   int64_t P;
   const uint8_t* keep;
   const uint32_t* block_off;
+  uint32_t limit;  // surviving rows beyond this many are dropped (a destination that holds only `limit` rows)
 };
 
 constexpr int CMP_TENSORS_PER_BLOCK = 8;  // tensors a block moves after scanning its part of the mask once
@@ -82,7 +83,8 @@ __global__ void __launch_bounds__(CMP_ROWS) compact_apply_kernel(const CompactAr
   const uint32_t k = (r < a.P && a.keep[r] != 0) ? 1u : 0u;
   uint32_t total;
   const uint32_t ex = block_excl_scan_u32<CMP_ROWS>(k, &total, smem);
-  pos[threadIdx.x] = k ? a.block_off[blockIdx.x] + ex : 0xffffffffu;
+  const uint32_t my_pos = a.block_off[blockIdx.x] + ex;
+  pos[threadIdx.x] = (k && my_pos < a.limit) ? my_pos : 0xffffffffu;
   __syncthreads();
   if (total == 0) return;
   const uint32_t nrows = (uint32_t)min((int64_t)CMP_ROWS, a.P - row0);
@@ -141,7 +143,7 @@ const uint64_t* compact_total_ptr(void* workspace, int64_t P) { return carve_com
 const uint32_t* compact_block_off_ptr(void* workspace, int64_t P) { return carve_compact(workspace, P).block_off; }
 
 hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace, int nt,
-                                const gsr_compact_tensor* tensors) {
+                                const gsr_compact_tensor* tensors, int64_t limit) {
   if (nt <= 0 || P <= 0) return hipSuccess;
   if (nt > CMP_MAX_TENSORS) return hipErrorInvalidValue;
   const CompactWork w = carve_compact(workspace, P);
@@ -151,6 +153,7 @@ hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, v
   a.nt = nt;
   a.keep = keep;
   a.block_off = w.block_off;
+  a.limit = (limit < 0 || limit > 0xfffffffell) ? 0xffffffffu : (uint32_t)limit;
   for (int i = 0; i < nt; ++i) {
     a.t[i].src = (const uint8_t*)tensors[i].src;
     a.t[i].dst = (uint8_t*)tensors[i].dst;

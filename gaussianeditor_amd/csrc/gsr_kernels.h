@@ -127,8 +127,9 @@ hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace
 size_t compact_workspace_bytes(int64_t P);
 hipError_t launch_compact_plan(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace);
 const uint64_t* compact_total_ptr(void* workspace, int64_t P);
+// limit: rows the destinations hold (survivors beyond it are dropped); < 0 = unlimited
 hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace, int nt,
-                                const gsr_compact_tensor* tensors);
+                                const gsr_compact_tensor* tensors, int64_t limit = -1);
 hipError_t launch_append_rows(hipStream_t s, int64_t P, int64_t n, int nt, const gsr_append_tensor* tensors);
 hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
                             double beta2, double eps, const uint8_t* row_mask, const float* row_weight);

@@ -85,6 +85,12 @@ class GradBucket:
         #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
         self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
         self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
+        #: called with the blend backward's four accumulators between K7 and K8+K9 (multiview_step sets it: the touched-row
+        #: counts are exchanged from there, underneath K8+K9)
+        self.on_blend_done = None
+        self._pending_counts = None
+        self._side_stream = None
+        self._cap_hint = None  # message capacity the next touched-rows exchange speculates on (rows)
         self.last_route = None  # what the last multiview_step's exchange did: "local" | "rows" | "sparse" | "dense"
         self.last_counts = None  # touched rows per view, as gathered by the last touched-rows exchange
         for name in slots:
@@ -94,6 +100,10 @@ class GradBucket:
         self._acc_span = (offs["means2D"], offs["opacities"] + P)
 
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool):
+        if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the four accumulators)
+            if self.on_blend_done is not None:
+                self.on_blend_done(shape)
+            return None
         if name == "sh_rgb":  # "rgb" exchange mode: ask the backward for dL_dRGB instead of dL_dsh
             return self.rgb if (self.rgb is not None and tuple(shape) == (self.P, 3)) else None
         if name == "accumulators":  # means2D, opacities and the two internal accumulators, zeroed by ONE fill
@@ -185,28 +195,91 @@ _ROW_BYTES = 4 * 18
 _ROW_SEGS = ("means3D", "scales", "rotations", "means2D", "opacities")
 
 
+def _start_counts_exchange(bucket: GradBucket, acc4, group, n: int):
+    """Called between K7 and K8+K9 of this rank's backward: marks the touched rows from the blend backward's four
+    accumulators, and exchanges the ranks' row counts -- on a side stream, so that the plan kernels, the tiny all-gather AND
+    the host's wait for its result all run while K8+K9 (~100 us) occupies the launch stream.  The step's one host
+    synchronisation then costs the GPU nothing: when K8+K9 retires, pack / all-gather / accumulate are already queued."""
+    dev = acc4[0].device
+    if dev.type != "cuda":  # gloo on CPU (tests): nothing to overlap
+        plan, mine = _C.view_message_plan_blend(acc4)
+        gathered = [torch.empty_like(mine) for _ in range(n)]
+        dist.all_gather(gathered, mine, group=group)
+        return plan, torch.cat(gathered), None
+    main = torch.cuda.current_stream(dev)
+    if bucket._side_stream is None:
+        bucket._side_stream = torch.cuda.Stream(device=dev)
+    side = bucket._side_stream
+    ready = torch.cuda.Event()
+    ready.record(main)  # K7 is enqueued in front of this
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        plan, mine = _C.view_message_plan_blend(acc4)
+        gathered = torch.empty(n, dtype=torch.int64, device=dev)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(n)]
+            dist.all_gather(parts, mine, group=group)
+            gathered.copy_(torch.cat(parts))
+        planned = torch.cuda.Event()
+        planned.record(side)  # the plan itself (mask + row offsets): all the pack kernel waits for
+        host = torch.empty(n, dtype=torch.int64, pin_memory=True)
+        host.copy_(gathered, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in plan[:2]:  # allocated under the side stream, consumed by the pack kernel on the launch stream
+        if t is not None:
+            t.record_stream(main)
+    return plan, host, (planned, done)
+
+
 def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Optional[str]:
     """The touched-rows exchange of the "rgb" mode (module docstring).  Returns "rows", or None when the dense route is
     cheaper (nothing has been modified then)."""
     P, dev = bucket.P, bucket.flat.device
     grads5 = [bucket.views[name] for name in _ROW_SEGS]
-    plan, mine = _C.view_message_plan(grads5, bucket.rgb, readback=False)  # the count stays on the device ...
-    gathered = [torch.empty_like(mine) for _ in range(n)]
-    dist.all_gather(gathered, mine, group=group)
-    counts = [int(c) for c in torch.cat(gathered).tolist()]  # ... this is the step's one host sync; identical on every rank
+    prepared, bucket._pending_counts = bucket._pending_counts, None
+
+    def send_messages(plan, cap):
+        words = _C.view_message_words(P, cap)
+        send = torch.empty(words, dtype=torch.float32, device=dev)
+        _C.view_message_pack(plan, grads5, bucket.rgb, bucket.campos, cap, send)
+        recv = torch.empty((n, words), dtype=torch.float32, device=dev)
+        if dist.get_backend(group) == "nccl":
+            dist.all_gather_into_tensor(recv, send, group=group)  # straight into the rows of recv
+        else:
+            dist.all_gather(list(recv.unbind(0)), send, group=group)
+        return recv
+
+    recv = cap = None
+    if prepared is not None:  # the counts were exchanged underneath K8+K9 (_start_counts_exchange)
+        plan, host, events = prepared
+        if events is not None:
+            torch.cuda.current_stream(dev).wait_event(events[0])  # (a GPU-side wait: the pack kernel reads the plan)
+        if bucket._cap_hint is not None:
+            # SPECULATE on the message size (the last step's largest count + 25 %): pack and all-gather are enqueued
+            # without waiting for this step's counts, so the host's wait below runs underneath them (and underneath
+            # the collective's wire time); nothing the messages feed -- the accumulate kernel -- is enqueued before
+            # the counts have been checked, and a message that turns out too small is simply sent again.
+            cap = bucket._cap_hint
+            recv = send_messages(plan, cap)
+        if events is not None:
+            events[1].synchronize()  # the host waits for the SIDE stream only
+        counts = [int(c) for c in host.tolist()]
+    else:
+        plan, mine = _C.view_message_plan(grads5, bucket.rgb, readback=False)  # the count stays on the device ...
+        gathered = [torch.empty_like(mine) for _ in range(n)]
+        dist.all_gather(gathered, mine, group=group)
+        counts = [int(c) for c in torch.cat(gathered).tolist()]  # ... the step's one host sync; identical on every rank
     bucket.last_counts = counts
+    bucket._cap_hint = (int(1.25 * max(max(counts), 1)) + 1023) // 1024 * 1024  # identical on every rank
     dense_bytes = 12 * n * P + 2 * 56 * P  # what a rank receives on the dense route (rgb all-gather + ring all-reduce)
     if not force and _ROW_BYTES * sum(counts) > 0.6 * dense_bytes:
-        return None
-    cap = max(max(counts), 1)
-    words = _C.view_message_words(P, cap)
-    send = torch.empty(words, dtype=torch.float32, device=dev)
-    _C.view_message_pack(plan, grads5, bucket.rgb, bucket.campos, cap, send)
-    recv = torch.empty((n, words), dtype=torch.float32, device=dev)
-    if dist.get_backend(group) == "nccl":
-        dist.all_gather_into_tensor(recv, send, group=group)  # straight into the rows of recv
-    else:
-        dist.all_gather(list(recv.unbind(0)), send, group=group)
+        return None  # (a speculative send is dropped: nothing was modified)
+    if recv is None or max(counts) > cap:
+        cap = max(max(counts), 1)
+        recv = send_messages(plan, cap)
     sh = torch.empty((P, bucket.M, 3), dtype=torch.float32, device=dev)
     # one kernel: per Gaussian, the views' rows added in ascending view order (zeros where no view touched it)
     _C.view_messages_accumulate(recv, P, cap, bucket.sh_degree, bucket.M, bucket.means3D_ref, grads5 + [sh])
@@ -290,9 +363,20 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
             batch_max = radii.clone()  # (the backward still needs this view's own radii)
             pending.append((batch_max, dist.all_reduce(batch_max, op=dist.ReduceOp.MAX, group=group, async_op=True)))
 
-    color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
-                                                   params["scaling"], params["rotation"], dL_dcolor, bucket,
-                                                   after_forward=start_radii)
+    exchanging = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
+    if exchanging and bucket.sh_exchange == "rgb" and rows in ("auto", True):
+        n = dist.get_world_size(group)
+
+        def start_counts(acc4):  # between K7 and K8+K9 of this rank's backward
+            bucket._pending_counts = _start_counts_exchange(bucket, acc4, group, n)
+
+        bucket.on_blend_done = start_counts
+    try:
+        color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
+                                                       params["scaling"], params["rotation"], dL_dcolor, bucket,
+                                                       after_forward=start_radii)
+    finally:
+        bucket.on_blend_done = None
     bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows, sparse=sparse, force_exchange=force_exchange)
     for batch_max, work in pending:
         work.wait()

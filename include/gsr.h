@@ -263,7 +263,19 @@ int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors,
  *                                 does not block: the count is then the uint64 at the start of `workspace`, in
  *                                 stream order (multiview.py all-gathers it from there: one host sync for all ranks'
  *                                 counts instead of two);
- *   gsr_view_message_pack         writes the message (same mask / workspace);
+ *   gsr_view_message_plan_blend   the same plan from what gsr_blend_backward ALONE leaves behind -- its four accumulators
+ *                                 dL_dmeans2D (P,3), dL_dconic (P,4), dL_dopacity (P), dL_dcolors (P,3): a Gaussian no pixel
+ *                                 blended has all-zero rows there, and gsr_preprocess_backward turns all-zero rows into
+ *                                 all-zero gradients, so this mask is a superset of gsr_view_message_plan's (a row it
+ *                                 adds carries zeros: the sums do not change).  It never blocks; the count is the uint64 at
+ *                                 the start of `workspace`.  Purpose: the ranks can exchange their counts and the host can
+ *                                 size the messages WHILE gsr_preprocess_backward (K8+K9, ~100 us) still runs, so the one
+ *                                 host synchronisation of the exchange costs the GPU nothing;
+ *   gsr_view_message_pack         writes the message (same mask / workspace).  If the view has more touched rows than
+ *                                 `cap`, only the first `cap` are written (no overrun) while the header keeps the true
+ *                                 count: such a message must not be accumulated -- a sender that sized its messages
+ *                                 before the counts were known (multiview.py speculates on the previous steps' counts)
+ *                                 sends it again with a sufficient cap;
  *   gsr_view_messages_accumulate  num_views messages, `stride_words` apart, -> the dense sums in `out` (every row of
  *                                 every array is written: Gaussians no view touched get zeros); out->sh, if not NULL,
  *                                 is rebuilt from the colour gradients exactly as gsr_sh_grad_compose does (means3D,
@@ -280,6 +292,8 @@ typedef struct gsr_dense_grads {
 int gsr_view_message_words(int64_t P, int64_t cap, int64_t* words);
 int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
                           void* workspace, int64_t* count_host);
+int gsr_view_message_plan_blend(void* stream, int64_t P, const float* dL_dmeans2D, const float* dL_dconic,
+                                const float* dL_dopacity, const float* dL_dcolors, uint8_t* mask, void* workspace);
 int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
                           const uint8_t* mask, void* workspace, int64_t cap, float* message);
 int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,

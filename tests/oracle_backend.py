@@ -49,6 +49,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                    viewmatrix, projmatrix, campos, background, W, H, tan_fovx, tan_fovy, scale_modifier, degree)
     P = means3D.size(0)
     M = sh.size(1) if sh.size(0) != 0 else 0
+    if M != 0 and grad_allocator is not None and grad_allocator("sh_rgb", (P, 3), False) is not None:
+        # the notification between K7 and K8+K9 (the four accumulators of the blend backward)
+        grad_allocator("after_blend_backward", tuple(torch.from_numpy(np.ascontiguousarray(g[k])).reshape(shape) for k, shape in
+                                                      (("dL_dmeans2D", (P, 3)), ("dL_dconic", (P, 4)), ("dL_dopacity", (P, 1)),
+                                                       ("dL_dcolors", (P, 3)))), False)
     out = []
     for name, key, shape in (("means2D", "dL_dmeans2D", (P, 3)), ("colors_precomp", "dL_dcolors", (P, 3)),
                              ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
@@ -85,17 +90,25 @@ def view_message_plan(grads5, rgb, readback=True):
     return idx, (int(idx.numel()) if readback else torch.tensor([idx.numel()], dtype=torch.int64))
 
 
+def view_message_plan_blend(acc4):
+    P = int(acc4[0].size(0))
+    rows = torch.cat([t.reshape(P, -1) for t in acc4], dim=1)
+    idx = (rows != 0).any(dim=1).nonzero().view(-1)
+    return idx, torch.tensor([idx.numel()], dtype=torch.int64)
+
+
 def view_message_pack(plan, grads5, rgb, campos, cap, message):
     P, n, nb = int(rgb.size(0)), int(plan.numel()), (int(rgb.size(0)) + 1023) // 1024
     w = message.view(torch.int32)
     message[0:3] = campos.reshape(3)
-    w[3] = n
+    w[3] = n  # the true count, even when only the first `cap` rows fit (the sender then sends the message again)
     w[4:4 + nb] = torch.searchsorted(plan, torch.arange(nb, dtype=plan.dtype) * 1024).to(torch.int32)
     off = 4 + nb
-    w[off:off + n] = plan.to(torch.int32)
+    m = min(n, int(cap))
+    w[off:off + m] = plan[:m].to(torch.int32)
     off += cap
     for t, k in zip(list(grads5) + [rgb], (3, 3, 4, 3, 1, 3)):
-        message[off:off + k * cap].view(cap, k)[:n] = t.reshape(P, k)[plan]
+        message[off:off + k * cap].view(cap, k)[:m] = t.reshape(P, k)[plan[:m]]
         off += k * cap
 
 
@@ -155,5 +168,5 @@ def install(monkeypatch):
     import gaussianeditor_amd.diff_gaussian_rasterization as dgr
 
     for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_aux", "sh_grad_compose",
-                 "view_message_words", "view_message_plan", "view_message_pack", "view_messages_accumulate", "mark_visible", "apply_weights"):
+                 "view_message_words", "view_message_plan", "view_message_plan_blend", "view_message_pack", "view_messages_accumulate", "mark_visible", "apply_weights"):
         monkeypatch.setattr(dgr._C, name, globals()[name])

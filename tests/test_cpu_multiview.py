@@ -53,14 +53,14 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
             from gaussianeditor_amd.multiview import multiview_step
 
             touched_of = []
-            orig = allreduce_view_grads.__globals__["_C"].view_message_plan
+            orig = allreduce_view_grads.__globals__["_C"].view_message_plan_blend
 
-            def spy(grads5, rgb, readback=True):
-                rows_of = torch.cat([g.reshape(P, -1) for g in grads5] + [rgb], dim=1)
+            def spy(acc4):  # the whole step plans from the blend backward's accumulators, between K7 and K8+K9
+                rows_of = torch.cat([g.reshape(P, -1) for g in acc4], dim=1)
                 touched_of.append(float((rows_of != 0).any(dim=1).float().mean()))
-                return orig(grads5, rgb, readback)
+                return orig(acc4)
 
-            mpatch.setattr(allreduce_view_grads.__globals__["_C"], "view_message_plan", spy)
+            mpatch.setattr(allreduce_view_grads.__globals__["_C"], "view_message_plan_blend", spy)
             params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
             color, radii, depth, grads = multiview_step(settings(case, "cpu"), params, G, bucket)
             assert grads["sh"] is None
@@ -409,3 +409,66 @@ def test_densify_synchronized_keeps_replicas_bit_identical(tmp_path):
     assert a["same"][0] and b["same"][0] and np.array_equal(a["xyz"], b["xyz"]) and a["xyz"].shape[0] > 200
     assert a["rng_kept"][0] and b["rng_kept"][0] and not np.array_equal(a["before"], b["before"])
     assert all(np.load(tmp_path / f"dzr_{r}.npz")["raised"][0] for r in range(world))
+
+
+def _worker_speculative_cap(rank, world, port, out_dir):
+    """Three steps on ONE bucket: the second and third size their messages from the step before (no wait for the counts
+    before pack / all-gather are enqueued); the third touches far more rows than the second, so its speculative messages
+    overflow and are sent again."""
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytest as _pt
+
+    import oracle_backend
+    from gaussianeditor_amd import multiview as mv
+
+    mpatch = _pt.MonkeyPatch()
+    oracle_backend.install(mpatch)
+    try:
+        Pn = 1500
+        case = make_case(Pn, W, H, seed=5, s0=0.07, view=rank, nviews=world)
+        sc = case["sc"]
+        params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+        bucket = mv.GradBucket(Pn, 16, "cpu")
+        sends = []
+        orig_pack = mv._C.view_message_pack
+        mpatch.setattr(mv._C, "view_message_pack", lambda plan, g5, rgb, cam, cap, msg: (sends.append(int(cap)), orig_pack(plan, g5, rgb, cam, cap, msg))[1])
+        Gfull = seed_gradient(H, W, 100 + rank) * H * W
+        Gsmall = Gfull.clone()
+        Gsmall[:, :, W // 6:] = 0.0  # only a strip of the image carries a gradient: few touched rows
+        log = []
+        for step, G in enumerate((Gsmall, Gsmall, Gfull)):
+            n0 = len(sends)
+            mv.multiview_step(settings(case, "cpu"), params, G, bucket, rows=True)
+            log.append((len(sends) - n0, list(bucket.last_counts), int(bucket._cap_hint)))
+        np.savez(os.path.join(out_dir, f"spec_{rank}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
+                 sends=np.array([e[0] for e in log]), counts=np.array([e[1] for e in log]), hints=np.array([e[2] for e in log]),
+                 caps=np.array(sends))
+    finally:
+        mpatch.undo()
+        dist.destroy_process_group()
+
+
+def test_speculative_message_size_is_exact_when_it_overflows(oracle, tmp_path):
+    world = 2
+    mp.spawn(_worker_speculative_cap, args=(world, _free_port(), str(tmp_path), ), nprocs=world, join=True)
+    z = [np.load(tmp_path / f"spec_{r}.npz") for r in range(world)]
+    # step 0 knows no hint (one send, exact cap); step 1 speculates and fits (one send); step 2 speculates on step 1's small
+    # counts, overflows and sends again
+    assert list(z[0]["sends"]) == [1, 1, 2] and list(z[1]["sends"]) == [1, 1, 2]
+    assert z[0]["counts"][2].max() > z[0]["hints"][1] >= z[0]["counts"][1].max()
+    assert np.array_equal(z[0]["counts"], z[1]["counts"]) and np.array_equal(z[0]["hints"], z[1]["hints"])
+    # the result of the overflowing step: the single-process sum of the two views' gradients, bit for bit on both replicas
+    want_flat, want_sh = None, None
+    for v in range(world):
+        case = make_case(1500, W, H, seed=5, s0=0.07, view=v, nviews=world)
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
+        segs = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dopacity")])
+        want_flat = segs if want_flat is None else want_flat + segs
+        want_sh = g["dL_dsh"].reshape(1500, 16, 3) if want_sh is None else want_sh + g["dL_dsh"].reshape(1500, 16, 3)
+    for r in range(world):
+        assert np.array_equal(z[r]["flat"], want_flat.astype(np.float32)) and np.array_equal(z[r]["sh"], want_sh.astype(np.float32))
