@@ -95,6 +95,13 @@ def main():
     ap.add_argument("--s0", type=float, default=0.01, help="synth-v1 median scale (0.01 = headline; 0.03-0.05 = deep tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=15, help="oracle train iterations timed for cpu_baseline")
+    ap.add_argument("--ply", type=str, default=None,
+                    help="a 3DGS point cloud in the reference's save_ply layout (gaussiansplatting/scene/gaussian_model.py:"
+                         "410-445), e.g. Mip-NeRF360 bicycle/point_cloud/iteration_30000/point_cloud.ply = BASELINE configs[1]; "
+                         "replaces the synthetic scene (cameras stay ring-v1 around the scene's median, see --ply-fit)")
+    ap.add_argument("--ply-fit", type=int, default=1,
+                    help="1 (default): translate the loaded scene's median to the origin and scale it (positions and scales) so "
+                         "that 90 %% of the Gaussians lie within the unit ball the ring-v1 cameras look at; 0: as stored")
     ap.add_argument("--force-exchange", action="store_true",
                     help="development: on ONE GPU, run the multi-rank gradient exchange anyway (an RCCL group of one rank, "
                          "touched-rows route, every collective issued): what a rank's step costs locally before a byte "
@@ -147,14 +154,29 @@ def main():
 
     P, W, H = args.gaussians, args.width, args.height
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    sc = synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
+    if args.ply is not None:
+        from gaussianeditor_amd import scene_ply
+
+        raw = scene_ply.load_gaussians_ply(args.ply)
+        sc = scene_ply.activated(raw)
+        if args.ply_fit:
+            c = sc["xyz"].median(dim=0).values
+            r = torch.quantile((sc["xyz"] - c).norm(dim=1)[:8_000_000], 0.9).clamp_min(1e-12)
+            sc["xyz"] = ((sc["xyz"] - c) / r).contiguous()
+            sc["scaling"] = (sc["scaling"] / r).contiguous()
+        sc["bg"] = torch.zeros(3)
+        P = int(sc["xyz"].shape[0])
+        ply_degree = int(raw["max_sh_degree"])
+    else:
+        sc = synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
+        ply_degree = 3
     M = sc["features"].shape[1]
     cam = ring_cameras(8, W, H)[rank % 8]
     tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
     params = {k: sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
     G = seed_gradient(H, W, 0).to(dev)
     rs = GaussianRasterizationSettings(H, W, tfx, tfy, sc["bg"].to(dev), 1.0, cam.world_view_transform.to(dev),
-                                       cam.full_proj_transform.to(dev), 3, cam.camera_center.to(dev), False, False)
+                                       cam.full_proj_transform.to(dev), ply_degree, cam.camera_center.to(dev), False, False)
     bucket = GradBucket(P, M, dev, sh_exchange="rgb" if args.force_exchange else "auto")
 
     def sync_all():
@@ -249,7 +271,7 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         Rc = (ctypes.c_int64 * 2)()
         ev[0].record(s)
-        _native.check("pre", L.gsr_preprocess(sp, P, 3, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
+        _native.check("pre", L.gsr_preprocess(sp, P, ply_degree, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
                                               p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
                                               p(rs.campos), W, H, tfx, tfy, 0, 0, flags, p(radii_t), p(geom), Rc))
         ev[1].record(s)
@@ -263,7 +285,7 @@ def main():
         _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
                                                   p(d_con), p(d_op), p(d_col), flags))
         ev[4].record(s)
-        _native.check("pbw", L.gsr_preprocess_backward(sp, P, 3, M, W, H, p(params["xyz"]), p(params["features"]),
+        _native.check("pbw", L.gsr_preprocess_backward(sp, P, ply_degree, M, W, H, p(params["xyz"]), p(params["features"]),
                                                        p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
                                                        p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom), p(d_m2),
                                                        p(d_con), p(d_col), p(d_m3), p(d_cov), p(d_sh), p(d_sc), p(d_rot)))
@@ -293,10 +315,10 @@ def main():
         def oracle_iter():
             f_ = O.forward(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], None, None,
                            cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"], W, H, tfx, tfy,
-                           1.0, 3)
+                           1.0, ply_degree)
             O.backward(f_, G_cpu, sc["xyz"], sc["scaling"], sc["rotation"], sc["features"], None, None,
                        cam0.world_view_transform, cam0.full_proj_transform, cam0.camera_center, sc["bg"], W, H, tfx, tfy,
-                       1.0, 3)
+                       1.0, ply_degree)
             return f_
 
         t0 = time.perf_counter()
@@ -316,9 +338,13 @@ def main():
         # second leg: the PyTorch-CPU restatement of the forward render, same view
         import subprocess
 
+        # (32 threads at most: the restatement is torch's stable argsort, gathers and per-tile cumprod, whose intra-op
+        #  parallelism saturates there; the oracle leg above uses every core)
         threads = max(1, min(32, os.cpu_count() or 1))
         stride = 8
         try:
+            if args.ply is not None:
+                raise RuntimeError("the PyTorch-CPU leg regenerates the synth-v1 scene; not run for --ply")
             env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
             pr = subprocess.run([sys.executable, "-m", "oracle.torch_cpu", str(P), str(W), str(H), str(args.s0), str(rank % 8), "8",
                                  str(stride), str(threads)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
@@ -328,7 +354,9 @@ def main():
                                 "sample": f"oracle/torch_cpu.py (vectorised float32 torch ops, stable argsort, per-tile cumprod "
                                           f"blending) on the same view: preprocess + sort of all {tj['num_rendered']} instances "
                                           f"{tj['prepare_s']:.2f} s, blending of {tj['tiles_blended']} of {tj['tiles_nonempty']} "
-                                          f"non-empty tiles (every {stride}th) {tj['blend_s_sampled']:.2f} s, scaled to all tiles"}
+                                          f"non-empty tiles (every {stride}th) {tj['blend_s_sampled']:.2f} s, scaled to all tiles; "
+                                          f"{threads} threads (the intra-op parallelism of argsort / gather / cumprod saturates "
+                                          f"there on this {os.cpu_count()}-thread host; the oracle leg uses all cores)"}
         except Exception as ex:  # the second leg must never cost the bench line
             cpu["torch_cpu"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
 
@@ -366,9 +394,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, one view per GPU "
-                                   "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)",
+            "data": "synthetic" if args.ply is None else "file (scene) + synthetic cameras / pixel gradient",
+            "config": {"workload": (f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, one view per GPU "
+                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)")
+                       if args.ply is None else
+                       (f"{os.path.basename(args.ply)}: {P} Gaussians SH{ply_degree} (M={M}) loaded from the reference's save_ply "
+                        f"layout{' (fitted to the unit ball)' if args.ply_fit else ''}, {W}x{H}, ring-v1 8 views "
+                        "(BASELINE.json configs[1] shape when the file is bicycle/point_cloud.ply)"),
                        "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
                        "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
                        "synth_s0": args.s0,

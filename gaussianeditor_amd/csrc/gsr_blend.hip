@@ -19,9 +19,10 @@
 //     heavy-tailed: with one workgroup per quadrant most SIMDs idle through a long tail);
 //     the four quadrants of a tile are consecutive items of ONE queue, so they gather the same
 //     Gaussians through the same 4 MiB L2.  Which wave runs an item never affects results;
-//   * the backward reduces the 9 per-Gaussian gradient terms across the 64 lanes with DPP
-//     row shifts / row broadcasts (6 v_add_f32_dpp per value) and issues ONE vectorised
-//     atomic per (quadrant, instance, term) instead of the reference's one per pixel.
+//   * the backward runs one 4-wave workgroup per tile: the quadrant waves reduce the 9 per-Gaussian gradient terms of
+//     four entries at a time across their 64 lanes (two v_permlane32_swap, one v_permlane16_swap, four row_shr DPP adds),
+//     add their totals into a per-chunk LDS accumulator, and ONE global atomic per (tile, instance, term) leaves the CU --
+//     the reference issues one per pixel.
 #include <stdlib.h>
 
 #include "gsr_kernels.h"
@@ -1100,41 +1101,44 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
 }
 
+// Compute units of the device a launch goes to: the device of the STREAM (a C-ABI caller may hand over a stream of another
+// device than the thread's current one), looked up per call, the attribute cached per device ordinal.
+static int cus_of_stream(hipStream_t s) {
+  static int cache[64] = {};  // 0 = not asked yet (a benign race: every writer stores the same value)
+  int dev = 0;
+  hipDevice_t sdev = 0;
+  if (s != nullptr && hipStreamGetDevice(s, &sdev) == hipSuccess) dev = (int)sdev;
+  else (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    int c = 0;
+    (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    cache[dev] = c > 0 ? c : 256;
+  }
+  return cache[dev];
+}
 // Number of persistent waves of a launch: (SIMDs on the device) x (waves per SIMD), 4 by default.
 // GSR_BLEND_WAVES_PER_SIMD overrides the default for all blend kernels, GSR_FWD_WAVES_PER_SIMD for the forward / trace
 // kernels only (the backward is built for exactly 4: amdgpu_waves_per_eu) -- tuning knobs, read once.
-static unsigned grid_for(const char* specific) {
-  int cus = 256, dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (cus <= 0) cus = 256;
-  int per_simd = 4;
-  if (const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD")) per_simd = atoi(e);
-  if (specific != nullptr)
-    if (const char* e = getenv(specific)) per_simd = atoi(e);
-  if (per_simd < 1) per_simd = 1;
-  if (per_simd > 8) per_simd = 8;
-  return (unsigned)cus * 4u * (unsigned)per_simd;
+static int waves_per_simd(bool backward) {
+  static const int all = [] { const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD"); return e ? atoi(e) : 4; }();
+  static const int fwd = [] { const char* e = getenv("GSR_FWD_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();
+  const int v = (!backward && fwd > 0) ? fwd : all;
+  return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
-unsigned blend_grid_size(bool backward) {
+unsigned blend_grid_size(bool backward, hipStream_t s) {
   // (GSR_FWD_GRID: development knob, any number of persistent forward waves -- tools/microbench, profiles/r02_e)
-  static const unsigned fwd = [] {
-    const char* e = getenv("GSR_FWD_GRID");
-    return e && atoi(e) > 0 ? (unsigned)atoi(e) : grid_for("GSR_FWD_WAVES_PER_SIMD");
-  }();
-  static const unsigned bwd = grid_for(nullptr);
-  return backward ? bwd : fwd;
+  static const unsigned fwd_fixed = [] { const char* e = getenv("GSR_FWD_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
+  if (!backward && fwd_fixed != 0u) return fwd_fixed;
+  return (unsigned)cus_of_stream(s) * 4u * (unsigned)waves_per_simd(backward);
 }
 // Placement units of a launch with `waves_per_wg`-wave workgroups (see first_item_of_block): SIMDs or CUs; 0 turns the
 // assigned first items off (GSR_BLEND_FOLD=0, or a CU count the fold does not divide).
-static unsigned blend_units(unsigned waves_per_wg) {
+static unsigned blend_units(unsigned waves_per_wg, hipStream_t s) {
   static const bool fold = [] { const char* e = getenv("GSR_BLEND_FOLD"); return !e || atoi(e) != 0; }();
-  static const unsigned cus = [] {
-    int c = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
-    return (unsigned)(c > 0 ? c : 256);
-  }();
+  const unsigned cus = (unsigned)cus_of_stream(s);
   const unsigned units = waves_per_wg == 1 ? cus * 4u : cus;
-  const unsigned grid = blend_grid_size(waves_per_wg != 1) / waves_per_wg;
+  const unsigned grid = blend_grid_size(waves_per_wg != 1, s) / waves_per_wg;
   if (!fold || units % 8u != 0u || grid % units != 0u) return 0u;
   return units;
 }
@@ -1148,13 +1152,13 @@ static hipError_t prepare_queue(hipStream_t s, BlendArgs& a, unsigned grid) {
   return use_memset ? hipMemsetAsync(a.queue, 0, sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES, s) : hipSuccess;
 }
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size());
+  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s));
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(1);
+  a.units = (int)blend_units(1, s);
   static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
   a.allow_split = split_ok ? 1 : 0;
   // fewer than two quadrant items per persistent wave (bounded by the tile count of the image): cut the quadrants
-  const unsigned grid = blend_grid_size(), quads = 4u * (unsigned)(a.gx * a.gy);
+  const unsigned grid = blend_grid_size(false, s), quads = 4u * (unsigned)(a.gx * a.gy);
   const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
   const dim3 g(grid), b(WAVE);
 #define GSR_FWD_LAUNCH(AUXV, FASTV)                                                                        \
@@ -1174,15 +1178,15 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size(true) / BWD_WAVES);
+  hipError_t e = prepare_queue(s, a, blend_grid_size(true, s) / BWD_WAVES);
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(BWD_WAVES);
+  a.units = (int)blend_units(BWD_WAVES, s);
   // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
   static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
   if (own_list && a.work_est != nullptr) {
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
     hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta,
-                       blend_grid_size(true) / BWD_WAVES, halves);
+                       blend_grid_size(true, s) / BWD_WAVES, halves);
     a.work_order = a.bwd_order;
     a.work_meta = a.bwd_meta;
   } else {
@@ -1191,7 +1195,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
-  const dim3 g(blend_grid_size(true) / BWD_WAVES), b(WAVE * BWD_WAVES);
+  const dim3 g(blend_grid_size(true, s) / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false>), g, b, 0, s, a); break;
@@ -1205,10 +1209,10 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size());
+  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s));
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(1);
-  const unsigned grid = blend_grid_size(), quads = 4u * (unsigned)(a.gx * a.gy);
+  a.units = (int)blend_units(1, s);
+  const unsigned grid = blend_grid_size(false, s), quads = 4u * (unsigned)(a.gx * a.gy);
   static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
   const int split = !split_ok || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);  // as the forward
   const dim3 g(grid), b(WAVE);

@@ -307,7 +307,7 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
                                     const void* binning, void* image, float* out_color, float* out_depth,
                                     uint64_t* records, int64_t max_records, int64_t* n_records_host) {
   if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
-  const int64_t n = (int64_t)blend_grid_size();
+  const int64_t n = (int64_t)blend_grid_size(false, (hipStream_t)stream);
   *n_records_host = n;
   if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
   if (P < 0 || R < 0 || W <= 0 || H <= 0 || !bg || !image || !out_color || !out_depth) return GSR_ERR_BAD_ARGUMENT;
@@ -386,7 +386,7 @@ int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int 
                                      float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
                                      int64_t max_records, int64_t* n_records_host) {
   if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
-  const int64_t n = (int64_t)blend_grid_size(true) / 4;
+  const int64_t n = (int64_t)blend_grid_size(true, (hipStream_t)stream) / 4;
   *n_records_host = n;
   if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
   if (P < 0 || R <= 0 || W <= 0 || H <= 0 || !bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;

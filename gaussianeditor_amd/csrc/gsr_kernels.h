@@ -134,7 +134,7 @@ hipError_t launch_append_rows(hipStream_t s, int64_t P, int64_t n, int nt, const
 hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
                             double beta2, double eps, const uint8_t* row_mask, const float* row_weight);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
-unsigned blend_grid_size(bool backward = false);
+unsigned blend_grid_size(bool backward, hipStream_t s);  // persistent waves of a blend launch on the device of stream s
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a);
 

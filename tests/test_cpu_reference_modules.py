@@ -175,3 +175,15 @@ def test_reference_model_loads_and_saves_through_the_shims(reference_modules, tm
     assert len(el["x"]) == P and np.allclose(np.asarray(el["x"]), gm._xyz[:, 0].numpy())
     assert np.allclose(np.asarray(el["f_rest_44"]), gm._features_rest.transpose(1, 2).flatten(start_dim=1)[:, 44].numpy())
     assert np.allclose(np.asarray(el["rot_3"]), gm._rotation[:, 3].numpy())
+    # the one-command asset path (gaussianeditor_amd/scene_ply.py, bench.py --ply): what the reference's writer wrote comes
+    # back, tensor for tensor, in the shapes load_ply (:455-533) produces; and a file written by scene_ply is byte-identical
+    from gaussianeditor_amd import scene_ply
+
+    back = scene_ply.load_gaussians_ply(path)
+    for k, t in (("xyz", gm._xyz), ("f_dc", gm._features_dc), ("f_rest", gm._features_rest), ("opacity", gm._opacity),
+                 ("scaling", gm._scaling), ("rotation", gm._rotation)):
+        assert torch.equal(back[k], t), k
+    assert back["max_sh_degree"] == 3
+    mine = str(tmp_path / "pc" / "mine.ply")
+    scene_ply.save_gaussians_ply(mine, gm._xyz, gm._features_dc, gm._features_rest, gm._opacity, gm._scaling, gm._rotation)
+    assert open(mine, "rb").read() == open(path, "rb").read()

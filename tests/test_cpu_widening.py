@@ -257,3 +257,40 @@ def test_fused_adam_rejects_stale_anchor_state():
     opt.set_anchor(q, torch.zeros(10, 3), 1.0, row_weight=torch.ones(8))  # a weight vector of the old length
     with pytest.raises(RuntimeError):  # CPU tensors: "no CPU fallback" is raised first on this machine; on the GPU the length check
         opt.step()
+
+
+def test_scene_ply_round_trip_and_layout(tmp_path):
+    """gaussianeditor_amd.scene_ply against the byte layout of GaussianModel.save_ply / load_ply
+    (gaussiansplatting/scene/gaussian_model.py:396-445, 455-533): column order, channel-major f_dc / f_rest, raw (logit /
+    log) values, and the round trip through the file."""
+    import torch
+
+    from gaussianeditor_amd import scene_ply
+    from gaussianeditor_amd.compat import plyfile
+
+    g = torch.Generator().manual_seed(2)
+    P = 37
+    raw = dict(xyz=torch.randn(P, 3, generator=g), f_dc=torch.randn(P, 1, 3, generator=g), f_rest=torch.randn(P, 15, 3, generator=g),
+               opacity=torch.randn(P, 1, generator=g), scaling=torch.randn(P, 3, generator=g), rotation=torch.randn(P, 4, generator=g))
+    path = str(tmp_path / "point_cloud.ply")
+    scene_ply.save_gaussians_ply(path, **raw)
+    v = plyfile.PlyData.read(path).elements[0]
+    names = [p.name for p in v.properties]
+    assert names[:6] == ["x", "y", "z", "nx", "ny", "nz"] and names[6:9] == ["f_dc_0", "f_dc_1", "f_dc_2"]
+    assert names[9:54] == [f"f_rest_{i}" for i in range(45)] and names[54:] == ["opacity", "scale_0", "scale_1", "scale_2",
+                                                                                  "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert all(p.val_dtype == "f4" for p in v.properties) and len(v.data) == P
+    # channel-major: f_rest_k for k < 15 is the RED channel of coefficient 1 + k (save_ply transposes (P,15,3) -> (P,3,15))
+    assert np.array_equal(np.asarray(v["f_rest_3"]), raw["f_rest"][:, 3, 0].numpy())
+    assert np.array_equal(np.asarray(v["f_rest_18"]), raw["f_rest"][:, 3, 1].numpy())
+    assert np.array_equal(np.asarray(v["nx"]), np.zeros(P, np.float32))
+    back = scene_ply.load_gaussians_ply(path)
+    assert back["max_sh_degree"] == 3
+    for k, t in raw.items():
+        assert torch.equal(back[k], t), k
+    act = scene_ply.activated(back)
+    assert act["features"].shape == (P, 16, 3) and torch.allclose(act["rotation"].norm(dim=1), torch.ones(P))
+    assert torch.equal(act["opacity"], torch.sigmoid(raw["opacity"])) and torch.equal(act["scaling"], torch.exp(raw["scaling"]))
+    # SH degree 1 file (3 * 4 - 3 = 9 f_rest columns)
+    scene_ply.save_gaussians_ply(path, raw["xyz"], raw["f_dc"], raw["f_rest"][:, :3], raw["opacity"], raw["scaling"], raw["rotation"])
+    assert scene_ply.load_gaussians_ply(path)["max_sh_degree"] == 1

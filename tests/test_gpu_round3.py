@@ -63,3 +63,39 @@ def _lists_match(case):
 def test_grouped_binning_shapes(oracle, P, W, H, s0):
     R, f = _lists_match(make_case(P, W, H, seed=9, s0=s0))
     print(f"P={P} {W}x{H} s0={s0}: R={R}, {R / max(1, int((f['radii'] > 0).sum())):.1f} tiles per visible Gaussian")
+
+
+def test_scene_from_ply_renders_like_the_oracle_and_benches(oracle, tmp_path):
+    """The one-command asset path for BASELINE configs[1] (a trained point_cloud.ply): a scene written in the reference's
+    save_ply layout (gaussiansplatting/scene/gaussian_model.py:410-445), loaded back as load_ply does (:455-533), activated
+    as the model's getters do and rendered on the GPU equals the oracle's render of the same loaded tensors; and
+    `bench.py --ply` takes the file."""
+    import json
+    import math
+
+    from gaussianeditor_amd import scene_ply
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    case = make_case(30000, 640, 360, seed=13, s0=0.03)
+    sc, cam = case["sc"], case["cam"]
+    path = str(tmp_path / "point_cloud.ply")
+    scene_ply.save_gaussians_ply(path, sc["xyz"], sc["features"][:, :1], sc["features"][:, 1:], torch.logit(sc["opacity"]),
+                                 torch.log(sc["scaling"]), sc["rotation"] * 1.7)  # (the file holds UNNORMALISED quaternions)
+    loaded = scene_ply.activated(scene_ply.load_gaussians_ply(path))
+    assert loaded["features"].shape == (30000, 16, 3)
+    f = oracle.forward(loaded["xyz"], loaded["scaling"], loaded["rotation"], loaded["opacity"], loaded["features"], None, None,
+                       cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], 640, 360, case["tfx"],
+                       case["tfy"], 1.0, 3)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    rs = GaussianRasterizationSettings(360, 640, case["tfx"], case["tfy"], d(case["bg"]), 1.0, d(cam.world_view_transform),
+                                       d(cam.full_proj_transform), 3, d(cam.camera_center), False, False)
+    color, radii, depth = GaussianRasterizer(rs)(d(loaded["xyz"]), torch.zeros(30000, 3, device=DEV), d(loaded["opacity"]),
+                                                 shs=d(loaded["features"]), scales=d(loaded["scaling"]), rotations=d(loaded["rotation"]))
+    assert np.array_equal(radii.cpu().numpy(), f["radii"]) and np.array_equal(color.cpu().numpy(), f["color"])
+    assert np.array_equal(depth.cpu().numpy(), f["depth"])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--ply", path, "--steps", "3", "--warmup", "1", "--width", "640",
+                        "--height", "360", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["gaussians"] == 30000 and "point_cloud.ply" in line["config"]["workload"] and line["value"] > 0
+    assert math.isfinite(line["forward_ms"]) and line["config"]["num_rendered"] > 0
