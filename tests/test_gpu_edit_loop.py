@@ -107,15 +107,28 @@ class Model:
         self.denom = torch.zeros((P, 1), device=DEV)
         self.max_radii2D = torch.zeros((P,), device=DEV)
         self.mask = torch.ones(P, dtype=torch.bool, device=DEV)
-        groups = [dict(params=[self.p[k]], lr=LR[k], name=k, **({"masked": k in MASKED} if stack == "product" else {}))
+        product = stack.startswith("product")
+        groups = [dict(params=[self.p[k]], lr=LR[k], name=k, **({"masked": k in MASKED} if product else {}))
                   for k in NAMES]  # training_setup, gaussian_model.py:336-380
-        if stack == "product":
+        if product:
             from gaussianeditor_amd.optim import FusedMaskedAdam
 
             self.optimizer = FusedMaskedAdam(groups, lr=0.0, eps=1e-15)
         else:
             self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
         self.hooks = []
+        self.oa = None
+        if stack == "product-arena":  # every per-Gaussian tensor a view of ONE buffer (gaussianeditor_amd/arena.py)
+            from gaussianeditor_amd.arena import OptimizerArena
+
+            self.oa = OptimizerArena(self.optimizer, extra=dict(xyz_gradient_accum=self.xyz_gradient_accum, denom=self.denom,
+                                                                max_radii2D=self.max_radii2D, mask=self.mask))
+            self._from_arena()
+
+    def _from_arena(self):
+        self.p = dict(self.oa.params())
+        e = self.oa.extra
+        self.xyz_gradient_accum, self.denom, self.max_radii2D, self.mask = e["xyz_gradient_accum"], e["denom"], e["max_radii2D"], e["mask"]
 
     P = property(lambda s: int(s.p["xyz"].shape[0]))
     get_xyz = property(lambda s: s.p["xyz"])
@@ -125,11 +138,14 @@ class Model:
     get_features = property(lambda s: torch.cat((s.p["f_dc"], s.p["f_rest"]), dim=1))
 
     def apply_grad_mask(self, mask):  # gaussian_model.py:837-856
+        if self.oa is not None and mask.data_ptr() != self.oa.extra["mask"].data_ptr():
+            self.oa.extra["mask"].copy_(mask)  # the mask lives in the arena, too
+            mask = self.oa.extra["mask"]
         self.mask = mask
         for h in self.hooks:
             h.remove()
         self.hooks = []
-        if self.stack == "product":
+        if self.stack.startswith("product"):
             self.optimizer.set_row_mask(mask)  # the mask is applied inside the fused step
             return
         for k in MASKED:
@@ -161,7 +177,10 @@ class Model:
 
     def _prune(self, remove):  # prune_points + _prune_optimizer, gaussian_model.py:568-607
         keep = ~remove
-        if self.stack == "product":
+        if self.oa is not None:
+            self.oa.prune(keep)
+            self._from_arena()
+        elif self.stack == "product":
             from gaussianeditor_amd.densify import compact_rows, prune_optimizer
 
             self.p = dict(prune_optimizer(self.optimizer, keep))
@@ -186,11 +205,19 @@ class Model:
             self.max_radii2D = self.max_radii2D[keep]
             self.mask = self.mask[keep]
 
-    def _postfix(self, ext):  # densification_postfix, gaussian_model.py:643-671
+    def _postfix(self, ext, new_mask):  # densification_postfix, gaussian_model.py:643-671 (+ the mask's cat, :751 / :705-706)
+        if self.oa is not None:
+            self.oa.append(ext, extra=dict(mask=new_mask))  # new rows behind the live ones; the statistics get zero rows ...
+            self._from_arena()
+            self.xyz_gradient_accum.zero_()                 # ... and are reset as a whole, as the reference does
+            self.denom.zero_()
+            self.max_radii2D.zero_()
+            return
         self._cat(ext)
         self.xyz_gradient_accum = torch.zeros((self.P, 1), device=DEV)
         self.denom = torch.zeros((self.P, 1), device=DEV)
         self.max_radii2D = torch.zeros((self.P,), device=DEV)
+        self.mask = torch.cat([self.mask, new_mask], dim=0)
 
     @torch.no_grad()
     def densify_and_prune(self, seed):  # gaussian_model.py:768-809
@@ -203,8 +230,7 @@ class Model:
         # densify_and_clone, :730-766
         sel = (torch.norm(grads, dim=-1) >= MAX_GRAD) & (self.get_scaling.max(dim=1).values <= PERCENT_DENSE * EXTENT)
         n_clone = int(sel.sum())
-        self._postfix({k: self.p[k][sel] for k in NAMES})
-        self.mask = torch.cat([self.mask, self.mask[sel]], dim=0)
+        self._postfix({k: self.p[k][sel] for k in NAMES}, self.mask[sel])
         # densify_and_split, :673-728 (N = 2)
         n_init = self.P
         padded = torch.zeros((n_init,), device=DEV)
@@ -219,9 +245,7 @@ class Model:
                    scaling=torch.log(self.get_scaling[sel].repeat(2, 1) / (0.8 * 2)), rotation=self.p["rotation"][sel].repeat(2, 1),
                    f_dc=self.p["f_dc"][sel].repeat(2, 1, 1), f_rest=self.p["f_rest"][sel].repeat(2, 1, 1),
                    opacity=self.p["opacity"][sel].repeat(2, 1))
-        new_mask = torch.cat([self.mask[sel]] * 2, dim=0)
-        self._postfix(ext)
-        self.mask = torch.cat([self.mask, new_mask], dim=0)
+        self._postfix(ext, torch.cat([self.mask[sel]] * 2, dim=0))
         self._prune(torch.cat((sel, torch.zeros(2 * n_split, device=DEV, dtype=torch.bool))))
         # prune, :787-797
         prune = (self.get_opacity < MIN_OPACITY).squeeze()
@@ -239,7 +263,7 @@ def _cam_to(cam):
 
 def _render(model, cam, bg, override_color=None, semantic_color=None):
     """render(), gaussiansplatting/gaussian_renderer/__init__.py:45-150, on the stack of `model`."""
-    if model.stack == "product":
+    if model.stack.startswith("product"):
         from types import SimpleNamespace
 
         from gaussianeditor_amd.gaussian_renderer import render
@@ -263,7 +287,7 @@ def _trace_mask(model, cams, masks2d):
     cnt = torch.zeros((P, 1), dtype=torch.int32, device=DEV)
     with torch.no_grad():
         for cam, m in zip(cams, masks2d):
-            if model.stack == "product":
+            if model.stack.startswith("product"):
                 from gaussianeditor_amd.gaussian_renderer import camera2rasterizer
 
                 camera2rasterizer(cam, torch.zeros(3, device=DEV)).apply_weights(
@@ -292,7 +316,7 @@ def _run(stack, sc, cams, trace_cams, masks2d, targets, record):
         for ci in batch:  # GassuianEditor.forward, :155-224
             cam = cams[ci]
             sem_color = model.mask[..., None].float().repeat(1, 3)
-            if stack == "product":  # one pass: the SH image + the semantic image from the same preprocessing / lists
+            if stack.startswith("product"):  # one pass: the SH image + the semantic image from the same preprocessing / lists
                 out = _render(model, cam, bg, semantic_color=sem_color)
                 semantic = out["semantic"]
             else:
@@ -325,6 +349,7 @@ def _run(stack, sc, cams, trace_cams, masks2d, targets, record):
     torch.cuda.synchronize()
     record["params"] = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in model.p.items()}
     record["mask"] = model.mask.cpu()
+    record["arena_allocations"] = None if model.oa is None else model.oa.arena.allocations
     return record
 
 
@@ -349,6 +374,14 @@ def test_edit_loop_product_vs_reference_stack():
         targets.append((0.15 + 0.7 * t.float() * torch.rand(1, generator=g).item()).to(DEV))
     a = _run("reference", sc, cams, trace_cams, masks2d, targets, {})
     b = _run("product", sc, cams, trace_cams, masks2d, targets, {})
+    c = _run("product-arena", sc, cams, trace_cams, masks2d, targets, {})
+    # --- the arena (prune = compaction into the other half, densify = rows appended in place, Parameters re-pointed) changes
+    # WHERE the tensors live, nothing else: the same counts, masks and losses as with fresh tensors, and parameters equal to
+    # the backward's run-to-run spread (its float atomics re-associate); ONE buffer for the whole run
+    assert c["P"] == b["P"] and c["densify"] == b["densify"] and torch.equal(c["mask"], b["mask"])
+    assert c["arena_allocations"] == 1
+    for k in NAMES:
+        assert np.abs(c["params"][k] - b["params"][k]).max() <= 1e-5 * max(np.abs(b["params"][k]).max(), 1e-30), k
 
     # --- the per-Gaussian mask traced from the 2-D masks.  cnt is an integer per Gaussian; it may differ only where a pixel's
     # alpha / transmittance sits within a rounding of a threshold under libm's exp (reference) vs gsr_expf (product) -- the

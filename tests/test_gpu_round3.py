@@ -99,3 +99,60 @@ def test_scene_from_ply_renders_like_the_oracle_and_benches(oracle, tmp_path):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["config"]["gaussians"] == 30000 and "point_cloud.ply" in line["config"]["workload"] and line["value"] > 0
     assert math.isfinite(line["forward_ms"]) and line["config"]["num_rendered"] > 0
+
+
+def test_row_arena_prune_and_append_bit_exact():
+    """gaussianeditor_amd/arena.py: compaction into the other half and in-place appends equal `tensor[mask]` / `torch.cat`
+    bit for bit for the row shapes of a Gaussian model (gaussiansplatting/scene/gaussian_model.py:568-641), views stay
+    inside ONE buffer until an append overflows it, and the optimizer keeps its Parameter objects and moments."""
+    from gaussianeditor_amd.arena import OptimizerArena, RowArena
+
+    g = torch.Generator(device=DEV).manual_seed(5)
+    P = 10007
+    t = dict(xyz=torch.randn(P, 3, device=DEV, generator=g), f_rest=torch.randn(P, 15, 3, device=DEV, generator=g),
+             opacity=torch.randn(P, 1, device=DEV, generator=g), rot=torch.randn(P, 4, device=DEV, generator=g),
+             radii=torch.randint(0, 99, (P,), device=DEV, generator=g, dtype=torch.int32),
+             mask=torch.rand(P, device=DEV, generator=g) > 0.5)
+    want = {k: v.clone() for k, v in t.items()}
+    A = RowArena(t, headroom=1.2)
+    base = A._buf.data_ptr()
+    for step in range(4):
+        keep = torch.rand(A.P, device=DEV, generator=g) > 0.1
+        A.compact(keep)
+        want = {k: v[keep] for k, v in want.items()}
+        n = 300 + 7 * step
+        ext = {"xyz": torch.randn(n, 3, device=DEV, generator=g), "f_rest": torch.randn(n, 15, 3, device=DEV, generator=g),
+               "rot": torch.randn(n, 4, device=DEV, generator=g), "mask": torch.rand(n, device=DEV, generator=g) > 0.5}
+        A.append(ext, n=n)  # opacity and radii: zero rows
+        want = {k: torch.cat((v, ext[k] if k in ext else torch.zeros((n,) + tuple(v.shape[1:]), dtype=v.dtype, device=DEV)))
+                for k, v in want.items()}
+        for k in want:
+            assert A[k].dtype == want[k].dtype and torch.equal(A[k], want[k]), (step, k)
+        assert A.P == want["xyz"].shape[0] and A.allocations == 1 and A._buf.data_ptr() == base
+    A.append({"xyz": torch.zeros(P * 2, 3, device=DEV)}, n=P * 2)  # does not fit: the arena grows once
+    assert A.allocations == 2 and torch.equal(A["xyz"][:want["xyz"].shape[0]], want["xyz"]) and float(A["opacity"][-1]) == 0.0
+    A.compact(torch.zeros(A.P, dtype=torch.bool, device=DEV))
+    assert A.P == 0 and A["f_rest"].shape == (0, 15, 3)
+    # with an optimizer: the Parameters and the state dictionary survive, the moments follow the rows
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    p1 = torch.nn.Parameter(torch.randn(500, 3, device=DEV, generator=g))
+    p2 = torch.nn.Parameter(torch.randn(500, 1, device=DEV, generator=g))
+    opt = FusedMaskedAdam([dict(params=[p1], lr=1e-2, name="xyz"), dict(params=[p2], lr=1e-2, name="opacity")], lr=0.0, eps=1e-15)
+    (p1.sum() * 2 + (p2 ** 2).sum()).backward()
+    opt.step()
+    m_before, x_before = opt.state[p1]["exp_avg"].clone(), p1.detach().clone()
+    oa = OptimizerArena(opt, extra=dict(denom=torch.ones(500, 1, device=DEV)))  # (the groups now hold Parameters on arena views)
+    assert torch.equal(oa.params()["xyz"].detach(), x_before) and torch.equal(opt.state[oa.params()["xyz"]]["exp_avg"], m_before)
+    keep = torch.rand(500, device=DEV, generator=g) > 0.3
+    new = oa.prune(keep)
+    q1 = new["xyz"]
+    assert opt.param_groups[0]["params"][0] is q1 and q1.grad is None and q1.is_leaf and len(opt.state) == 2
+    assert torch.equal(q1.detach(), x_before[keep]) and torch.equal(opt.state[q1]["exp_avg"], m_before[keep])
+    new = oa.append({"xyz": torch.full((5, 3), 7.0, device=DEV), "opacity": torch.full((5, 1), 8.0, device=DEV)})
+    q1, q2 = new["xyz"], new["opacity"]
+    assert q1.shape[0] == int(keep.sum()) + 5 and float(q1.detach()[-1, 0]) == 7.0 and float(opt.state[q1]["exp_avg"][-5:].abs().sum()) == 0.0
+    assert float(oa.extra["denom"][-5:].abs().sum()) == 0.0 and float(oa.extra["denom"][0]) == 1.0
+    (q1.sum() + q2.sum()).backward()
+    opt.step()  # the grown optimizer keeps stepping
+    assert int(opt.state[q1]["step"]) == 2 and len(opt.state) == 2
