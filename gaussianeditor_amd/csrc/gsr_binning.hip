@@ -52,20 +52,21 @@ constexpr int RBINS = 1 << RBITS;
 // depth keys) and writes the four words into the caller's pinned, device-mapped host buffer -- the readback of
 // gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before) and without a
 // header to clear in front of K1.
-template <class K>
-__global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int shift,
+// TH threads per block (256, or 1024 for sorts of few blocks: see radix_sort_pairs), SORT_KPB / TH keys per thread.
+template <class K, int TH>
+__global__ void __launch_bounds__(TH) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t nblocks, const uint4* __restrict__ publish_src,
                                                                 uint32_t publish_count, uint32_t* __restrict__ publish_dst,
                                                                 uint32_t publish_seq) {
   __shared__ uint32_t h[RBINS];
   if (publish_dst != nullptr && blockIdx.x == 0) {
-    __shared__ unsigned long long psum[SORT_THREADS / 64];
-    __shared__ uint32_t pmax[SORT_THREADS / 64], pinv[SORT_THREADS / 64];
-    __shared__ unsigned long long pgrp[SORT_THREADS / 64];
+    __shared__ unsigned long long psum[TH / 64];
+    __shared__ uint32_t pmax[TH / 64], pinv[TH / 64];
+    __shared__ unsigned long long pgrp[TH / 64];
     unsigned long long sum = 0, gsum = 0;
     uint32_t kmax = 0, kinv = 0;
-    for (uint32_t i = threadIdx.x; i < publish_count; i += SORT_THREADS) {
+    for (uint32_t i = threadIdx.x; i < publish_count; i += TH) {
       const uint4 v = publish_src[i];
       sum += v.x;
       gsum += v.w;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __rest
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      for (int w = 1; w < SORT_THREADS / 64; ++w) {
+      for (int w = 1; w < TH / 64; ++w) {
         sum += psum[w];
         gsum += pgrp[w];
         kmax = max(kmax, pmax[w]);
@@ -104,24 +105,24 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_hist_kernel(const K* __rest
       __hip_atomic_store(publish_dst + GEOM_HDR_FINAL, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  h[threadIdx.x] = 0;
+  if (threadIdx.x < RBINS) h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
-  // all 16 loads of a thread are issued back to back (unconditional, index clamped): the kernel runs one 4-wave block
-  // per CU and is bound by memory latency, not by bandwidth or the LDS atomics
-  uint32_t kv[SORT_ITEMS];
+  // all loads of a thread are issued back to back (unconditional, index clamped): the kernel is bound by memory latency,
+  // not by bandwidth or the LDS atomics
+  uint32_t kv[(SORT_KPB / TH)];
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+  for (int i = 0; i < (SORT_KPB / TH); ++i) {
+    const int64_t k = base + (int64_t)i * TH + threadIdx.x;
     kv[i] = (uint32_t)keys[k < n ? k : n - 1];
   }
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+  for (int i = 0; i < (SORT_KPB / TH); ++i) {
+    const int64_t k = base + (int64_t)i * TH + threadIdx.x;
     if (k < n) atomicAdd(&h[(kv[i] >> shift) & mask], 1u);
   }
   __syncthreads();
-  hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < RBINS) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 // One block per bin; exclusive scan of that bin's nblocks counts in place.  Every thread takes SCAN_PER consecutive counts
@@ -158,48 +159,48 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scan_kernel(uint32_t* __res
 // (lower lanes with the same digit in this iteration, from 8 ballots).  The block's pairs are then
 // permuted into digit order IN LDS and written out with consecutive threads covering consecutive
 // sorted slots, so every digit's run is one contiguous global store stream.
-template <bool IOTA, class K>
-__global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const K* __restrict__ keys_in,
+template <bool IOTA, class K, int TH>
+__global__ void __launch_bounds__(TH) sort_scatter_kernel(const K* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    K* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, int64_t n, int shift,
                                                                    uint32_t mask, const uint32_t* __restrict__ hist,
                                                                    const uint32_t* __restrict__ bin_total,
                                                                    uint32_t nblocks) {
-  constexpr int NW = SORT_THREADS / 64;
+  constexpr int NW = TH / 64, ITEMS = SORT_KPB / TH;  // waves per block, keys per thread (a wave owns 64 * ITEMS consecutive keys)
   __shared__ uint32_t cnt[NW][RBINS];   // per-wave digit counts -> per-wave local bases
   __shared__ uint32_t gbase[RBINS];     // global position of the block's first key of each digit
   __shared__ uint32_t lexcl[RBINS];     // position of each digit's run inside the block-sorted order
-  __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
+  __shared__ uint32_t smem[TH / 64 + 1];
   __shared__ uint32_t skey[SORT_KPB];
   __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
   const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
-  const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
-  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
-  uint16_t rank[SORT_ITEMS];
+  const int64_t wbase = bbase + (int64_t)w * (ITEMS * 64);
+  uint32_t key[ITEMS], val[ITEMS];
+  uint16_t rank[ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
   // the block's pairs are requested first, so that they travel while the digit bases below are loaded and scanned
   // (no load crosses a barrier on its own)
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
     key[i] = (uint32_t)keys_in[kc];
     val[i] = IOTA ? (uint32_t)kc : vals_in[kc];
   }
-  const uint32_t my_hist = hist[(size_t)threadIdx.x * nblocks + blockIdx.x];
-#pragma unroll
-  for (int i = 0; i < NW; ++i) cnt[i][threadIdx.x] = 0;
+  const bool owns_bin = threadIdx.x < RBINS;  // thread d < 256 owns digit d
+  const uint32_t my_hist = owns_bin ? hist[(size_t)threadIdx.x * nblocks + blockIdx.x] : 0u;
+  for (int i = threadIdx.x; i < NW * RBINS; i += TH) (&cnt[0][0])[i] = 0;
   {
     uint32_t tot;
-    const uint32_t run = block_excl_scan_u32<SORT_THREADS>(bin_total[threadIdx.x], &tot, smem);
-    gbase[threadIdx.x] = run + my_hist;
+    const uint32_t run = block_excl_scan_u32<TH>(owns_bin ? bin_total[threadIdx.x] : 0u, &tot, smem);
+    if (owns_bin) gbase[threadIdx.x] = run + my_hist;
   }
   __syncthreads();
 
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const bool valid = k < n;
     const uint32_t d = (key[i] >> shift) & mask;
@@ -220,18 +221,21 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const K* __r
   {
     // per digit: block total, exclusive prefix over the waves, and the digit's offset in block-sorted order
     uint32_t run = 0;
+    if (owns_bin) {
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const uint32_t c = cnt[i][threadIdx.x];
-      cnt[i][threadIdx.x] = run;
-      run += c;
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t c = cnt[i][threadIdx.x];
+        cnt[i][threadIdx.x] = run;
+        run += c;
+      }
     }
     uint32_t tot;
-    lexcl[threadIdx.x] = block_excl_scan_u32<SORT_THREADS>(run, &tot, smem);
+    const uint32_t ex = block_excl_scan_u32<TH>(run, &tot, smem);
+    if (owns_bin) lexcl[threadIdx.x] = ex;
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     if (k < n) {
       const uint32_t d = (key[i] >> shift) & mask;
@@ -243,8 +247,8 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const K* __r
   __syncthreads();
   const int nvalid = (int)min((int64_t)SORT_KPB, n - bbase);
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int j = i * SORT_THREADS + (int)threadIdx.x;
+  for (int i = 0; i < ITEMS; ++i) {
+    const int j = i * TH + (int)threadIdx.x;
     if (j < nvalid) {
       const uint32_t kk = skey[j];
       const uint32_t d = (kk >> shift) & mask;
@@ -255,6 +259,33 @@ __global__ void __launch_bounds__(SORT_THREADS) sort_scatter_kernel(const K* __r
   }
 }
 
+// A sort of few blocks (the depth order of ~10^6 Gaussians is 245 blocks on 256 CUs) is bound by the latency of ONE block:
+// with 1024 threads a block's 4096 keys are ranked by 16 waves in 4 rounds instead of by 4 waves in 16.  Many-block sorts
+// keep 256 threads (more blocks resident per CU).
+constexpr uint32_t SORT_WIDE_MAX_BLOCKS = 1024;
+template <class K, int TH>
+static void radix_sort_pairs_th(hipStream_t s, K* const keys[2], uint32_t* const vals[2], int64_t n, int npass,
+                                const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0,
+                                const uint4* publish_src, uint32_t publish_count, uint32_t* publish_dst, uint32_t publish_seq) {
+  const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
+  int cur = p0 & 1, shift = 0;
+  for (int p = 0; p < p0; ++p) shift += digit_bits[p];
+  for (int p = p0; p < npass; ++p) {
+    const uint32_t mask = (1u << digit_bits[p]) - 1u;
+    const bool pub = p == p0 && publish_dst != nullptr;
+    hipLaunchKernelGGL((sort_hist_kernel<K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur], n, shift, mask, hist, nblocks,
+                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
+    if (p == 0 && iota_first)
+      hipLaunchKernelGGL((sort_scatter_kernel<true, K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur],
+                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+    else
+      hipLaunchKernelGGL((sort_scatter_kernel<false, K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur],
+                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
+    shift += digit_bits[p];
+    cur ^= 1;
+  }
+}
 // Sorts (keys[0], vals[0]) by key bits [0, sum(digits)); result in buffer (npass & 1).  Passes [p0, npass) of the
 // sequence are launched (pass p reads buffer p & 1), so a caller can enqueue a prefix of the passes, decide how
 // many more are needed and continue.
@@ -263,24 +294,12 @@ static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const va
                              const int* digit_bits, uint32_t* hist, uint32_t* bin_total, bool iota_first, int p0 = 0,
                              const uint4* publish_src = nullptr, uint32_t publish_count = 0, uint32_t* publish_dst = nullptr,
                              uint32_t publish_seq = 0) {
-  const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
-  int cur = p0 & 1, shift = 0;
-  for (int p = 0; p < p0; ++p) shift += digit_bits[p];
-  for (int p = p0; p < npass; ++p) {
-    const uint32_t mask = (1u << digit_bits[p]) - 1u;
-    const bool pub = p == p0 && publish_dst != nullptr;
-    hipLaunchKernelGGL(sort_hist_kernel<K>, dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur], n, shift, mask, hist, nblocks,
-                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
-    hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
-    if (p == 0 && iota_first)
-      hipLaunchKernelGGL((sort_scatter_kernel<true, K>), dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur],
-                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
-    else
-      hipLaunchKernelGGL((sort_scatter_kernel<false, K>), dim3(nblocks), dim3(SORT_THREADS), 0, s, (const K*)keys[cur],
-                         (const uint32_t*)vals[cur], keys[cur ^ 1], vals[cur ^ 1], n, shift, mask, hist, bin_total, nblocks);
-    shift += digit_bits[p];
-    cur ^= 1;
-  }
+  if ((uint32_t)((n + SORT_KPB - 1) / SORT_KPB) <= SORT_WIDE_MAX_BLOCKS)
+    radix_sort_pairs_th<K, 1024>(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first, p0, publish_src, publish_count,
+                                 publish_dst, publish_seq);
+  else
+    radix_sort_pairs_th<K, SORT_THREADS>(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first, p0, publish_src,
+                                         publish_count, publish_dst, publish_seq);
 }
 
 // ----------------------------------------------------------------------------------
@@ -633,37 +652,37 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
 // histogram of the pass + the padding value into every KEY slot of the output side (the scatter overwrites the real ones:
 // what remains are the padding slots between the segments and behind the last one; a real key never equals GROUP_PAD,
 // its local rectangle has 12 bits)
-template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) group_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
+template <int BITS, int TH>
+__global__ void __launch_bounds__(TH) group_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
                                                                  uint32_t* __restrict__ hist, uint32_t nblocks,
                                                                  uint32_t* __restrict__ fill_dst, int64_t fill_n) {
   constexpr int NB = 1 << BITS;
   __shared__ uint32_t h[NB];
-  for (int i = threadIdx.x; i < NB; i += SORT_THREADS) h[i] = 0;
+  for (int i = threadIdx.x; i < NB; i += TH) h[i] = 0;
   {
     const int64_t per = (fill_n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(lo + per, fill_n);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += SORT_THREADS) fill_dst[i] = GROUP_PAD;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += TH) fill_dst[i] = GROUP_PAD;
   }
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
-  uint32_t kv[SORT_ITEMS];
+  uint32_t kv[(SORT_KPB / TH)];
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+  for (int i = 0; i < (SORT_KPB / TH); ++i) {
+    const int64_t k = base + (int64_t)i * TH + threadIdx.x;
     kv[i] = (uint32_t)keys[k < n ? k : n - 1];
   }
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int64_t k = base + (int64_t)i * SORT_THREADS + threadIdx.x;
+  for (int i = 0; i < (SORT_KPB / TH); ++i) {
+    const int64_t k = base + (int64_t)i * TH + threadIdx.x;
     if (k < n) atomicAdd(&h[kv[i] & (NB - 1)], 1u);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < NB; i += SORT_THREADS) hist[(size_t)i * nblocks + blockIdx.x] = h[i];
+  for (int i = threadIdx.x; i < NB; i += TH) hist[(size_t)i * nblocks + blockIdx.x] = h[i];
 }
 
 // sort_scatter_kernel with 2^BITS bins and padded segment starts; ranks from BITS ballots per key (stable).
-template <int BITS>
-__global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint32_t* __restrict__ keys_in,
+template <int BITS, int TH>
+__global__ void __launch_bounds__(TH) group_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                     const uint32_t* __restrict__ vals_in,
                                                                     uint32_t* __restrict__ keys_out,
                                                                     uint32_t* __restrict__ vals_out, int64_t n,
@@ -671,21 +690,23 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint3
                                                                     const uint32_t* __restrict__ bin_total,
                                                                     uint32_t nblocks, uint32_t chunk,
                                                                     uint32_t* __restrict__ group_first) {
-  constexpr int NB = 1 << BITS, NW = SORT_THREADS / 64, BPT = NB / SORT_THREADS;  // bins per thread (consecutive)
+  constexpr int NB = 1 << BITS, NW = TH / 64, ITEMS = SORT_KPB / TH;
+  constexpr int BT = NB < TH ? NB : TH, BPT = NB / BT;  // the first BT threads own BPT consecutive bins each
+  const bool owns = (int)threadIdx.x < BT;
   __shared__ uint16_t cnt[NW][NB];     // per-wave digit counts -> per-wave local bases
   __shared__ uint32_t gbase[NB];       // global position of the block's first key of each digit
   __shared__ uint16_t lexcl[NB];       // position of each digit's run inside the block-sorted order
-  __shared__ uint32_t smem[SORT_THREADS / 64 + 1];
+  __shared__ uint32_t smem[TH / 64 + 1];
   __shared__ uint32_t skey[SORT_KPB];
   __shared__ uint32_t sval[SORT_KPB];
   const int w = (int)(threadIdx.x >> 6), l = lane_id();
   const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
-  const int64_t wbase = bbase + (int64_t)w * (SORT_ITEMS * 64);
-  uint32_t key[SORT_ITEMS], val[SORT_ITEMS];  // key: group id (the digit) | local rectangle << 16 (payload)
-  uint16_t rank[SORT_ITEMS];
+  const int64_t wbase = bbase + (int64_t)w * (ITEMS * 64);
+  uint32_t key[ITEMS], val[ITEMS];  // key: group id (the digit) | local rectangle << 16 (payload)
+  uint16_t rank[ITEMS];
   const uint64_t lt_mask = (1ull << l) - 1ull;
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
     key[i] = keys_in[kc];
@@ -696,28 +717,30 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint3
     uint32_t padded[BPT], mine[BPT], sum = 0;
 #pragma unroll
     for (int j = 0; j < BPT; ++j) {
-      const uint32_t d = threadIdx.x * BPT + j;
-      const uint32_t tot = bin_total[d];
+      const uint32_t d = owns ? threadIdx.x * BPT + j : 0u;
+      const uint32_t tot = owns ? bin_total[d] : 0u;
       padded[j] = (tot + chunk - 1u) / chunk * chunk;
-      mine[j] = hist[(size_t)d * nblocks + blockIdx.x];
+      mine[j] = owns ? hist[(size_t)d * nblocks + blockIdx.x] : 0u;
       sum += padded[j];
     }
     uint32_t tot;
-    uint32_t run = block_excl_scan_u32<SORT_THREADS>(sum, &tot, smem);
+    uint32_t run = block_excl_scan_u32<TH>(sum, &tot, smem);
+    if (owns) {
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) {
-      gbase[threadIdx.x * BPT + j] = run + mine[j];
-      // row of the group's first chunk in the per-chunk tables (+ one entry behind the last group), for group_colscan_kernel
-      if (blockIdx.x == 0) group_first[threadIdx.x * BPT + j] = run / chunk;
-      run += padded[j];
+      for (int j = 0; j < BPT; ++j) {
+        gbase[threadIdx.x * BPT + j] = run + mine[j];
+        // row of the group's first chunk in the per-chunk tables (+ one entry behind the last group), for group_colscan_kernel
+        if (blockIdx.x == 0) group_first[threadIdx.x * BPT + j] = run / chunk;
+        run += padded[j];
+      }
+      if (blockIdx.x == 0 && (int)threadIdx.x == BT - 1) group_first[NB] = run / chunk;
     }
-    if (blockIdx.x == 0 && threadIdx.x == SORT_THREADS - 1) group_first[NB] = run / chunk;
   }
-  for (int i = threadIdx.x; i < NW * NB; i += SORT_THREADS) (&cnt[0][0])[i] = 0;
+  for (int i = threadIdx.x; i < NW * NB; i += TH) (&cnt[0][0])[i] = 0;
   __syncthreads();
 
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     const bool valid = k < n;
     const uint32_t d = key[i] & (NB - 1);
@@ -740,28 +763,32 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint3
     uint32_t tot_d[BPT], sum = 0;
 #pragma unroll
     for (int j = 0; j < BPT; ++j) {
-      const uint32_t d = threadIdx.x * BPT + j;
+      const uint32_t d = owns ? threadIdx.x * BPT + j : 0u;
       uint32_t run = 0;
+      if (owns) {
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        const uint32_t c = cnt[i][d];
-        cnt[i][d] = (uint16_t)run;
-        run += c;
+        for (int i = 0; i < NW; ++i) {
+          const uint32_t c = cnt[i][d];
+          cnt[i][d] = (uint16_t)run;
+          run += c;
+        }
       }
       tot_d[j] = run;
       sum += run;
     }
     uint32_t tot;
-    uint32_t run = block_excl_scan_u32<SORT_THREADS>(sum, &tot, smem);
+    uint32_t run = block_excl_scan_u32<TH>(sum, &tot, smem);
+    if (owns) {
 #pragma unroll
-    for (int j = 0; j < BPT; ++j) {
-      lexcl[threadIdx.x * BPT + j] = (uint16_t)run;
-      run += tot_d[j];
+      for (int j = 0; j < BPT; ++j) {
+        lexcl[threadIdx.x * BPT + j] = (uint16_t)run;
+        run += tot_d[j];
+      }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const int64_t k = wbase + (int64_t)i * 64 + l;
     if (k < n) {
       const uint32_t d = key[i] & (NB - 1);
@@ -773,8 +800,8 @@ __global__ void __launch_bounds__(SORT_THREADS) group_scatter_kernel(const uint3
   __syncthreads();
   const int nvalid = (int)min((int64_t)SORT_KPB, n - bbase);
 #pragma unroll
-  for (int i = 0; i < SORT_ITEMS; ++i) {
-    const int j = i * SORT_THREADS + (int)threadIdx.x;
+  for (int i = 0; i < ITEMS; ++i) {
+    const int j = i * TH + (int)threadIdx.x;
     if (j < nvalid) {
       const uint32_t kk = skey[j], d = kk & (NB - 1);
       const uint32_t pos = gbase[d] + ((uint32_t)j - (uint32_t)lexcl[d]);
@@ -991,13 +1018,32 @@ __global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int g
   const uint16_t* __restrict__ src = chunk_cnt + (size_t)(first + r0) * GROUP_TILES + lane;
   uint32_t* __restrict__ out = chunk_pre + (size_t)(first + r0) * GROUP_TILES + lane;
   const uint32_t rows = r1 - r0;
-  uint32_t v[COLSCAN_REG];
+  // a slab is read COLSCAN_REG rows at a time, all loads of a round issued together (unconditionally, row index clamped: a
+  // predicated or a dependent load costs one memory round trip each -- the central groups of an image have several times
+  // the average number of chunks, and a row-by-row loop over their slabs made this kernel 14 us)
+  auto load_rows = [&](uint32_t first_row, uint32_t (&v)[COLSCAN_REG]) {
+    const uint32_t last = rows - 1u;
+    uint32_t raw[COLSCAN_REG];
+#pragma unroll
+    for (int i = 0; i < COLSCAN_REG; ++i) raw[i] = (uint32_t)src[(size_t)min(first_row + (uint32_t)i, last) * GROUP_TILES];
+#pragma unroll
+    for (int i = 0; i < COLSCAN_REG; ++i) v[i] = first_row + (uint32_t)i < rows ? raw[i] : 0u;
+  };
+  uint32_t v0[COLSCAN_REG];  // the first round stays in registers between the two steps
   uint32_t sum = 0;
 #pragma unroll
-  for (int i = 0; i < COLSCAN_REG; ++i) v[i] = (uint32_t)i < rows ? (uint32_t)src[(size_t)i * GROUP_TILES] : 0u;
+  for (int i = 0; i < COLSCAN_REG; ++i) v0[i] = 0u;
+  if (rows != 0u) {
+    load_rows(0u, v0);
 #pragma unroll
-  for (int i = 0; i < COLSCAN_REG; ++i) sum += v[i];
-  for (uint32_t r = COLSCAN_REG; r < rows; ++r) sum += src[(size_t)r * GROUP_TILES];
+    for (int i = 0; i < COLSCAN_REG; ++i) sum += v0[i];
+    for (uint32_t r = COLSCAN_REG; r < rows; r += COLSCAN_REG) {
+      uint32_t v[COLSCAN_REG];
+      load_rows(r, v);
+#pragma unroll
+      for (int i = 0; i < COLSCAN_REG; ++i) sum += v[i];
+    }
+  }
   slab[w][lane] = sum;
   __syncthreads();
   uint32_t run = 0, total = 0;
@@ -1010,11 +1056,16 @@ __global__ void __launch_bounds__(COLSCAN_WAVES * 64) group_colscan_kernel(int g
 #pragma unroll
   for (int i = 0; i < COLSCAN_REG; ++i) {
     if ((uint32_t)i < rows) out[(size_t)i * GROUP_TILES] = run;
-    run += v[i];
+    run += v0[i];
   }
-  for (uint32_t r = COLSCAN_REG; r < rows; ++r) {
-    out[(size_t)r * GROUP_TILES] = run;
-    run += src[(size_t)r * GROUP_TILES];
+  for (uint32_t r = COLSCAN_REG; r < rows; r += COLSCAN_REG) {
+    uint32_t v[COLSCAN_REG];
+    load_rows(r, v);
+#pragma unroll
+    for (int i = 0; i < COLSCAN_REG; ++i) {
+      if (r + (uint32_t)i < rows) out[(size_t)(r + (uint32_t)i) * GROUP_TILES] = run;
+      run += v[i];
+    }
   }
   if (w == 0) {
     const uint32_t tx = ((s % (uint32_t)sgx) << GROUP_SHIFT) + (uint32_t)(lane & 7);
@@ -1040,12 +1091,22 @@ static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, cons
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   const int64_t padded = b.chunks * (int64_t)b.chunk;
   hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0]);
-  hipLaunchKernelGGL(group_hist_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint32_t*)b.gkey[0], b.G,
-                     b.ghist, b.sort_blocks, b.gkey[1], padded);
+  const bool wide = b.sort_blocks <= SORT_WIDE_MAX_BLOCKS;  // few blocks: 1024 threads per block (see radix_sort_pairs)
+  if (wide)
+    hipLaunchKernelGGL((group_hist_kernel<BITS, 1024>), dim3(b.sort_blocks), dim3(1024), 0, s, (const uint32_t*)b.gkey[0], b.G,
+                       b.ghist, b.sort_blocks, b.gkey[1], padded);
+  else
+    hipLaunchKernelGGL((group_hist_kernel<BITS, SORT_THREADS>), dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s,
+                       (const uint32_t*)b.gkey[0], b.G, b.ghist, b.sort_blocks, b.gkey[1], padded);
   hipLaunchKernelGGL(sort_scan_kernel, dim3(1 << BITS), dim3(SORT_THREADS), 0, s, b.ghist, b.gbin_total, b.sort_blocks);
-  hipLaunchKernelGGL(group_scatter_kernel<BITS>, dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s, (const uint32_t*)b.gkey[0],
-                     (const uint32_t*)b.gval[0], b.gkey[1], b.gval[1], b.G, (const uint32_t*)b.ghist,
-                     (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk, b.group_first);
+  if (wide)
+    hipLaunchKernelGGL((group_scatter_kernel<BITS, 1024>), dim3(b.sort_blocks), dim3(1024), 0, s, (const uint32_t*)b.gkey[0],
+                       (const uint32_t*)b.gval[0], b.gkey[1], b.gval[1], b.G, (const uint32_t*)b.ghist,
+                       (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk, b.group_first);
+  else
+    hipLaunchKernelGGL((group_scatter_kernel<BITS, SORT_THREADS>), dim3(b.sort_blocks), dim3(SORT_THREADS), 0, s,
+                       (const uint32_t*)b.gkey[0], (const uint32_t*)b.gval[0], b.gkey[1], b.gval[1], b.G, (const uint32_t*)b.ghist,
+                       (const uint32_t*)b.gbin_total, b.sort_blocks, (uint32_t)b.chunk, b.group_first);
   GroupArgs a;
   a.gx = gx; a.gy = gy; a.sgx = b.sgx; a.chunks = (size_t)b.chunks;
   // stage of the scatter pass: a whole chunk's entries when they fit 1024 (8 KB of LDS: 20 waves per CU), else 2048
