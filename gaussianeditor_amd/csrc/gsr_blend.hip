@@ -1049,11 +1049,29 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   __shared__ uint32_t s_threshold;
   const uint32_t sub = threadIdx.x & (BWD_SUB - 1);
   for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
+  // The kernel is one block between the forward and the backward blend, i.e. a chain of dependent round trips: the
+  // forward's counts are fetched ONCE (all loads of a thread in flight together; images of up to 1024 * EST_REG tiles keep
+  // them in registers, larger ones re-read) and the counters are scanned by one block scan.
+  constexpr int EST_REG = 8;
+  const bool in_regs = T <= 1024 * EST_REG;
+  uint4 er[EST_REG];
+#pragma unroll
+  for (int j = 0; j < EST_REG; ++j) {
+    const int t = (int)threadIdx.x + 1024 * j;
+    er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[t < T ? t : T - 1] : make_uint4(0u, 0u, 0u, 0u);
+    if (t >= T) er[j] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  auto est_of = [&](int t, int j) -> uint4 { return in_regs ? er[j] : reinterpret_cast<const uint4*>(est)[t]; };
   // total work -> the weight above which a tile is cut
   uint32_t mine = 0;
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
-    mine += e.x + e.y + e.z + e.w;
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < EST_REG; ++j) mine += er[j].x + er[j].y + er[j].z + er[j].w;
+  } else {
+    for (int t = threadIdx.x; t < T; t += 1024) {
+      const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+      mine += e.x + e.y + e.z + e.w;
+    }
   }
   uint32_t total;
   (void)block_excl_scan_u32<1024>(mine, &total, smem);
@@ -1065,8 +1083,19 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
   };
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+  auto for_each_tile = [&](auto&& fn) {
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < EST_REG; ++j) {
+        const int t = (int)threadIdx.x + 1024 * j;
+        if (t < T) fn(t, er[j]);
+      }
+    } else {
+      for (int t = threadIdx.x; t < T; t += 1024) fn(t, reinterpret_cast<const uint4*>(est)[t]);
+    }
+  };
+  (void)est_of;
+  for_each_tile([&](int, const uint4 e) {
     const uint32_t w = e.x + e.y + e.z + e.w;
     if (w >= threshold) {
       atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
@@ -1074,23 +1103,28 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     } else {
       atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u);
     }
-  }
+  });
   __syncthreads();
-  {  // exclusive scan over the counters in (bucket, sub) order: counts -> cursors
-    uint32_t carry = 0;
-    for (int base = 0; base < NCNT; base += 1024) {
-      const int i = base + (int)threadIdx.x;
-      const uint32_t v = i < NCNT ? cnt[i] : 0u;
-      uint32_t chunk;
-      const uint32_t ex = block_excl_scan_u32<1024>(v, &chunk, smem);
-      if (i < NCNT) cnt[i] = carry + ex;
-      if (i == BWD_BUCKETS * BWD_SUB) meta[0] = carry + ex;  // number of items with work
-      carry += chunk;
+  {  // exclusive scan over the counters in (bucket, sub) order: counts -> cursors (one block scan, CPT counters a thread)
+    constexpr int CPT = (NCNT + 1023) / 1024;
+    const int i0 = (int)threadIdx.x * CPT;
+    uint32_t v[CPT], sum = 0;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      v[j] = i0 + j < NCNT ? cnt[i0 + j] : 0u;
+      sum += v[j];
+    }
+    uint32_t all;
+    uint32_t run = block_excl_scan_u32<1024>(sum, &all, smem);
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+      if (i0 + j < NCNT) cnt[i0 + j] = run;
+      if (i0 + j == BWD_BUCKETS * BWD_SUB) meta[0] = run;  // number of items with work
+      run += v[j];
     }
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+  for_each_tile([&](int t, const uint4 e) {
     const uint32_t w = e.x + e.y + e.z + e.w;
     if (w >= threshold) {
       order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
@@ -1098,7 +1132,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     } else {
       order[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = (uint32_t)t;
     }
-  }
+  });
 }
 
 // Compute units of the device a launch goes to: the device of the STREAM (a C-ABI caller may hand over a stream of another

@@ -100,7 +100,7 @@ __device__ __forceinline__ void load_sh_vec(const float4* __restrict__ q, V3 (&s
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     if (i < NV) {
-      const float4 v = q[i];
+      const float4 v = q[i];  // (a nontemporal load here: K1 +54 us, K8+K9 +80 us -- measured, profiles/r03_b)
       f[4 * i] = v.x; f[4 * i + 1] = v.y; f[4 * i + 2] = v.z; f[4 * i + 3] = v.w;
     } else {
       f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
@@ -434,7 +434,15 @@ __device__ __forceinline__ void sh_tile_store_rows(float* __restrict__ dst_rows,
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const int e = k * 64 + lane, r = e / 12, c = e - 12 * r;
-    if (e < nf4) q[e] = tile[r * 13 + c];
+    if (e < nf4) {
+      // streaming store: the gradient is written once and next read by the optimizer, long after; written through the
+      // caches it evicts the parameters K1 streams again at the start of the next iteration (same-box A/B: preprocess
+      // stage 156 -> 146 us, profiles/r03_b)
+      typedef float nt_f4 __attribute__((ext_vector_type(4)));
+      const float4 tv = tile[r * 13 + c];
+      const nt_f4 nv = {tv.x, tv.y, tv.z, tv.w};
+      __builtin_nontemporal_store(nv, reinterpret_cast<nt_f4*>(q) + e);
+    }
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -443,7 +451,10 @@ __device__ __forceinline__ void sh_tile_store_rows(float* __restrict__ dst_rows,
 __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 preprocess_backward_kernel(const PreBwdArgs a) {
   __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
-  const int idx_raw = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
+  // Blocks take the Gaussians in DESCENDING order: K8+K9 is the last kernel of an iteration and K1 the first of the next,
+  // both stream the same 236 B of parameters per Gaussian -- what this kernel touches last is what K1 asks for first, and
+  // finds in the 256 MB memory-side cache (same-box A/B: K1 + depth sort 144.8 -> 141.1 us, this kernel 106.9 -> 102.0)
+  const int idx_raw = (int)((gridDim.x - 1u - blockIdx.x) * GAUSS_BLOCK + threadIdx.x);
   const bool live = idx_raw < a.P;  // (no early return: the SH-gradient rows leave wave-cooperatively)
   const int idx = live ? idx_raw : a.P - 1;
   const int ncoef = (a.D + 1) * (a.D + 1);
@@ -670,22 +681,28 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     }
   }
   if (!live) return;
-  a.dL_dmeans3D[3 * (size_t)idx] = dmean.x;
-  a.dL_dmeans3D[3 * (size_t)idx + 1] = dmean.y;
-  a.dL_dmeans3D[3 * (size_t)idx + 2] = dmean.z;
+#if defined(GSR_K9_NT_GRADS) && GSR_K9_NT_GRADS
+#define K9_ST(p, v) __builtin_nontemporal_store((v), (p))  // (A/B build)
+#else
+#define K9_ST(p, v) (*(p) = (v))
+#endif
+  K9_ST(&a.dL_dmeans3D[3 * (size_t)idx], dmean.x);
+  K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 1], dmean.y);
+  K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 2], dmean.z);
 #pragma unroll
-  for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+  for (int i = 0; i < 6; ++i) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);
   if (a.dL_drgb != nullptr) {
     a.dL_drgb[3 * (size_t)idx] = drgb.x;
     a.dL_drgb[3 * (size_t)idx + 1] = drgb.y;
     a.dL_drgb[3 * (size_t)idx + 2] = drgb.z;
   }
   if (a.dL_dscale != nullptr) {
-    a.dL_dscale[3 * (size_t)idx] = dscale.x;
-    a.dL_dscale[3 * (size_t)idx + 1] = dscale.y;
-    a.dL_dscale[3 * (size_t)idx + 2] = dscale.z;
+    K9_ST(&a.dL_dscale[3 * (size_t)idx], dscale.x);
+    K9_ST(&a.dL_dscale[3 * (size_t)idx + 1], dscale.y);
+    K9_ST(&a.dL_dscale[3 * (size_t)idx + 2], dscale.z);
   }
   if (a.dL_drot != nullptr) reinterpret_cast<float4*>(a.dL_drot)[idx] = drot;
+#undef K9_ST
 }
 
 // ----------------------------------------------------------------------------------
