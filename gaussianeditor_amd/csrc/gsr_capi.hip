@@ -367,6 +367,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   pa.scale_modifier = scale_modifier;
   pa.cov3D_precomp = cov3D_precomp;
   pa.clamped = g.clamped;
+  for (int i = 0; i < 3; ++i) pa.dcol[i] = g.dcol[i];
   pa.viewmatrix = viewmatrix; pa.projmatrix = projmatrix; pa.campos = campos;
   pa.h_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:308-309
   pa.h_x = W / (2.0f * tan_fovx);

@@ -152,6 +152,42 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s
   c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
 }
 
+// d(RGB)/d(dir) of computeColorFromSH, backward.cu:88-136 (the part of its backward that needs the SH coefficients):
+// evaluated by K1, which holds them, and handed to K8+K9 through the geometry scratch.
+__device__ __forceinline__ void sh_color_dir_derivatives(int D, float x, float y, float z, const V3 (&sh)[16], V3& dRGBdx,
+                                                         V3& dRGBdy, V3& dRGBdz) {
+  dRGBdx = {0, 0, 0};
+  dRGBdy = {0, 0, 0};
+  dRGBdz = {0, 0, 0};
+  if (D > 0) {
+    dRGBdx = (-SH_C1) * sh[3];
+    dRGBdy = (-SH_C1) * sh[1];
+    dRGBdz = SH_C1 * sh[2];
+    if (D > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      dRGBdx = dRGBdx + ((SH_C2[0] * y) * sh[4] + (SH_C2[2] * 2.f * -x) * sh[6] + (SH_C2[3] * z) * sh[7] +
+                         (SH_C2[4] * 2.f * x) * sh[8]);
+      dRGBdy = dRGBdy + ((SH_C2[0] * x) * sh[4] + (SH_C2[1] * z) * sh[5] + (SH_C2[2] * 2.f * -y) * sh[6] +
+                         (SH_C2[4] * 2.f * -y) * sh[8]);
+      dRGBdz = dRGBdz + ((SH_C2[1] * y) * sh[5] + (SH_C2[2] * 2.f * 2.f * z) * sh[6] + (SH_C2[3] * x) * sh[7]);
+      if (D > 2) {
+        // `SH_C3[k] * sh[n] * s1 * s2` parses as (((SH_C3[k]*sh[n])*s1)*s2)
+        dRGBdx = dRGBdx + ((SH_C3[0] * sh[9]) * 3.f * 2.f * xy + (SH_C3[1] * sh[10]) * yz +
+                           (SH_C3[2] * sh[11]) * -2.f * xy + (SH_C3[3] * sh[12]) * -3.f * 2.f * xz +
+                           (SH_C3[4] * sh[13]) * (-3.f * xx + 4.f * zz - yy) + (SH_C3[5] * sh[14]) * 2.f * xz +
+                           (SH_C3[6] * sh[15]) * 3.f * (xx - yy));
+        dRGBdy = dRGBdy + ((SH_C3[0] * sh[9]) * 3.f * (xx - yy) + (SH_C3[1] * sh[10]) * xz +
+                           (SH_C3[2] * sh[11]) * (-3.f * yy + 4.f * zz - xx) +
+                           (SH_C3[3] * sh[12]) * -3.f * 2.f * yz + (SH_C3[4] * sh[13]) * -2.f * xy +
+                           (SH_C3[5] * sh[14]) * -2.f * yz + (SH_C3[6] * sh[15]) * -3.f * 2.f * xy);
+        dRGBdz = dRGBdz + ((SH_C3[1] * sh[10]) * xy + (SH_C3[2] * sh[11]) * 4.f * 2.f * yz +
+                           (SH_C3[3] * sh[12]) * 3.f * (2.f * zz - xx - yy) +
+                           (SH_C3[4] * sh[13]) * 4.f * 2.f * xz + (SH_C3[5] * sh[14]) * (xx - yy));
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------------
 // K1: preprocessCUDA, DGR/cuda_rasterizer/forward.cu:155-256 (+ apply_weights.cu:148-234).
 // Additionally produces the per-block sum of tiles_touched (first level of K2).
@@ -302,6 +338,13 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
                          (SH_C3[6] * x * (xx - 3.0f * yy)) * sh[15];
               }
             }
+          }
+          {  // what the backward needs of the SH record (see Geom::dcol)
+            V3 ddx, ddy, ddz;
+            sh_color_dir_derivatives(a.D, dir.x, dir.y, dir.z, sh, ddx, ddy, ddz);
+            a.g.dcol[0][idx] = make_float4(ddx.x, ddx.y, ddx.z, 0.f);
+            a.g.dcol[1][idx] = make_float4(ddy.x, ddy.y, ddy.z, 0.f);
+            a.g.dcol[2][idx] = make_float4(ddz.x, ddz.y, ddz.z, 0.f);
           }
           result = {result.x + 0.5f, result.y + 0.5f, result.z + 0.5f};
           a.g.clamped[idx] = (uint8_t)((result.x < 0 ? 1 : 0) | (result.y < 0 ? 2 : 0) | (result.z < 0 ? 4 : 0));
@@ -564,24 +607,22 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       const V3 dir_orig = {m.x - cam.campos[0], m.y - cam.campos[1], m.z - cam.campos[2]};
       const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
       const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
-      V3 sh[16];
-      load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
+      // d(RGB)/d(dir): K1 evaluated it from the SH record it held (sh_color_dir_derivatives) -- the record itself is not read
+      // again (192 B per Gaussian at M = 16 against these 48)
+      const float4 d0 = a.dcol[0][idx], d1 = a.dcol[1][idx], d2 = a.dcol[2][idx];
+      const V3 dRGBdx = {d0.x, d0.y, d0.z}, dRGBdy = {d1.x, d1.y, d1.z}, dRGBdz = {d2.x, d2.y, d2.z};
       const uint8_t cl = a.clamped[idx];
       V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
       dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
       dL_dRGB.y *= (cl & 2) ? 0.f : 1.f;
       dL_dRGB.z *= (cl & 4) ? 0.f : 1.f;
       drgb = dL_dRGB;
-      V3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
       const float x = dir.x, y = dir.y, z = dir.z;
       dsh[0] = SH_C0 * dL_dRGB;
       if (a.D > 0) {
         dsh[1] = (-SH_C1 * y) * dL_dRGB;
         dsh[2] = (SH_C1 * z) * dL_dRGB;
         dsh[3] = (-SH_C1 * x) * dL_dRGB;
-        dRGBdx = (-SH_C1) * sh[3];
-        dRGBdy = (-SH_C1) * sh[1];
-        dRGBdz = SH_C1 * sh[2];
         if (a.D > 1) {
           const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
           dsh[4] = (SH_C2[0] * xy) * dL_dRGB;
@@ -589,11 +630,6 @@ preprocess_backward_kernel(const PreBwdArgs a) {
           dsh[6] = (SH_C2[2] * (2.f * zz - xx - yy)) * dL_dRGB;
           dsh[7] = (SH_C2[3] * xz) * dL_dRGB;
           dsh[8] = (SH_C2[4] * (xx - yy)) * dL_dRGB;
-          dRGBdx = dRGBdx + ((SH_C2[0] * y) * sh[4] + (SH_C2[2] * 2.f * -x) * sh[6] + (SH_C2[3] * z) * sh[7] +
-                             (SH_C2[4] * 2.f * x) * sh[8]);
-          dRGBdy = dRGBdy + ((SH_C2[0] * x) * sh[4] + (SH_C2[1] * z) * sh[5] + (SH_C2[2] * 2.f * -y) * sh[6] +
-                             (SH_C2[4] * 2.f * -y) * sh[8]);
-          dRGBdz = dRGBdz + ((SH_C2[1] * y) * sh[5] + (SH_C2[2] * 2.f * 2.f * z) * sh[6] + (SH_C2[3] * x) * sh[7]);
           if (a.D > 2) {
             dsh[9] = (SH_C3[0] * y * (3.f * xx - yy)) * dL_dRGB;
             dsh[10] = (SH_C3[1] * xy * z) * dL_dRGB;
@@ -602,18 +638,6 @@ preprocess_backward_kernel(const PreBwdArgs a) {
             dsh[13] = (SH_C3[4] * x * (4.f * zz - xx - yy)) * dL_dRGB;
             dsh[14] = (SH_C3[5] * z * (xx - yy)) * dL_dRGB;
             dsh[15] = (SH_C3[6] * x * (xx - 3.f * yy)) * dL_dRGB;
-            // `SH_C3[k] * sh[n] * s1 * s2` parses as (((SH_C3[k]*sh[n])*s1)*s2)
-            dRGBdx = dRGBdx + ((SH_C3[0] * sh[9]) * 3.f * 2.f * xy + (SH_C3[1] * sh[10]) * yz +
-                               (SH_C3[2] * sh[11]) * -2.f * xy + (SH_C3[3] * sh[12]) * -3.f * 2.f * xz +
-                               (SH_C3[4] * sh[13]) * (-3.f * xx + 4.f * zz - yy) + (SH_C3[5] * sh[14]) * 2.f * xz +
-                               (SH_C3[6] * sh[15]) * 3.f * (xx - yy));
-            dRGBdy = dRGBdy + ((SH_C3[0] * sh[9]) * 3.f * (xx - yy) + (SH_C3[1] * sh[10]) * xz +
-                               (SH_C3[2] * sh[11]) * (-3.f * yy + 4.f * zz - xx) +
-                               (SH_C3[3] * sh[12]) * -3.f * 2.f * yz + (SH_C3[4] * sh[13]) * -2.f * xy +
-                               (SH_C3[5] * sh[14]) * -2.f * yz + (SH_C3[6] * sh[15]) * -3.f * 2.f * xy);
-            dRGBdz = dRGBdz + ((SH_C3[1] * sh[10]) * xy + (SH_C3[2] * sh[11]) * 4.f * 2.f * yz +
-                               (SH_C3[3] * sh[12]) * 3.f * (2.f * zz - xx - yy) +
-                               (SH_C3[4] * sh[13]) * 4.f * 2.f * xz + (SH_C3[5] * sh[14]) * (xx - yy));
           }
         }
       }
