@@ -65,6 +65,7 @@ SIGNATURES = {
     "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gsr_view_message_pack": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, _P, c_int64, _P]),
     "gsr_view_messages_accumulate": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads)]),
+    "gsr_view_messages_accumulate_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads), _P]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
     "gsr_compact_workspace_size": (c_int, [c_int64, POINTER(c_size_t)]),
@@ -73,6 +74,8 @@ SIGNATURES = {
     "gsr_append_rows": (c_int, [_P, c_int64, c_int64, c_int, POINTER(AppendTensor)]),
     "gsr_adam_step": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
                             _P]),
+    "gsr_adam_step_rows": (c_int, [_P, c_int, POINTER(AdamTensor), c_int64, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P,
+                            _P, _P]),
     "gsr_mark_visible": (c_int, [_P, c_int, _P, _P, _P, _P]),
     "gsr_trace_weights": (c_int, [_P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),

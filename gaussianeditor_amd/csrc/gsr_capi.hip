@@ -515,12 +515,18 @@ int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local,
 
 int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
                                  int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out) {
+  return gsr_view_messages_accumulate_rows(stream, P, D, M, num_views, messages, stride_words, cap, means3D, out, nullptr);
+}
+
+int gsr_view_messages_accumulate_rows(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
+                                      int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out,
+                                      uint8_t* row_valid) {
   if (P == 0) return GSR_OK;
   if (P < 0 || num_views < 1 || !messages || cap < 0 || stride_words < view_message_words_host(P, cap)) return GSR_ERR_BAD_ARGUMENT;
   if (!dense_grads_complete(out)) return GSR_ERR_BAD_ARGUMENT;
   if (out->sh && (!means3D || D < 0 || D > 3 || M < (D + 1) * (D + 1))) return GSR_ERR_BAD_ARGUMENT;
   float* const d[6] = {out->means3D, out->scales, out->rotations, out->means2D, out->opacities, out->sh};
-  GSR_HIP(launch_view_messages_accumulate((hipStream_t)stream, P, D, M, num_views, messages, stride_words, cap, means3D, d));
+  GSR_HIP(launch_view_messages_accumulate((hipStream_t)stream, P, D, M, num_views, messages, stride_words, cap, means3D, d, row_valid));
   return GSR_OK;
 }
 
@@ -586,6 +592,11 @@ int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace
 
 int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
                   double eps, const uint8_t* row_mask, const float* row_weight) {
+  return gsr_adam_step_rows(stream, num_tensors, tensors, step, beta1, beta2, eps, row_mask, row_weight, nullptr);
+}
+
+int gsr_adam_step_rows(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
+                       double eps, const uint8_t* row_mask, const float* row_weight, const uint8_t* grad_valid) {
   if (num_tensors == 0) return GSR_OK;
   if (num_tensors < 0 || num_tensors > 8 || !tensors || step < 1) return GSR_ERR_BAD_ARGUMENT;
   if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return GSR_ERR_BAD_ARGUMENT;
@@ -594,7 +605,8 @@ int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors,
     if (t.numel < 0 || t.row_len < 1) return GSR_ERR_BAD_ARGUMENT;
     if (t.numel > 0 && (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq)) return GSR_ERR_BAD_ARGUMENT;
   }
-  GSR_HIP(launch_adam_step((hipStream_t)stream, num_tensors, tensors, (long long)step, beta1, beta2, eps, row_mask, row_weight));
+  GSR_HIP(launch_adam_step((hipStream_t)stream, num_tensors, tensors, (long long)step, beta1, beta2, eps, row_mask, row_weight,
+                           grad_valid));
   return GSR_OK;
 }
 

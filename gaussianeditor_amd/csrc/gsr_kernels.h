@@ -110,7 +110,8 @@ int64_t view_message_words_host(int64_t P, int64_t cap);
 hipError_t launch_view_message_header(hipStream_t s, int64_t P, const float* campos, const uint32_t* block_off,
                                       const uint64_t* total, float* msg);
 hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int M, int n_views, const float* messages,
-                                           int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6]);
+                                           int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6],
+                                           uint8_t* row_valid);
 const uint32_t* compact_block_off_ptr(void* workspace, int64_t P);
 hipError_t launch_export_cov3d(hipStream_t s, int P, const float* scales, float scale_modifier, const float* rotations,
                                float* cov3D);
@@ -133,7 +134,8 @@ hipError_t launch_compact_apply(hipStream_t s, int64_t P, const uint8_t* keep, v
                                 const gsr_compact_tensor* tensors, int64_t limit = -1);
 hipError_t launch_append_rows(hipStream_t s, int64_t P, int64_t n, int nt, const gsr_append_tensor* tensors);
 hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
-                            double beta2, double eps, const uint8_t* row_mask, const float* row_weight);
+                            double beta2, double eps, const uint8_t* row_mask, const float* row_weight,
+                            const uint8_t* grad_valid = nullptr);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
 unsigned blend_grid_size(bool backward, hipStream_t s);  // persistent waves of a blend launch on the device of stream s
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);

@@ -46,6 +46,7 @@ struct AdamArgs {
   int nt;
   const uint8_t* row_mask;
   const float* row_weight;
+  const uint8_t* grad_valid;  // null, or per row: 0 = the gradient row was not written, take zeros and do not read it
   float beta2, one_minus_b1, one_minus_b2, bc2_sqrt, eps;
 };
 
@@ -75,7 +76,17 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(const AdamArgs 
   if (e0 >= t.n) return;
   if (t.vec4 && e0 + ADAM_PER_THREAD <= t.n) {
     float4 p = *reinterpret_cast<const float4*>(t.p + e0);
-    const float4 g = *reinterpret_cast<const float4*>(t.g + e0);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.grad_valid == nullptr) {
+      g = *reinterpret_cast<const float4*>(t.g + e0);
+    } else {  // gradient rows that were never written (gsr_view_messages_accumulate_rows) are zeros and are not read
+      const bool v0 = a.grad_valid[e0 / t.row_len] != 0, v1 = a.grad_valid[(e0 + 1) / t.row_len] != 0;
+      const bool v2 = a.grad_valid[(e0 + 2) / t.row_len] != 0, v3 = a.grad_valid[(e0 + 3) / t.row_len] != 0;
+      if (v0 || v1 || v2 || v3) {
+        const float4 x = *reinterpret_cast<const float4*>(t.g + e0);
+        g = make_float4(v0 ? x.x : 0.f, v1 ? x.y : 0.f, v2 ? x.z : 0.f, v3 ? x.w : 0.f);
+      }
+    }
     float4 m = *reinterpret_cast<const float4*>(t.m + e0);
     float4 v = *reinterpret_cast<const float4*>(t.v + e0);
     adam_scalar(a, t, e0, p.x, g.x, m.x, v.x);
@@ -88,7 +99,8 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(const AdamArgs 
   } else {
     for (long long e = e0; e < min(e0 + (long long)ADAM_PER_THREAD, t.n); ++e) {
       float p = t.p[e], m = t.m[e], v = t.v[e];
-      adam_scalar(a, t, e, p, t.g[e], m, v);
+      const float ge = (a.grad_valid == nullptr || a.grad_valid[e / t.row_len] != 0) ? t.g[e] : 0.f;
+      adam_scalar(a, t, e, p, ge, m, v);
       t.p[e] = p;
       t.m[e] = m;
       t.v[e] = v;
@@ -97,7 +109,8 @@ __global__ void __launch_bounds__(ADAM_THREADS) adam_step_kernel(const AdamArgs 
 }
 
 hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensors, long long step, double beta1,
-                            double beta2, double eps, const uint8_t* row_mask, const float* row_weight) {
+                            double beta2, double eps, const uint8_t* row_mask, const float* row_weight,
+                            const uint8_t* grad_valid) {
   if (nt <= 0) return hipSuccess;
   if (nt > ADAM_MAX_TENSORS) return hipErrorInvalidValue;
   AdamArgs a;
@@ -105,6 +118,7 @@ hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensor
   a.nt = nt;
   a.row_mask = row_mask;
   a.row_weight = row_weight;
+  a.grad_valid = grad_valid;
   // scalars in double, as torch computes them from Python floats (torch/optim/adam.py: bias_correction1/2, step_size)
   const double bc1 = 1.0 - pow(beta1, (double)step);
   const double bc2 = 1.0 - pow(beta2, (double)step);

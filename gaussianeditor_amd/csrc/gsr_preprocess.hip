@@ -877,11 +877,16 @@ __global__ void __launch_bounds__(256) view_message_header_kernel(int64_t P, con
 // view, notes in an LDS position map where the rows of its quarter are, and the thread of Gaussian g then adds them in
 // view order.  The SH rows leave wave-cooperatively (sh_tile_store_rows).
 constexpr int VIEW_BATCH = 8;  // views whose position maps are resident in LDS at a time
+// SPARSE (row_valid != null): a Gaussian no view sent a row for gets row_valid[g] = 0 and NOTHING is written to its gradient
+// rows (they keep whatever they held); the others get row_valid[g] = 1 and their sums.  The consumer treats invalid rows as
+// zero gradients (gsr_adam_step: `masked` tensors with row_mask = row_valid).  At 2 / 8 views 81 / 43 % of the rows are
+// invalid, and the dense write of 248 B per Gaussian is most of this kernel's time.
+template <bool SPARSE>
 __global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(int64_t P, int D, int M, int n_views,
                                                                               const float* __restrict__ messages,
                                                                               int64_t stride_words, int64_t cap,
                                                                               const float* __restrict__ means3D_param,
-                                                                              DenseGrads d) {
+                                                                              DenseGrads d, uint8_t* __restrict__ row_valid) {
   __shared__ uint16_t posmap[VIEW_BATCH][GAUSS_BLOCK];
   __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
   constexpr int QUARTERS = VIEW_MSG_ROWS / GAUSS_BLOCK;
@@ -899,43 +904,107 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(i
   for (int k = 0; k < 16; ++k) dsh[k] = {0.f, 0.f, 0.f};
   V3 m = {0.f, 0.f, 0.f};
   if (d.sh != nullptr) m = {means3D_param[3 * g], means3D_param[3 * g + 1], means3D_param[3 * g + 2]};
+  bool touched = false;
+  // Every step below issues the loads of ALL views of the batch before it uses any of them: the kernel is a chain of
+  // dependent round trips (slice bounds -> row indices -> rows), and walked view by view it paid that chain once per view
+  // (0.011 ms per view and launch at 1 M Gaussians; the arithmetic is a fraction of that).
   for (int vb = 0; vb < n_views; vb += VIEW_BATCH) {
     const int nv = min(VIEW_BATCH, n_views - vb);
-    for (int u = 0; u < nv; ++u) posmap[u][threadIdx.x] = 0xffffu;
+    uint32_t lo[VIEW_BATCH], hi[VIEW_BATCH];
+#pragma unroll
+    for (int u = 0; u < VIEW_BATCH; ++u) {
+      lo[u] = hi[u] = 0u;
+      if (u < nv) {
+        const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
+        lo[u] = v.boff[b];
+        hi[u] = b + 1 < nb ? v.boff[b + 1] : v.count;
+      }
+      posmap[u][threadIdx.x] = 0xffffu;
+    }
     __syncthreads();
-    for (int u = 0; u < nv; ++u) {
+    int32_t first[VIEW_BATCH];
+#pragma unroll
+    for (int u = 0; u < VIEW_BATCH; ++u) {  // the first 256 rows of every slice (a view sends ~100 rows per message block)
+      first[u] = -1;
+      if (u < nv && hi[u] > lo[u]) {
+        const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
+        first[u] = v.idx[min(lo[u] + threadIdx.x, hi[u] - 1u)];  // (clamped: an unconditional load)
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < VIEW_BATCH; ++u) {
+      if (u < nv && lo[u] + threadIdx.x < hi[u]) {
+        const int64_t q = (int64_t)first[u] - g0;
+        if (q >= 0 && q < GAUSS_BLOCK) posmap[u][q] = (uint16_t)threadIdx.x;
+      }
+    }
+    for (int u = 0; u < nv; ++u) {  // (rare: more than 256 rows of a view in this message block)
+      if (hi[u] - lo[u] <= (uint32_t)GAUSS_BLOCK) continue;
       const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
-      const uint32_t lo = v.boff[b], hi = b + 1 < nb ? v.boff[b + 1] : v.count;
-      for (uint32_t j = lo + threadIdx.x; j < hi; j += GAUSS_BLOCK) {
+      for (uint32_t j = lo[u] + GAUSS_BLOCK + threadIdx.x; j < hi[u]; j += GAUSS_BLOCK) {
         const int64_t q = (int64_t)v.idx[j] - g0;
-        if (q >= 0 && q < GAUSS_BLOCK) posmap[u][q] = (uint16_t)(j - lo);
+        if (q >= 0 && q < GAUSS_BLOCK) posmap[u][q] = (uint16_t)(j - lo[u]);
       }
     }
     __syncthreads();
-    for (int u = 0; u < nv; ++u) {
-      const uint32_t o = posmap[u][threadIdx.x];
-      if (o == 0xffffu || !live) continue;
-      const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
-      const size_t j = (size_t)v.boff[b] + o;
-      am = am + V3{v.means3D[3 * j], v.means3D[3 * j + 1], v.means3D[3 * j + 2]};
-      as = as + V3{v.scales[3 * j], v.scales[3 * j + 1], v.scales[3 * j + 2]};
-      a2 = a2 + V3{v.means2D[3 * j], v.means2D[3 * j + 1], v.means2D[3 * j + 2]};
-      ar.x += v.rotations[4 * j];
-      ar.y += v.rotations[4 * j + 1];
-      ar.z += v.rotations[4 * j + 2];
-      ar.w += v.rotations[4 * j + 3];
-      ao += v.opacities[j];
-      if (d.sh == nullptr) continue;
-      const V3 dL_dRGB = {v.rgb[3 * j], v.rgb[3 * j + 1], v.rgb[3 * j + 2]};
-      if (dL_dRGB.x == 0.f && dL_dRGB.y == 0.f && dL_dRGB.z == 0.f) continue;  // (as sh_grad_compose_kernel)
-      V3 t[16];
-      sh_grad_terms(D, m, v.cam, dL_dRGB, t);
+    constexpr int VG = 4;  // views whose rows are in flight together (17 registers each)
 #pragma unroll
-      for (int k = 0; k < 16; ++k) dsh[k] = dsh[k] + t[k];
+    for (int u0 = 0; u0 < VIEW_BATCH; u0 += VG) {
+      if (u0 >= nv || cap <= 0) break;
+      float r[VG][17];
+      bool hit[VG];
+#pragma unroll
+      for (int k = 0; k < VG; ++k) {
+        const int u = u0 + k;
+        hit[k] = false;
+        if (u < nv) {
+          const uint32_t o = posmap[u][threadIdx.x];
+          hit[k] = o != 0xffffu && live;
+          const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
+          const size_t j = min((size_t)lo[u] + (hit[k] ? o : 0u), (size_t)cap - 1);  // (any valid row where there is none)
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            r[k][i] = v.means3D[3 * j + i];
+            r[k][3 + i] = v.scales[3 * j + i];
+            r[k][10 + i] = v.means2D[3 * j + i];
+            r[k][14 + i] = v.rgb[3 * j + i];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) r[k][6 + i] = v.rotations[4 * j + i];
+          r[k][13] = v.opacities[j];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < VG; ++k) {  // view order
+        const int u = u0 + k;
+        if (u >= nv || !hit[k]) continue;
+        touched = true;
+        am = am + V3{r[k][0], r[k][1], r[k][2]};
+        as = as + V3{r[k][3], r[k][4], r[k][5]};
+        a2 = a2 + V3{r[k][10], r[k][11], r[k][12]};
+        ar.x += r[k][6];
+        ar.y += r[k][7];
+        ar.z += r[k][8];
+        ar.w += r[k][9];
+        ao += r[k][13];
+        if (d.sh == nullptr) continue;
+        const V3 dL_dRGB = {r[k][14], r[k][15], r[k][16]};
+        if (dL_dRGB.x == 0.f && dL_dRGB.y == 0.f && dL_dRGB.z == 0.f) continue;  // (as sh_grad_compose_kernel)
+        const ViewMsg v = carve_view_message(messages + (size_t)(vb + u) * stride_words, P, cap);
+        V3 t[16];
+        sh_grad_terms(D, m, v.cam, dL_dRGB, t);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) dsh[kk] = dsh[kk] + t[kk];
+      }
     }
     __syncthreads();
   }
-  if (d.sh != nullptr) {
+  if (SPARSE) {  // only the rows some view sent: one row per thread (no tile: the rows are not consecutive)
+    if (!live) return;
+    row_valid[g] = touched ? 1 : 0;
+    if (!touched) return;
+    if (d.sh != nullptr) store_sh_grad(d.sh + (size_t)g * M * 3, M, dsh, ncoef);
+  } else if (d.sh != nullptr) {
     if (M == 16 && (reinterpret_cast<uintptr_t>(d.sh) & 15u) == 0) {
       const int lane = (int)(threadIdx.x & 63u);
       const int64_t row0 = g_raw - lane;
@@ -1034,11 +1103,16 @@ hipError_t launch_view_message_header(hipStream_t s, int64_t P, const float* cam
   return hipGetLastError();
 }
 hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int M, int n_views, const float* messages,
-                                           int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6]) {
+                                           int64_t stride_words, int64_t cap, const float* means3D, float* const dense[6],
+                                           uint8_t* row_valid) {
   DenseGrads d = {dense[0], dense[1], dense[2], dense[3], dense[4], dense[5]};
   const int64_t nblk = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(view_messages_accumulate_kernel, dim3((unsigned)nblk), dim3(GAUSS_BLOCK), 0, s, P, D, M, n_views, messages,
-                     stride_words, cap, means3D, d);
+  if (row_valid != nullptr)
+    hipLaunchKernelGGL(view_messages_accumulate_kernel<true>, dim3((unsigned)nblk), dim3(GAUSS_BLOCK), 0, s, P, D, M, n_views,
+                       messages, stride_words, cap, means3D, d, row_valid);
+  else
+    hipLaunchKernelGGL(view_messages_accumulate_kernel<false>, dim3((unsigned)nblk), dim3(GAUSS_BLOCK), 0, s, P, D, M, n_views,
+                       messages, stride_words, cap, means3D, d, row_valid);
   return hipGetLastError();
 }
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a) {

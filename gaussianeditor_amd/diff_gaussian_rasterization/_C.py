@@ -355,15 +355,19 @@ def view_message_pack(plan, grads5, rgb, campos, cap, message):
             _stream(dev), P, ctypes.byref(dg), ptr(rgb), campos.data_ptr(), ptr(mask), ptr(work), int(cap), message.data_ptr()))
 
 
-def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
+def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense, row_valid=None):
     """dense = the sum of the views' messages (rows of `messages`, (n, words)), view 0 first; dense[5] (SH gradient,
-    (P,M,3) or None) rebuilt from the colour gradients -- gsr_view_messages_accumulate."""
+    (P,M,3) or None) rebuilt from the colour gradients -- gsr_view_messages_accumulate.
+    `row_valid` (uint8 (P,), optional): receives 1 where some view sent a row, 0 elsewhere, and the rows of `dense` of the
+    latter are NOT written (gsr_view_messages_accumulate_rows): the consumer must take them as zeros."""
     dev = messages.device
     dg = _dense_grads(dense)
+    if row_valid is not None and (row_valid.dtype != torch.uint8 or row_valid.numel() != int(P) or not row_valid.is_contiguous()):
+        raise RuntimeError("row_valid must be a contiguous uint8 tensor of P elements")
     with torch.cuda.device(dev):
-        _native.check("gsr_view_messages_accumulate", _native.lib().gsr_view_messages_accumulate(
+        _native.check("gsr_view_messages_accumulate", _native.lib().gsr_view_messages_accumulate_rows(
             _stream(dev), int(P), int(degree), int(M), int(messages.size(0)), messages.data_ptr(), int(messages.stride(0)),
-            int(cap), means3D.data_ptr(), ctypes.byref(dg)))
+            int(cap), means3D.data_ptr(), ctypes.byref(dg), None if row_valid is None else row_valid.data_ptr()))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

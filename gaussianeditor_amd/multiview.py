@@ -58,8 +58,13 @@ class GradBucket:
     means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent -- and followed, outside
     the exchanged part, by the backward's two internal accumulators -- so that one fill clears all four."""
 
-    def __init__(self, P: int, M: int, device, sh_exchange: str = "auto"):
+    def __init__(self, P: int, M: int, device, sh_exchange: str = "auto", sparse_rows: bool = False):
         self.P, self.M = int(P), int(M)
+        #: `sparse_rows`: the touched-rows exchange writes the summed gradients only for the Gaussians some view touched and
+        #: marks them in `row_valid` (uint8 (P,)); the other rows of the gradient tensors are stale or uninitialised and count
+        #: as zeros -- hand `row_valid` to the consumer (FusedMaskedAdam.set_grad_valid).  After any other route every row is
+        #: valid (row_valid is all ones).
+        self.row_valid = torch.ones(int(P), dtype=torch.uint8, device=device) if sparse_rows else None
         if sh_exchange == "auto":
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             sh_exchange = "rgb" if (multi and M > 0) else "direct"
@@ -282,7 +287,9 @@ def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Op
         recv = send_messages(plan, cap)
     sh = torch.empty((P, bucket.M, 3), dtype=torch.float32, device=dev)
     # one kernel: per Gaussian, the views' rows added in ascending view order (zeros where no view touched it)
-    _C.view_messages_accumulate(recv, P, cap, bucket.sh_degree, bucket.M, bucket.means3D_ref, grads5 + [sh])
+    # (`sparse_rows` buckets: only for the Gaussians some view touched, marked in bucket.row_valid)
+    _C.view_messages_accumulate(recv, P, cap, bucket.sh_degree, bucket.M, bucket.means3D_ref, grads5 + [sh],
+                                row_valid=bucket.row_valid)
     bucket.views["sh"] = sh
     return "rows"
 
@@ -306,6 +313,8 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
     rank (tests: every route on the RCCL backend of a single-GPU box)."""
     single = not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1
     if single and not (force_exchange and dist.is_available() and dist.is_initialized()):
+        if bucket.row_valid is not None:
+            bucket.row_valid.fill_(1)
         if bucket.sh_exchange == "rgb":  # a single view: the "sum" has one term
             bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
                                                      bucket.sh_degree, bucket.M)
@@ -315,6 +324,8 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
             if radii is not None:
                 dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
             return "rows"
+    if bucket.row_valid is not None:
+        bucket.row_valid.fill_(1)  # every other route writes every row
     if bucket.sh_exchange == "rgb":
         # colour gradients + camera centres of all views, then the SH gradient of the batch, rebuilt locally
         n = dist.get_world_size(group)

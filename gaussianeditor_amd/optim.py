@@ -28,6 +28,9 @@ class FusedMaskedAdam(torch.optim.Optimizer):
       set_row_mask(mask)              (P,) bool / uint8 tensor, or None: the mask of `apply_grad_mask`
       set_anchor(param, anchor, scale, row_weight=None)
                                       adds scale * row_weight[row] * (param - anchor) to the gradient of `param`
+      set_grad_valid(mask)            (P,) uint8 tensor, or None: gradient rows with mask 0 were never written and count as
+                                      zeros without being read (multiview.GradBucket(..., sparse_rows=True).row_valid);
+                                      applies to every group, independently of `masked`
     A parameter's leading dimension is the Gaussian index; the row length is numel / shape[0]."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
@@ -37,6 +40,12 @@ class FusedMaskedAdam(torch.optim.Optimizer):
         self._row_mask: Optional[torch.Tensor] = None
         self._row_weight: Optional[torch.Tensor] = None
         self._anchors: Dict[torch.Tensor, tuple] = {}
+        self._grad_valid: Optional[torch.Tensor] = None
+
+    def set_grad_valid(self, mask: Optional[torch.Tensor]) -> None:
+        if mask is not None and (mask.dtype != torch.uint8 or not mask.is_contiguous()):
+            raise RuntimeError("FusedMaskedAdam.set_grad_valid: a contiguous uint8 tensor with one entry per Gaussian")
+        self._grad_valid = mask  # (not copied: the exchange refills it every step)
 
     def set_row_mask(self, mask: Optional[torch.Tensor]) -> None:
         self._row_mask = None if mask is None else mask.detach().to(torch.uint8).contiguous()
@@ -104,6 +113,8 @@ class FusedMaskedAdam(torch.optim.Optimizer):
                     masked = bool(group.get("masked", False)) and self._row_mask is not None
                     if masked and self._row_mask.numel() != rows:
                         raise RuntimeError("FusedMaskedAdam: the row mask must have one entry per Gaussian")
+                    if self._grad_valid is not None and self._grad_valid.numel() != rows:
+                        raise RuntimeError("FusedMaskedAdam: grad_valid must have one entry per Gaussian")
                     if anchor is not None and anchor[0].shape != p.shape:
                         raise RuntimeError("FusedMaskedAdam: anchor and parameter shapes differ")
                     # the kernel indexes row_weight[row] for every row of an anchored tensor: a weight vector of another
@@ -118,9 +129,10 @@ class FusedMaskedAdam(torch.optim.Optimizer):
                                                 anchor[1] if anchor is not None else 0.0)
                 mask_ptr = self._row_mask.data_ptr() if self._row_mask is not None else None
                 w_ptr = self._row_weight.data_ptr() if self._row_weight is not None else None
+                valid_ptr = self._grad_valid.data_ptr() if self._grad_valid is not None else None
                 with torch.cuda.device(dev):
-                    _native.check("gsr_adam_step", L.gsr_adam_step(
+                    _native.check("gsr_adam_step", L.gsr_adam_step_rows(
                         torch.cuda.current_stream(dev).cuda_stream, len(chunk), arr, step, float(betas[0]), float(betas[1]),
-                        float(eps), mask_ptr, w_ptr))
+                        float(eps), mask_ptr, w_ptr, valid_ptr))
                 del keep
         return loss

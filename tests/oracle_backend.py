@@ -112,11 +112,18 @@ def view_message_pack(plan, grads5, rgb, campos, cap, message):
         off += k * cap
 
 
-def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
+def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense, row_valid=None):
     nb = (int(P) + 1023) // 1024
+    stale = [None if d is None else d.clone() for d in dense] if row_valid is not None else None
     for d in dense:
         if d is not None:
             d.zero_()
+    if row_valid is not None:
+        row_valid.zero_()
+        for v in range(messages.size(0)):
+            msg = messages[v]
+            n = int(msg.view(torch.int32)[3])
+            row_valid[msg.view(torch.int32)[4 + nb:4 + nb + n].to(torch.int64)] = 1
     for v in range(messages.size(0)):  # ascending view order
         msg = messages[v]
         n = int(msg.view(torch.int32)[3])
@@ -136,6 +143,11 @@ def view_messages_accumulate(messages, P, cap, degree, M, means3D, dense):
             t = O.sh_grad_compose(means3D.detach()[i].numpy(), msg[0:3].reshape(1, 3).numpy(),
                                   rows[5].reshape(1, n, 3).numpy(), int(degree), int(M))
             dense[5][i] += torch.from_numpy(t)
+    if row_valid is not None:  # rows no view sent keep what they held (the kernel does not write them)
+        inv = ~row_valid.bool()
+        for d, o in zip(dense, stale):
+            if d is not None:
+                d[inv] = o[inv]
 
 
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,

@@ -45,7 +45,10 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
     try:
         case = make_case(P, W, H, seed=5, s0=s0, view=rank, nviews=world)
         sc = case["sc"]
-        bucket = GradBucket(P, 16, "cpu")  # "auto" -> "rgb" because two ranks run
+        sparse_rows = rows == "sparse_rows"  # the touched-rows route, writing only the rows some view touched
+        if sparse_rows:
+            rows = True
+        bucket = GradBucket(P, 16, "cpu", sparse_rows=sparse_rows)  # "auto" -> "rgb" because two ranks run
         assert bucket.sh_exchange == "rgb" and bucket.flat.numel() >= P * 14
         assert all(v.data_ptr() % 16 == 0 for v in bucket.views.values())  # whatever P is
         G = seed_gradient(H, W, 100 + rank) * H * W
@@ -71,7 +74,18 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
             assert grads["sh"] is None
             rows_of = torch.cat([v.reshape(P, -1) for v in bucket.flat_views().values()] + [bucket.rgb], dim=1)
             touched = float((rows_of != 0).any(dim=1).float().mean())
+            if sparse_rows:  # poison what must not be read afterwards: the rows that are zero on this rank
+                own = rows_of.any(dim=1)
             mode = allreduce_view_grads(bucket, radii, sparse=(rank >= 0), rows=rows)
+            if sparse_rows:
+                valid = bucket.row_valid.bool()
+                assert mode == "rows", mode
+                assert bool((valid | ~own).all()), "a row this rank touched is not marked valid"
+                assert int(valid.sum()) > 0  # (in this small scene the two views together reach nearly every Gaussian; the
+                #                              GPU suite checks a view pair that leaves 86 % of the rows invalid)
+                for name in ("means3D", "scales", "rotations", "means2D", "opacities"):
+                    assert not bool(bucket.views[name][~valid].any())  # (stale = this rank's own zeros)
+                bucket.views["sh"][~valid] = 0.0  # uninitialised by contract: what the consumer takes them for
         np.savez(os.path.join(out_dir, f"rgb_rank{rank}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
                  radii=radii.numpy(), touched=np.array([touched]), rows_route=np.array([mode == "rows"]))
     finally:
@@ -149,7 +163,8 @@ def test_two_rank_allreduce_matches_single_process(oracle, tmp_path, P):
 
 
 @pytest.mark.parametrize("rows,s0,P", [(False, 0.07, 1200), (True, 0.07, 1200), ("auto", 0.07, 1200), ("auto", 0.004, 1200),
-                                       (False, 0.07, 1201), (True, 0.07, 1201), ("auto", 0.07, 1202)])
+                                       (False, 0.07, 1201), (True, 0.07, 1201), ("auto", 0.07, 1202),
+                                       ("sparse_rows", 0.004, 1201)])
 def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path, rows, s0, P):
     world = 2
     mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path), rows, s0, P), nprocs=world, join=True)
@@ -169,7 +184,7 @@ def test_two_rank_rgb_exchange_matches_single_process(oracle, tmp_path, rows, s0
     assert rel_err(r0["flat"], tot) < 1e-6
     # the route: forced, or chosen from the gathered counts (72 B per touched row against the dense route's bytes)
     t = float(r0["touched"][0]) + float(r1["touched"][0])
-    want_rows = rows is True or (rows == "auto" and 72 * t <= 0.6 * (12 * world + 112))
+    want_rows = rows in (True, "sparse_rows") or (rows == "auto" and 72 * t <= 0.6 * (12 * world + 112))
     assert bool(r0["rows_route"][0]) == bool(r1["rows_route"][0]) == want_rows, (t, rows)
     if want_rows:  # packed rows are added view after view to zeros: the single process's sums, bit for bit
         assert np.array_equal(r0["flat"], tot)

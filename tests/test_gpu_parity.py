@@ -879,6 +879,51 @@ def test_touched_rows_exchange_kernels(oracle, D, s0, P):
         assert torch.equal(got, ref11.reshape(got.shape))
     assert torch.equal(dense11[5], _C.sh_grad_compose(m3, torch.stack([cams[v] for v in reps]),
                                                       torch.stack([rgbs[v] for v in reps]), D, M))
+    # only the rows some view sent (gsr_view_messages_accumulate_rows): those equal the dense sums bit for bit and are
+    # marked valid; nothing else is written; and the fused Adam that takes the mask (gsr_adam_step_rows: invalid rows are
+    # zero gradients that are never read -- here they are NaN) equals the step on the dense, zero-filled gradients
+    sparse = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [torch.full((P, M, 3), float("nan"), device=DEV)]
+    valid = torch.full((P,), 7, dtype=torch.uint8, device=DEV)
+    _C.view_messages_accumulate(messages, P, cap, D, M, m3, sparse, row_valid=valid)
+    sent = torch.zeros(P, dtype=torch.bool, device=DEV)
+    for v in range(views):
+        sent[messages[v].view(torch.int32)[4 + nb:4 + nb + int(messages[v].view(torch.int32)[3])].long()] = True
+    assert torch.equal(valid.bool(), sent) and int(valid.max()) == 1
+    for got, ref in zip(sparse, dense):
+        assert torch.equal(got[sent], ref[sent]) and bool(got[~sent].isnan().all()) and not bool(ref[~sent].any())
+    one = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [None]  # one view: fewer rows are valid
+    valid1 = torch.empty(P, dtype=torch.uint8, device=DEV)
+    _C.view_messages_accumulate(messages[:1], P, cap, D, M, m3, one, row_valid=valid1)
+    sent1 = torch.zeros(P, dtype=torch.bool, device=DEV)
+    sent1[messages[0].view(torch.int32)[4 + nb:4 + nb + int(messages[0].view(torch.int32)[3])].long()] = True
+    assert torch.equal(valid1.bool(), sent1)
+    for got, name in zip(one[:5], _ROW_SEGS):
+        ref1 = buckets[0].views[name].reshape(got.shape)
+        assert torch.equal(got[sent1], ref1[sent1]) and bool(got[~sent1].isnan().all()) and not bool(ref1[~sent1].any()), name
+    from gaussianeditor_amd.optim import FusedMaskedAdam
+
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    names = ("xyz", "scaling", "rotation", "m2", "opacity", "sh")
+    pa = {n: torch.randn(t.shape, device=DEV, generator=gen) for n, t in zip(names, dense)}
+    pb = {n: t.clone() for n, t in pa.items()}
+    anchor = {n: t + 0.01 for n, t in pa.items()}
+    row_mask = torch.rand(P, device=DEV, generator=gen) > 0.3
+    opts = []
+    for params, grads, gv in ((pa, dense, None), (pb, sparse, valid)):
+        ps = {n: torch.nn.Parameter(t) for n, t in params.items()}
+        opt = FusedMaskedAdam([{"params": [ps[n]], "lr": 1e-3 * (i + 1), "name": n, "masked": n in ("xyz", "sh")}
+                               for i, n in enumerate(names)], lr=0.0, eps=1e-15)
+        opt.set_row_mask(row_mask)
+        opt.set_anchor(ps["scaling"], anchor["scaling"], 0.5)
+        opt.set_grad_valid(gv)
+        for step in range(2):
+            for n, gt in zip(names, grads):
+                ps[n].grad = gt.reshape(ps[n].shape)
+            opt.step()
+        opts.append(ps)
+    for n in names:
+        assert torch.equal(opts[0][n].detach(), opts[1][n].detach()), n
+        assert bool(torch.isfinite(opts[1][n]).all())
     # without an SH target only the five dense segments are written; a single message is a valid batch
     dense2 = [torch.full((P, k), float("nan"), device=DEV) for k in (3, 3, 4, 3, 1)] + [None]
     _C.view_messages_accumulate(messages[:1], P, cap, D, M, m3, dense2)

@@ -51,4 +51,17 @@ for kind in ("torch_foreach", "torch_foreach_mask_hooks", "torch_fused", "hip"):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     out[kind] = {"ms_per_step": round(ms, 4), "GB_per_s_at_28B_per_scalar": round(28 * 59 * P / ms / 1e6, 1)}
+# gradients of which only the rows some view touched were written (multiview: GradBucket(..., sparse_rows=True)):
+# the step with FusedMaskedAdam.set_grad_valid reads no gradient of an invalid row
+for frac in (0.14, 0.32):
+    params, opt = make("hip")
+    opt.set_grad_valid((torch.rand(P, device=dev) < frac).to(torch.uint8))
+    for _ in range(3):
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        opt.step()
+    torch.cuda.synchronize()
+    out[f"hip_grad_valid_{frac}"] = {"ms_per_step": round((time.perf_counter() - t0) / 20 * 1e3, 4)}
 print(json.dumps(out, indent=1))
