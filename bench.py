@@ -102,6 +102,9 @@ def main():
     ap.add_argument("--ply-fit", type=int, default=1,
                     help="1 (default): translate the loaded scene's median to the origin and scale it (positions and scales) so "
                          "that 90 %% of the Gaussians lie within the unit ball the ring-v1 cameras look at; 0: as stored")
+    ap.add_argument("--persistent-grads", action="store_true",
+                    help="GradBucket(persistent_rows=True): the backward rewrites a zero gradient row only if it does not hold zeros "
+                         "already (development runs; the default writes every row of every gradient every iteration)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="development: on ONE GPU, run the multi-rank gradient exchange anyway (an RCCL group of one rank, "
                          "touched-rows route, every collective issued): what a rank's step costs locally before a byte "
@@ -177,7 +180,7 @@ def main():
     G = seed_gradient(H, W, 0).to(dev)
     rs = GaussianRasterizationSettings(H, W, tfx, tfy, sc["bg"].to(dev), 1.0, cam.world_view_transform.to(dev),
                                        cam.full_proj_transform.to(dev), ply_degree, cam.camera_center.to(dev), False, False)
-    bucket = GradBucket(P, M, dev, sh_exchange="rgb" if args.force_exchange else "auto")
+    bucket = GradBucket(P, M, dev, sh_exchange="rgb" if args.force_exchange else "auto", persistent_rows=args.persistent_grads)
 
     def sync_all():
         if world > 1:
@@ -406,6 +409,8 @@ def main():
                        "synth_s0": args.s0,
                        "grad_exchange": exchange + (" (forced on one rank: development run)" if args.force_exchange else ""),
                        "grad_exchange_route": route["last"],
+                       "grad_rows": "persistent: zero rows rewritten only when they do not hold zeros already (--persistent-grads)"
+                       if args.persistent_grads else "every row of every gradient written every iteration",
                        "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
                        "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
             "forward_renders_per_s": renders_per_s,

@@ -59,6 +59,8 @@ SIGNATURES = {
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                             c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gsr_preprocess_backward_rows": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
+                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_view_message_words": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
     "gsr_view_message_plan": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, POINTER(c_int64)]),

@@ -352,7 +352,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
                                     const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
                                     const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
                                     const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                                    float* dL_drgb, float* dL_dscales, float* dL_drots) {
+                                    float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state = nullptr) {
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
@@ -378,6 +378,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   pa.dL_drgb = shs ? dL_drgb : nullptr;
   pa.dL_dscale = scales ? dL_dscales : nullptr;
   pa.dL_drot = scales ? dL_drots : nullptr;
+  pa.row_state = row_state;
   GSR_HIP(launch_preprocess_backward((hipStream_t)stream, pa));
   return GSR_OK;
 }
@@ -436,6 +437,20 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                   viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
                                   dL_dcolors, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots);
+}
+
+int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                 const float* scales, float scale_modifier, const float* rotations,
+                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                 const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                                 const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                 float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state) {
+  if (!row_state || (dL_dsh && dL_drgb)) return GSR_ERR_BAD_ARGUMENT;
+  if (shs && !dL_dsh && !dL_drgb) return GSR_ERR_BAD_ARGUMENT;
+  return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_drgb, dL_dscales, dL_drots, row_state);
 }
 
 int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const float* means3D, const float* campos,

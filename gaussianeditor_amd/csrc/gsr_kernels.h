@@ -52,6 +52,7 @@ struct PreBwdArgs {
   float* dL_drgb;           // (P,3)   | null: the clamp-masked colour gradient, for gsr_sh_grad_compose
   float* dL_dscale;         // (P,3)   | null
   float* dL_drot;           // (P,4)   | null
+  uint8_t* row_state;       // (P) | null: gsr_preprocess_backward_rows -- rows that still hold this kernel's zeros are not rewritten
 };
 
 // K6 / K7 / K12 arguments (gsr_blend.hip)

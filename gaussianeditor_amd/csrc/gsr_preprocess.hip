@@ -491,6 +491,11 @@ __device__ __forceinline__ void sh_tile_store_rows(float* __restrict__ dst_rows,
 }
 
 // (Three waves per SIMD: the 52 KB of store tiles per workgroup allow three workgroups per CU, ~140 VGPRs.)
+// ROWS (PreBwdArgs::row_state, gsr_preprocess_backward_rows): the gradient arrays belong to the caller ACROSS calls.  Nine
+// Gaussians of ten get all-zero gradients from a view (culled, or no pixel blended them); their rows are rewritten only if
+// they do not hold this kernel's zeros already (row_state[g] != 0), so what leaves the chip per view is the rows that are
+// non-zero now or were the last time -- 248 B x ~20 % instead of 248 B x P.  dL_dcov3D is always written.
+template <bool ROWS>
 __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 preprocess_backward_kernel(const PreBwdArgs a) {
   __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
@@ -509,6 +514,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   V3 dscale = {0.f, 0.f, 0.f};
   float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
   V3 drgb = {0.f, 0.f, 0.f};  // dL_dRGB with the clamped channels zeroed (output of the "rgb" mode)
+  bool nonzero_in = false;    // ROWS: some entry of the Gaussian's accumulator rows is not zero (NaN != 0: counts)
 
   if (live && a.radii[idx] > 0) {
     Cam cam;
@@ -525,6 +531,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     }
     const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
     const V3 dL_dcon = {gc.x, gc.y, gc.w};
+    nonzero_in = gc.x != 0.f || gc.y != 0.f || gc.w != 0.f;
 
     // ---- computeCov2DCUDA, backward.cu:159-273 ----
     V3 t = {view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12],
@@ -596,6 +603,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
     const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+    nonzero_in = nonzero_in || g2x != 0.f || g2y != 0.f;
     V3 dL_dmean;
     dL_dmean.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
     dL_dmean.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
@@ -613,6 +621,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       const V3 dRGBdx = {d0.x, d0.y, d0.z}, dRGBdy = {d1.x, d1.y, d1.z}, dRGBdz = {d2.x, d2.y, d2.z};
       const uint8_t cl = a.clamped[idx];
       V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
+      nonzero_in = nonzero_in || dL_dRGB.x != 0.f || dL_dRGB.y != 0.f || dL_dRGB.z != 0.f;
       dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
       dL_dRGB.y *= (cl & 2) ? 0.f : 1.f;
       dL_dRGB.z *= (cl & 4) ? 0.f : 1.f;
@@ -695,7 +704,18 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     }
   }
 
-  if (a.dL_dsh != nullptr) {
+  if (ROWS) {
+    if (!live) return;
+    // the inputs of a Gaussian decide: all-zero accumulator rows give all-zero gradients (with precomputed colours the
+    // colour accumulator is not this kernel's input)
+    const bool nonzero = nonzero_in;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    const uint8_t was = a.row_state[idx];
+    if (!nonzero && was == 0) return;  // the rows hold the zeros written when this Gaussian last went from non-zero to zero
+    if ((nonzero ? 1 : 0) != was) a.row_state[idx] = nonzero ? 1 : 0;
+    if (a.dL_dsh != nullptr) store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
+  } else if (a.dL_dsh != nullptr) {
     if (a.M == 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0) {
       const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
       const int row0 = idx_raw - lane;  // first row of this wave
@@ -713,8 +733,10 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx], dmean.x);
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 1], dmean.y);
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 2], dmean.z);
+  if (!ROWS) {
 #pragma unroll
-  for (int i = 0; i < 6; ++i) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);
+    for (int i = 0; i < 6; ++i) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);
+  }
   if (a.dL_drgb != nullptr) {
     a.dL_drgb[3 * (size_t)idx] = drgb.x;
     a.dL_drgb[3 * (size_t)idx + 1] = drgb.y;
@@ -1117,7 +1139,8 @@ hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int 
 }
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(preprocess_backward_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  if (a.row_state != nullptr) hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 

@@ -180,7 +180,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
       "sh_rgb"             shape (P,3): a tensor here asks for the clamp-masked colour gradient INSTEAD of dL_dsh (which is
                            then returned as None; gaussianeditor_amd.multiview rebuilds it after the exchange);
       "after_blend_backward"  a notification, only in the "sh_rgb" mode: `shape` is the tuple of the four accumulators,
-                           K7 has been enqueued and K8+K9 has not; the return value is ignored."""
+                           K7 has been enqueued and K8+K9 has not; the return value is ignored;
+      "row_state"          shape (P,): a uint8 tensor here says that "means3D", "sh" / "sh_rgb", "scales" and "rotations" were
+                           answered with tensors the allocator keeps across calls, with this per-Gaussian state next to them
+                           (include/gsr.h: gsr_preprocess_backward_rows): rows that still hold the zeros of an earlier call
+                           are not rewritten."""
     flags = _flags(flags)
     dev = means3D.device
     P = int(means3D.size(0))
@@ -241,9 +245,29 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)
+    row_state = grad_alloc("row_state", (P,), False) if grad_alloc is not None else None
+    if row_state is not None and not (isinstance(row_state, torch.Tensor) and row_state.dtype == torch.uint8 and
+                                      row_state.numel() == P and row_state.is_contiguous() and row_state.device == dev):
+        row_state = None
     L = _native.lib()
     with torch.cuda.device(dev):
-        if dL_drgb is None:
+        if row_state is not None:  # gradient arrays kept across calls: only the rows that change are written
+            if int(R) > 0:
+                _native.check("gsr_blend_backward", L.gsr_blend_backward(
+                    _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
+                    imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), flags))
+            if dL_drgb is not None:
+                grad_alloc("after_blend_backward", (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), False)
+            _native.check("gsr_preprocess_backward_rows", L.gsr_preprocess_backward_rows(
+                _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
+                _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
+                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), dL_dmeans2D.data_ptr(),
+                dL_dconic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                _ptr(dL_dsh) if dL_drgb is None else None, None if dL_drgb is None else dL_drgb.data_ptr(),
+                dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None,
+                row_state.data_ptr()))
+        elif dL_drgb is None:
             _native.check("gsr_backward", L.gsr_backward(
                 _stream(dev), P, int(degree), M, int(R), W, H, background.data_ptr(), means3D.data_ptr(), _ptr(sh),
                 _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),

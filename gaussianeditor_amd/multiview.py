@@ -58,8 +58,15 @@ class GradBucket:
     means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent -- and followed, outside
     the exchanged part, by the backward's two internal accumulators -- so that one fill clears all four."""
 
-    def __init__(self, P: int, M: int, device, sh_exchange: str = "auto", sparse_rows: bool = False):
+    def __init__(self, P: int, M: int, device, sh_exchange: str = "auto", sparse_rows: bool = False,
+                 persistent_rows: bool = False):
         self.P, self.M = int(P), int(M)
+        #: `persistent_rows`: the bucket's gradient tensors live across iterations, and a view leaves nine rows of ten zero.
+        #: With `row_state` (uint8 (P,), 1 = the row may hold anything) next to them the backward rewrites a zero row only if
+        #: it does not already hold the zeros of an earlier backward (gsr_preprocess_backward_rows): K8+K9 72 -> 54 us at 1 M
+        #: Gaussians, 401 -> 244 us at 6 M.  Every row is valid and correct after every backward, as without the option.
+        #: Whatever else writes into the bucket's gradients must call invalidate_rows() (the exchange routes do).
+        self.row_state = torch.ones(int(P), dtype=torch.uint8, device=device) if persistent_rows else None
         #: `sparse_rows`: the touched-rows exchange writes the summed gradients only for the Gaussians some view touched and
         #: marks them in `row_valid` (uint8 (P,)); the other rows of the gradient tensors are stale or uninitialised and count
         #: as zeros -- hand `row_valid` to the consumer (FusedMaskedAdam.set_grad_valid).  After any other route every row is
@@ -104,7 +111,14 @@ class GradBucket:
         # the span one fill clears for the two atomically accumulated gradients (means2D .. end of opacities)
         self._acc_span = (offs["means2D"], offs["opacities"] + P)
 
+    def invalidate_rows(self) -> None:
+        """Something other than the backward has written to the gradient tensors: every row is rewritten next time."""
+        if self.row_state is not None:
+            self.row_state.fill_(1)
+
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool):
+        if name == "row_state":  # (asked last: the gradient tensors handed out above are this bucket's own)
+            return self.row_state if (self.row_state is not None and tuple(shape) == (self.P,)) else None
         if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the four accumulators)
             if self.on_blend_done is not None:
                 self.on_blend_done(shape)
@@ -319,6 +333,7 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
             bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
                                                      bucket.sh_degree, bucket.M)
         return "local"
+    bucket.invalidate_rows()  # every route below writes sums into the bucket's gradient tensors
     if bucket.sh_exchange == "rgb" and rows in ("auto", True):
         if _exchange_touched_rows(bucket, group, dist.get_world_size(group), force=rows is True) is not None:
             if radii is not None:

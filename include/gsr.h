@@ -194,6 +194,25 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
                                 const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
                                 const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
                                 float* dL_dscales, float* dL_drots);
+
+/* The same kernel for gradient arrays the caller keeps ACROSS calls (a training loop's gradient bucket).  A view leaves
+ * nine Gaussians of ten with all-zero gradients (culled, or blended by no pixel), and rewriting those zeros is most of
+ * this kernel's traffic (248 B per Gaussian at M = 16).  row_state (P bytes, device) travels with the arrays
+ * dL_dmeans3D, dL_dsh or dL_drgb (exactly one of the two, the other NULL), dL_dscales, dL_drots:
+ *   row_state[g] != 0  the rows of g may hold anything: they are written (values, or zeros) -- initialise to 1;
+ *   row_state[g] == 0  the rows of g hold the zeros this function wrote before: if g's gradients are zero again, nothing
+ *                      is written.
+ * On return row_state[g] = 1 iff g's gradients may be non-zero.  After the call every row holds what
+ * gsr_preprocess_backward(_rgb) would have written (a Gaussian with all-zero accumulator rows gets exact zeros; non-finite
+ * parameters, for which 0 x inf would give NaN there, give zeros here).  Whoever else writes to these arrays must set
+ * row_state to 1 for the rows it touched.  dL_dcov3D is written for every Gaussian. */
+int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
+                                 const float* scales, float scale_modifier, const float* rotations,
+                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
+                                 const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
+                                 const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                 float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state);
 int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const float* means3D, const float* campos,
                         const float* dL_drgb, float* dL_dsh);
 

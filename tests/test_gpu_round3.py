@@ -156,3 +156,55 @@ def test_row_arena_prune_and_append_bit_exact():
     (q1.sum() + q2.sum()).backward()
     opt.step()  # the grown optimizer keeps stepping
     assert int(opt.state[q1]["step"]) == 2 and len(opt.state) == 2
+
+
+@pytest.mark.parametrize("mode", ["direct", "rgb"])
+def test_persistent_gradient_rows_equal_the_dense_backward(mode):
+    """GradBucket(persistent_rows=True): the backward rewrites a zero gradient row only when it does not already hold the
+    zeros of an earlier backward (gsr_preprocess_backward_rows).  Over a sequence of different views -- Gaussians go from
+    touched to untouched and back -- every gradient tensor equals the one a fresh bucket (every row written) gets, every time (up to the run-to-run
+    spread of the blend backward's float atomics; the all-zero rows are the same rows);
+    and the state says "zero" exactly for the rows that are zero."""
+    from gaussianeditor_amd.multiview import GradBucket, render_view_grads
+    from helpers import seed_gradient, settings
+
+    P, W, H = 60000, 640, 480
+    d = lambda t: t.to(DEV)  # noqa: E731
+    def _same(a, c, what):
+        # two runs of the blend backward differ in the last bits (float atomics): same zero rows, values within 1e-5 of max
+        assert not bool(a.isnan().any()), what
+        za, zc = (a.reshape(P, -1) == 0).all(dim=1), (c.reshape(P, -1) == 0).all(dim=1)
+        assert torch.equal(za, zc), what
+        assert float((a - c).abs().max()) <= 1e-5 * float(c.abs().max()) + 1e-30, what
+
+    keep = GradBucket(P, 16, DEV, sh_exchange=mode, persistent_rows=True)
+    keep.flat.fill_(float("nan"))  # nothing may survive from before the first backward
+    if keep.rgb is not None:
+        keep.rgb.fill_(float("nan"))
+    zero_rows_seen = 0
+    for step, view in enumerate([0, 3, 0, 5, 5, 1]):
+        case = make_case(P, W, H, seed=11, s0=0.02, view=view, nviews=8)
+        sc = case["sc"]
+        G = d(seed_gradient(H, W, 40 + step)) * H * W
+        fresh = GradBucket(P, 16, DEV, sh_exchange=mode)
+        outs = []
+        for b in (keep, fresh):
+            _, radii, _, grads = render_view_grads(settings(case, DEV), d(sc["xyz"]), d(sc["opacity"]), d(sc["features"]),
+                                                   d(sc["scaling"]), d(sc["rotation"]), G, b)
+            outs.append((grads, radii))
+        for name in ("means3D", "sh", "opacities", "scales", "rotations", "means2D"):
+            a, c = outs[0][0][name], outs[1][0][name]
+            assert (a is None) == (c is None), name
+            if a is not None:
+                _same(a, c, (step, name))
+        if mode == "rgb":
+            _same(keep.rgb, fresh.rgb, (step, "rgb"))
+        rows = torch.cat([fresh.views[n].reshape(P, -1) for n in ("means3D", "scales", "rotations")] +
+                         ([fresh.rgb] if mode == "rgb" else [fresh.views["sh"].reshape(P, -1)]), dim=1)
+        nz = (rows != 0).any(dim=1)
+        st = keep.row_state.bool()
+        assert bool((st | ~nz).all())          # a row with a non-zero entry is marked
+        zero_rows_seen += int((~st).sum())
+    assert zero_rows_seen > P  # (most rows are zero for every view: the state is not just "all dirty")
+    keep.invalidate_rows()
+    assert int(keep.row_state.min()) == 1
