@@ -333,12 +333,19 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
             bucket.views["sh"] = _C.sh_grad_compose(bucket.means3D_ref, bucket.campos.view(1, 3), bucket.rgb.view(1, bucket.P, 3),
                                                      bucket.sh_degree, bucket.M)
         return "local"
-    bucket.invalidate_rows()  # every route below writes sums into the bucket's gradient tensors
     if bucket.sh_exchange == "rgb" and rows in ("auto", True):
         if _exchange_touched_rows(bucket, group, dist.get_world_size(group), force=rows is True) is not None:
+            if bucket.row_state is not None:
+                # persistent rows: the accumulate kernel wrote sums into the rows it marks valid (all rows without sparse_rows);
+                # a row it did not write still holds the backward's zeros
+                if bucket.row_valid is not None:
+                    bucket.row_state.copy_(bucket.row_valid)
+                else:
+                    bucket.invalidate_rows()
             if radii is not None:
                 dist.all_reduce(radii, op=dist.ReduceOp.MAX, group=group)
             return "rows"
+    bucket.invalidate_rows()  # every route below writes sums into all rows of the bucket's gradient tensors
     if bucket.row_valid is not None:
         bucket.row_valid.fill_(1)  # every other route writes every row
     if bucket.sh_exchange == "rgb":

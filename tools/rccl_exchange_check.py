@@ -94,6 +94,36 @@ def main():
         if rank == 0:
             print(f"[rccl_exchange_check] world {world} exchange {exch} route {route}: ok" if not failures else
                   f"[rccl_exchange_check] failures so far: {failures}", flush=True)
+    # sparse + persistent rows (GradBucket(sparse_rows=True, persistent_rows=True)) over several steps on ONE bucket: the
+    # exchange writes only the rows some view touched, the backward rewrites a zero row only if it does not hold zeros
+    # already; after every step the valid rows hold the batch sums, the others are zero (SH rows: not written at all)
+    bucket = GradBucket(P, M, dev, sh_exchange="rgb", sparse_rows=True, persistent_rows=True)
+    for step in range(4):
+        shift = step % max(world, 2)
+        view = (rank + shift) % max(world, 2)
+        ref = None
+        for v in range(world):
+            vv = (v + shift) % max(world, 2)
+            _, _, _, g = render_view_grads(settings(vv), params["xyz"], params["opacity"], params["features"],
+                                           params["scaling"], params["rotation"], G(vv))
+            ref = {k: g[k].clone() for k in names} if ref is None else {k: ref[k] + g[k] for k in names}
+        multiview_step(settings(view), params, G(view), bucket, force_exchange=True, rows=True)
+        torch.cuda.synchronize(dev)
+        valid = bucket.row_valid.bool()
+        for k in names:
+            got, want_k = bucket.views[k].reshape(P, -1), ref[k].reshape(P, -1)
+            scale = float(want_k.abs().max()) or 1.0
+            if float((got[valid] - want_k[valid]).abs().max()) / scale > 2e-6:
+                failures.append(f"sparse+persistent step {step}: {k} valid rows differ")
+            if bool(want_k[~valid].any()):
+                failures.append(f"sparse+persistent step {step}: {k} has a non-zero row that is not marked valid")
+            if k != "sh" and bool(got[~valid].any()):
+                failures.append(f"sparse+persistent step {step}: {k} invalid rows are not zero")
+        if not (0 < int(valid.sum()) < P):
+            failures.append(f"sparse+persistent step {step}: {int(valid.sum())} valid rows of {P}")
+    if rank == 0:
+        print("[rccl_exchange_check] sparse + persistent rows over 4 steps: ok" if not failures else
+              f"[rccl_exchange_check] failures so far: {failures}", flush=True)
     dist.barrier()
     dist.destroy_process_group()
     if failures:
