@@ -9,8 +9,7 @@ of `GaussianModel.apply_grad_mask` (:841-856) is applied inside, and optionally 
 """
 from __future__ import annotations
 
-import ctypes
-from typing import Dict, Iterable, Optional
+from typing import Dict, Optional
 
 import torch
 
