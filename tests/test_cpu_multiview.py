@@ -247,6 +247,14 @@ def test_bucket_layout_and_allocator():
         assert four[2].data_ptr() % 16 == 0 and tuple(four[2].shape) == (P_, 4) and tuple(four[3].shape) == (P_, 3)
         b3 = GradBucket(P_, 16, "cpu", sh_exchange="rgb")
         assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
+        # the two opt-in row masks: absent by default; persistent rows start out "may hold anything" and return there
+        assert b3.row_valid is None and b3.row_state is None and b3.allocator("row_state", (P_,), False) is None
+        b4 = GradBucket(P_, 16, "cpu", sparse_rows=True, persistent_rows=True)
+        assert b4.row_valid.dtype == b4.row_state.dtype == torch.uint8 and int(b4.row_state.min()) == int(b4.row_valid.min()) == 1
+        assert b4.allocator("row_state", (P_,), False) is b4.row_state and b4.allocator("row_state", (P_ + 1,), False) is None
+        b4.row_state.zero_()
+        b4.invalidate_rows()
+        assert int(b4.row_state.min()) == 1
 
 
 def test_grad_allocator_rides_on_the_autograd_node(oracle, monkeypatch):
