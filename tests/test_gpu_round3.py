@@ -208,3 +208,21 @@ def test_persistent_gradient_rows_equal_the_dense_backward(mode):
     assert zero_rows_seen > P  # (most rows are zero for every view: the state is not just "all dirty")
     keep.invalidate_rows()
     assert int(keep.row_state.min()) == 1
+
+
+def test_bench_line_carries_the_contract_fields_and_the_gradient_row_mode():
+    """`bench.py` (small run): one JSON line with the contract's keys, `roofline` and the note how gradient rows are written;
+    `--persistent-grads` is a labelled development mode, not the default."""
+    import json
+
+    for extra, word in (([], "every row"), (["--persistent-grads"], "persistent")):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gaussians", "50000", "--steps", "5", "--warmup", "2",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                           env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in line, key
+        assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0 and word in line["config"]["grad_rows"]
+        assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
