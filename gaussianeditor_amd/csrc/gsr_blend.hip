@@ -1039,9 +1039,46 @@ constexpr int BWD_BUCKETS = 256;
 // (the kernel ends with its longest tile: measured 505 K of 509 K cycles).  Such tiles are cut into two items, each
 // a workgroup that covers TWO quadrants with two waves per quadrant (8x4 pixels per wave): half the tile per
 // workgroup, and the finer culling shortens the waves' lists as well.  `workgroups` = size of the launch.
+// GSR_FLAG_CLEAR_GRADS: the four arrays the blend backward accumulates into are cleared by EXTRA blocks of this launch
+// (blocks 1 .. gridDim.x - 1; block 0 is the work list): the list is one block of dependent round trips during which the
+// rest of the chip idles.  Measured: work list 8.2 us + a separate fill of 44 bytes per Gaussian 8.9 us -> 14 us together
+// (the fill runs at 3.1 TB/s here against 4.9 TB/s alone), and one launch less between the forward and the backward.
+struct ClearArgs {
+  float* ptr[4];
+  long long n[4];  // floats
+};
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
                                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
-                                                                uint32_t workgroups, int allow_halves) {  // allow_halves: 0, or the threshold in 1/8 of a fair share
+                                                                uint32_t workgroups, int allow_halves,  // allow_halves: 0, or the threshold in 1/8 of a fair share
+                                                                const ClearArgs clear) {
+  if (blockIdx.x != 0) {
+    const long long nb = (long long)gridDim.x - 1, b = (long long)blockIdx.x - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* const p = clear.ptr[k];
+      const long long n = clear.n[k];
+      if (p == nullptr || n <= 0) continue;
+      // 16-byte stores over the aligned middle, scalar stores at the two ends
+      const long long head = min(n, (long long)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / 4u));
+      const long long n4 = (n - head) / 4;
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4* const q = reinterpret_cast<f4*>(p + head);
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      // consecutive blocks take consecutive 64 KB pieces (4 x 16 KB per thread block and round), four stores in flight per thread
+      for (long long i0 = b * 4096; i0 < n4; i0 += nb * 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long i = i0 + u * 1024 + threadIdx.x;
+          if (i < n4) q[i] = z;
+        }
+      }
+      if (b == 0) {
+        for (long long i = threadIdx.x; i < head; i += 1024) p[i] = 0.f;
+        for (long long i = head + 4 * n4 + threadIdx.x; i < n; i += 1024) p[i] = 0.f;
+      }
+    }
+    return;
+  }
   // (BWD_SUB counters per bucket, chosen by the lane: see tile_worklist_kernel in gsr_binning.hip)
   constexpr int BWD_SUB = 16, NCNT = (BWD_BUCKETS + 1) * BWD_SUB;
   __shared__ uint32_t cnt[NCNT];
@@ -1217,14 +1254,27 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   a.units = (int)blend_units(BWD_WAVES, s);
   // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
   static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
+  ClearArgs clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
+  if (a.clear_grads) {
+    const long long P = a.P;
+    clear.ptr[0] = a.dL_dmean2D; clear.n[0] = 3 * P;
+    clear.ptr[1] = a.dL_dconic; clear.n[1] = 4 * P;
+    clear.ptr[2] = a.dL_dopacity; clear.n[2] = P;
+    clear.ptr[3] = a.dL_dcolors; clear.n[3] = 3 * P;
+  }
   if (own_list && a.work_est != nullptr) {
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
-    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order, a.bwd_meta,
-                       blend_grid_size(true, s) / BWD_WAVES, halves);
+    const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : 0u;  // (1 .. 8 per CU: the same 14 us)
+    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order,
+                       a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear);
     a.work_order = a.bwd_order;
     a.work_meta = a.bwd_meta;
   } else {
     a.units = 0;  // the list-length order is too poor a predictor for assigned first tiles (measured: +4 %)
+    for (int k = 0; k < 4 && a.clear_grads; ++k) {
+      hipError_t me = hipMemsetAsync(clear.ptr[k], 0, sizeof(float) * (size_t)clear.n[k], s);
+      if (me != hipSuccess) return me;
+    }
   }
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();

@@ -328,7 +328,16 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
                        const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
                        float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags) {
   if (flags & ~GSR_FLAG_ALL) return GSR_ERR_BAD_ARGUMENT;
-  if (P == 0 || R == 0) return GSR_OK;
+  if (P == 0) return GSR_OK;
+  if (R == 0) {  // nothing to blend: the accumulators stay zero -- or become zero
+    if (flags & GSR_FLAG_CLEAR_GRADS) {
+      if (P < 0 || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors) return GSR_ERR_BAD_ARGUMENT;
+      float* const acc[4] = {dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors};
+      const size_t len[4] = {3, 4, 1, 3};
+      for (int k = 0; k < 4; ++k) GSR_HIP(hipMemsetAsync(acc[k], 0, sizeof(float) * len[k] * (size_t)P, (hipStream_t)stream));
+    }
+    return GSR_OK;
+  }
   if (P < 0 || R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
   if (!bg || !geom || !binning || !image || !dL_dpix || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors)
     return GSR_ERR_BAD_ARGUMENT;
@@ -342,6 +351,8 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   a.dL_dopacity = dL_dopacity;
   a.dL_dcolors = dL_dcolors;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
+  a.P = P;
+  a.clear_grads = (flags & GSR_FLAG_CLEAR_GRADS) ? 1 : 0;
   GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
   return GSR_OK;
 }

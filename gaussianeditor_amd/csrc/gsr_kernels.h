@@ -88,6 +88,8 @@ struct BlendArgs {
   const float* image_weights;
   float* weights;
   int32_t* cnt;
+  int P;           // number of Gaussians (rows of the backward's accumulators)
+  int clear_grads; // GSR_FLAG_CLEAR_GRADS: the backward clears its four accumulators itself (launch_blend_backward)
   int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)

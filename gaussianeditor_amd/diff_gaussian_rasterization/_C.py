@@ -173,7 +173,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     "means2D", "opacities", "means3D", "cov3Ds_precomp", "sh", "scales", "rotations" with the tensor's shape.  An allocator
     may answer None to anything (the gradient is then allocated privately).  Four special names, all optional:
       "accumulators"       shape (11 P,): -> (dL_dmeans2D (P,3), dL_dopacity (P,1), dL_dconic (P,4), dL_dcolors (P,3)), the
-                           four buffers the blend backward adds into, already zeroed when `zero` (one fill for all four);
+                           four buffers the blend backward adds into (asked with zero = False since round 3: the blend
+                           backward clears them itself, GSR_FLAG_CLEAR_GRADS);
       "means2D+opacities"  shape (4 P,): -> (dL_dmeans2D, dL_dopacity) only, zeroed likewise;
                            (anything but a tuple of the right length and shapes is ignored: an allocator that answers
                            unknown names with a plain tensor keeps working)
@@ -218,23 +219,25 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 return None
         return tuple(ans)
 
-    four = _views(grad_alloc("accumulators", (11 * P,), True), ((P, 3), (P, 1), (P, 4), (P, NUM_CHANNELS))) \
+    # (none of them is zero-filled here: the blend backward clears all four itself, inside the launch that builds its work
+    # list -- GSR_FLAG_CLEAR_GRADS; a separate fill of 44 bytes per Gaussian cost 8 us at 10^6 Gaussians)
+    four = _views(grad_alloc("accumulators", (11 * P,), False), ((P, 3), (P, 1), (P, 4), (P, NUM_CHANNELS))) \
         if grad_alloc is not None else None
     joint = None if (four is not None or grad_alloc is None) else \
-        _views(grad_alloc("means2D+opacities", (4 * P,), True), ((P, 3), (P, 1)))
+        _views(grad_alloc("means2D+opacities", (4 * P,), False), ((P, 3), (P, 1)))
     if four is not None:
         dL_dmeans2D, dL_dopacity, dL_dconic, dL_dcolors = four
     elif joint is not None:
         dL_dmeans2D, dL_dopacity = joint
-        rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
+        rest = torch.empty((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
     elif grad_alloc is not None:
-        dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), True, dev)
-        dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), True, dev)
-        rest = torch.zeros((7 * P,), dtype=torch.float32, device=dev)
+        dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), False, dev)
+        dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), False, dev)
+        rest = torch.empty((7 * P,), dtype=torch.float32, device=dev)
         dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
     else:
-        acc = torch.zeros((11 * P,), dtype=torch.float32, device=dev)  # conic first: its rows are dwordx4-accessed
+        acc = torch.empty((11 * P,), dtype=torch.float32, device=dev)  # conic first: its rows are dwordx4-accessed
         dL_dconic, dL_dmeans2D = acc[:4 * P].view(P, 4), acc[4 * P:7 * P].view(P, 3)
         dL_dcolors, dL_dopacity = acc[7 * P:10 * P].view(P, NUM_CHANNELS), acc[10 * P:].view(P, 1)
     dL_dmeans3D = _alloc(grad_alloc, "means3D", (P, 3), False, dev)
@@ -245,6 +248,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)
+    bwd_flags = flags | options.FLAG_CLEAR_GRADS  # (the accumulators above are not zero: the blend backward clears them)
     row_state = grad_alloc("row_state", (P,), False) if grad_alloc is not None else None
     if row_state is not None and not (isinstance(row_state, torch.Tensor) and row_state.dtype == torch.uint8 and
                                       row_state.numel() == P and row_state.is_contiguous() and row_state.device == dev):
@@ -252,11 +256,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     L = _native.lib()
     with torch.cuda.device(dev):
         if row_state is not None:  # gradient arrays kept across calls: only the rows that change are written
-            if int(R) > 0:
-                _native.check("gsr_blend_backward", L.gsr_blend_backward(
-                    _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                    imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
-                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), flags))
+            # (also when nothing was rendered: the call then only clears the accumulators)
+            _native.check("gsr_blend_backward", L.gsr_blend_backward(
+                _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), bwd_flags))
             if dL_drgb is not None:
                 grad_alloc("after_blend_backward", (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), False)
             _native.check("gsr_preprocess_backward_rows", L.gsr_preprocess_backward_rows(
@@ -275,13 +279,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
                 dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
-                dL_drotations.data_ptr() if has_scales else None, flags))
+                dL_drotations.data_ptr() if has_scales else None, bwd_flags))
         else:
-            if int(R) > 0:
-                _native.check("gsr_blend_backward", L.gsr_blend_backward(
-                    _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                    imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
-                    dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), flags))
+            # (also when nothing was rendered: the call then only clears the accumulators)
+            _native.check("gsr_blend_backward", L.gsr_blend_backward(
+                _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
+                dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), bwd_flags))
             # notification (no allocation): K7 is enqueued, K8+K9 not yet -- multiview.py starts the exchange of the
             # touched-row counts here, so that it (and the host's wait for it) runs underneath K8+K9
             grad_alloc("after_blend_backward", (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), False)

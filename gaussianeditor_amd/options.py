@@ -13,7 +13,8 @@ import threading
 
 FLAG_TILE_BOUNDS_ALPHA = 1
 FLAG_FAST_EXP = 2
-FLAG_ALL = 3
+FLAG_ALL = 3             # the behaviour switches a caller may set
+FLAG_CLEAR_GRADS = 4     # (internal to the binding: the backward clears its accumulators itself; include/gsr.h)
 
 _default = 0
 _local = threading.local()

@@ -84,6 +84,9 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *                        forward.cu:340-344, so images, depths, radii, traced weights and gradients are unchanged --
  *                        but num_rendered, the instance lists in the binning scratch and n_contrib differ from the
  *                        reference's.
+ *   GSR_FLAG_CLEAR_GRADS (read by gsr_blend_backward / gsr_backward) dL_dmeans2D, dL_dconic, dL_dopacity and dL_dcolors
+ *       need not be zero on entry: the call clears them before it accumulates (inside the launch that builds the backward's
+ *       work list, while that one workgroup runs: 14 us instead of 8 + 9 at 10^6 Gaussians, and one launch less);
  *   GSR_FLAG_FAST_EXP    (read by the blend / trace entry points) exp(power) is evaluated with the hardware's
  *                        v_exp_f32 (2^x, 1 ulp) on power * log2(e) instead of the exactly specified polynomial
  *                        gsr_expf.  Colours / depths / gradients stay within the 1e-5 parity
@@ -93,7 +96,8 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  * Unknown bits are rejected with GSR_ERR_BAD_ARGUMENT. */
 #define GSR_FLAG_TILE_BOUNDS_ALPHA 1u
 #define GSR_FLAG_FAST_EXP 2u
-#define GSR_FLAG_ALL 3u
+#define GSR_FLAG_CLEAR_GRADS 4u
+#define GSR_FLAG_ALL 7u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);
