@@ -67,6 +67,7 @@ class GradBucket:
         #: Gaussians, 401 -> 244 us at 6 M.  Every row is valid and correct after every backward, as without the option.
         #: Whatever else writes into the bucket's gradients must call invalidate_rows() (the exchange routes do).
         self.row_state = torch.ones(int(P), dtype=torch.uint8, device=device) if persistent_rows else None
+        self._handed = set()  # names of the gradients handed out as this bucket's tensors in the current backward
         #: `sparse_rows`: the touched-rows exchange writes the summed gradients only for the Gaussians some view touched and
         #: marks them in `row_valid` (uint8 (P,)); the other rows of the gradient tensors are stale or uninitialised and count
         #: as zeros -- hand `row_valid` to the consumer (FusedMaskedAdam.set_grad_valid).  After any other route every row is
@@ -117,14 +118,22 @@ class GradBucket:
             self.row_state.fill_(1)
 
     def allocator(self, name: str, shape: Tuple[int, ...], zero: bool):
-        if name == "row_state":  # (asked last: the gradient tensors handed out above are this bucket's own)
-            return self.row_state if (self.row_state is not None and tuple(shape) == (self.P,)) else None
+        if name == "row_state":
+            # asked last.  Only if every gradient the state stands for was answered with this bucket's own tensor in THIS
+            # backward: a row that is not rewritten must be a row of a tensor that lives across iterations
+            own = {"means3D", "scales", "rotations"} <= self._handed and ({"sh", "sh_rgb"} & self._handed)
+            return self.row_state if (self.row_state is not None and own and tuple(shape) == (self.P,)) else None
         if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the four accumulators)
             if self.on_blend_done is not None:
                 self.on_blend_done(shape)
             return None
         if name == "sh_rgb":  # "rgb" exchange mode: ask the backward for dL_dRGB instead of dL_dsh
-            return self.rgb if (self.rgb is not None and tuple(shape) == (self.P, 3)) else None
+            ok = self.rgb is not None and tuple(shape) == (self.P, 3)
+            if ok:
+                self._handed.add("sh_rgb")
+            return self.rgb if ok else None
+        if name in ("accumulators", "means2D+opacities", "means2D"):
+            self._handed = set()  # (the first request of a backward)
         if name == "accumulators":  # means2D, opacities and the two internal accumulators, zeroed by ONE fill
             if tuple(shape) != (11 * self.P,):
                 return None
@@ -144,6 +153,7 @@ class GradBucket:
             return None
         if zero:
             v.zero_()
+        self._handed.add(name)
         return v
 
     def attach(self, color: torch.Tensor) -> None:

@@ -251,7 +251,16 @@ def test_bucket_layout_and_allocator():
         assert b3.row_valid is None and b3.row_state is None and b3.allocator("row_state", (P_,), False) is None
         b4 = GradBucket(P_, 16, "cpu", sparse_rows=True, persistent_rows=True)
         assert b4.row_valid.dtype == b4.row_state.dtype == torch.uint8 and int(b4.row_state.min()) == int(b4.row_valid.min()) == 1
+        # the state is only handed out in a backward whose gradients were all answered with the bucket's own tensors
+        assert b4.allocator("row_state", (P_,), False) is None
+        b4.allocator("accumulators", (11 * P_,), False)
+        for nm in ("means3D", "scales", "rotations"):
+            assert b4.allocator(nm, tuple(b4.views[nm].shape), False) is b4.views[nm]
+        assert b4.allocator("row_state", (P_,), False) is None  # (the SH / colour gradient is missing)
+        assert b4.allocator("sh", (P_, 16, 3), False) is b4.views["sh"]
         assert b4.allocator("row_state", (P_,), False) is b4.row_state and b4.allocator("row_state", (P_ + 1,), False) is None
+        b4.allocator("accumulators", (11 * P_,), False)  # the next backward starts from nothing again
+        assert b4.allocator("row_state", (P_,), False) is None
         b4.row_state.zero_()
         b4.invalidate_rows()
         assert int(b4.row_state.min()) == 1
