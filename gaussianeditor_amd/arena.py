@@ -13,8 +13,10 @@ buffer with head-room:
     the halves swap: no allocation of parameter size, nothing freed;
   * DENSIFY = the new rows written BEHIND the live rows of the live half (`gsr_append_rows` with no old rows to move):
     the old rows are not touched at all, where `torch.cat` copies all of them;
-  * the tensors the model and the optimizer hold are re-pointed IN PLACE (`param.data = view`): the `nn.Parameter`
-    objects, and with them the optimizer's state dictionary, stay what they were -- no re-keying.
+  * the optimizer's moments ARE arena views; its parameters are new `nn.Parameter` objects wrapping the arena's views after
+    every prune / append, exactly as in the reference (re-pointing `param.data` to a view of another shape leaves autograd's
+    accumulator of the old shape behind: "invalid gradient ... expected shape"), and their state entries are re-keyed --
+    dictionary operations, no device work.
 When an append does not fit, the arena grows once (new buffer of twice the capacity, one copy).
 
 Results are bit-identical to `tensor[mask]` / `torch.cat` (the same kernels as densify.compact_rows / append_rows; tests).
