@@ -201,6 +201,7 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.focal_x = W / (2.0f * tan_fovx);
   a.gx = (W + TILE - 1) / TILE; a.gy = (H + TILE - 1) / TILE;
   a.skip_color = skip_color;
+  a.forward_only = (flags & GSR_FLAG_FORWARD_ONLY) ? 1 : 0;
   a.tile_bounds = (flags & GSR_FLAG_TILE_BOUNDS_ALPHA) ? 1 : 0;
   a.radii = radii;
   a.g = carve_geom(geom, P);

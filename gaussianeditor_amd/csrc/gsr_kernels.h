@@ -22,6 +22,7 @@ struct PreArgs {
   float tan_fovx, tan_fovy, focal_x, focal_y;
   int gx, gy;
   int skip_color;
+  int forward_only;  // GSR_FLAG_FORWARD_ONLY: Geom::dcol (read by the backward only) is not written
   int tile_bounds;  // 0: the reference's square of side 2 ceil(3 sigma_max); 1: its intersection with the alpha >= 1/255 box (gsr_set_option)
   int32_t* radii;
   Geom g;

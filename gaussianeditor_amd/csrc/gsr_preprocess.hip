@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
               }
             }
           }
-          {  // what the backward needs of the SH record (see Geom::dcol)
+          if (!a.forward_only) {  // what the backward needs of the SH record (see Geom::dcol)
             V3 ddx, ddy, ddz;
             sh_color_dir_derivatives(a.D, dir.x, dir.y, dir.z, sh, ddx, ddy, ddz);
             a.g.dcol[0][idx] = make_float4(ddx.x, ddx.y, ddx.z, 0.f);

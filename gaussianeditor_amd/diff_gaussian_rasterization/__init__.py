@@ -66,7 +66,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = raster_settings
         # behaviour flags (include/gsr.h: GSR_FLAG_*) are fixed per render: read once here, reused by the backward
         flags = _options.current_flags()
-        run = lambda fn: (lambda *a: fn(*a, flags=flags))  # noqa: E731
+        # a render no input of which requires a gradient (the viewer, torch.no_grad()) will never see a backward: the
+        # preprocessing then leaves out what only the backward reads (GSR_FLAG_FORWARD_ONLY)
+        fwd_flags = flags if any(ctx.needs_input_grad) else flags | _options.FLAG_FORWARD_ONLY
+        run = lambda fn: (lambda *a: fn(*a, flags=fwd_flags))  # noqa: E731
         # argument order of _C.rasterize_gaussians (rasterize_points.h:17-36)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,

@@ -15,6 +15,7 @@ FLAG_TILE_BOUNDS_ALPHA = 1
 FLAG_FAST_EXP = 2
 FLAG_ALL = 3             # the behaviour switches a caller may set
 FLAG_CLEAR_GRADS = 4     # (internal to the binding: the backward clears its accumulators itself; include/gsr.h)
+FLAG_FORWARD_ONLY = 8    # (internal to the binding: a render none of whose inputs requires a gradient)
 
 _default = 0
 _local = threading.local()

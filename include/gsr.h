@@ -87,6 +87,10 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *   GSR_FLAG_CLEAR_GRADS (read by gsr_blend_backward / gsr_backward) dL_dmeans2D, dL_dconic, dL_dopacity and dL_dcolors
  *       need not be zero on entry: the call clears them before it accumulates (inside the launch that builds the backward's
  *       work list, while that one workgroup runs: 14 us instead of 8 + 9 at 10^6 Gaussians, and one launch less);
+ *   GSR_FLAG_FORWARD_ONLY (read by gsr_preprocess) no gsr_preprocess_backward / gsr_backward will be called on the geometry
+ *       state this call leaves: the 48 bytes per Gaussian only the backward reads (the colour's derivative by the view
+ *       direction) are neither computed nor written.  A backward on such a state reads uninitialised memory: the Python
+ *       binding sets the flag exactly for renders none of whose inputs requires a gradient;
  *   GSR_FLAG_FAST_EXP    (read by the blend / trace entry points) exp(power) is evaluated with the hardware's
  *                        v_exp_f32 (2^x, 1 ulp) on power * log2(e) instead of the exactly specified polynomial
  *                        gsr_expf.  Colours / depths / gradients stay within the 1e-5 parity
@@ -97,7 +101,8 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
 #define GSR_FLAG_TILE_BOUNDS_ALPHA 1u
 #define GSR_FLAG_FAST_EXP 2u
 #define GSR_FLAG_CLEAR_GRADS 4u
-#define GSR_FLAG_ALL 7u
+#define GSR_FLAG_FORWARD_ONLY 8u
+#define GSR_FLAG_ALL 15u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);

@@ -90,9 +90,9 @@ def test_argument_validation_needs_no_gpu():
     assert not hasattr(L, "gsr_set_option")
     one = ctypes.c_void_p(256)
     assert L.gsr_preprocess(None, 10, 3, 16, one, one, 1.0, one, one, one, None, None, one, one, one, 64, 64, 1.0, 1.0,
-                            0, 0, 8, one, one, r) == -1
-    assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 8) == -1
-    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, one, one, one, 8) == -1
+                            0, 0, 16, one, one, r) == -1
+    assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 16) == -1
+    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, one, one, one, 16) == -1
     assert L.gsr_trace_weights(None, 10, 5, 64, 64, 1, one, one, one, one, one, one, 16) == -1
 
 
