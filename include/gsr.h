@@ -211,10 +211,11 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
  *   row_state[g] != 0  the rows of g may hold anything: they are written (values, or zeros) -- initialise to 1;
  *   row_state[g] == 0  the rows of g hold the zeros this function wrote before: if g's gradients are zero again, nothing
  *                      is written.
- * On return row_state[g] = 1 iff g's gradients may be non-zero.  After the call every row holds what
- * gsr_preprocess_backward(_rgb) would have written (a Gaussian with all-zero accumulator rows gets exact zeros; non-finite
- * parameters, for which 0 x inf would give NaN there, give zeros here).  Whoever else writes to these arrays must set
- * row_state to 1 for the rows it touched.  dL_dcov3D is written for every Gaussian. */
+ * On return row_state[g] = 1 iff g's accumulator rows (dL_dconic, dL_dmeans2D, and dL_dcolors when shs != NULL) had a
+ * non-zero entry.  After the call every row holds what gsr_preprocess_backward(_rgb) would have written, for finite
+ * parameters (all-zero accumulator rows give all-zero gradients; with a non-finite parameter that kernel computes 0 x inf
+ * on every call, this one only when it writes the row).  Whoever else writes to these arrays must set row_state to 1 for
+ * the rows it touched.  dL_dcov3D is written for every Gaussian. */
 int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                                  const float* scales, float scale_modifier, const float* rotations,
                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
