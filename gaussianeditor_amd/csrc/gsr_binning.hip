@@ -546,8 +546,15 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
   __shared__ uint32_t smem[1024 / 64 + 1];
   __shared__ uint32_t s_len[WORK_LDS_TILES];
   const bool cached = T <= WORK_LDS_TILES;
+  // Two independent halves: the prefix of the tile totals (ranges, tile_start: what the list-append kernel waits for) and the
+  // counting sort of the tiles by list length (the work list: what only the blend kernels read).  Launched as TWO blocks they
+  // run side by side, each through its own chain of dependent round trips (10.7 -> ~7 us on the path); as one block (legacy
+  // path: the ranges exist already) one after the other.
+  const bool split = gridDim.x == 2;
+  const bool do_prefix = tile_total != nullptr && (!split || blockIdx.x == 0);
+  const bool do_sort = !split || blockIdx.x == 1;
   for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
-  if (tile_total != nullptr) {
+  if (do_prefix) {
     constexpr int PER = 8;  // consecutive tiles per thread and round: two 16-byte loads, six 16-byte stores
     uint32_t carry = 0;
     for (int base = 0; base < T; base += 1024 * PER) {
@@ -592,15 +599,19 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
       carry += chunk;
     }
     if (threadIdx.x == 0) tile_start[T] = carry;
+  } else if (cached && tile_total != nullptr) {  // (the sorting block of a split launch)
+    for (int t = threadIdx.x; t < T; t += 1024) s_len[t] = tile_total[t];
   } else if (cached) {
     for (int t = threadIdx.x; t < T; t += 1024) {
       const uint2 r = ranges[t];
       s_len[t] = r.y - r.x;
     }
   }
+  if (!do_sort) return;
   __syncthreads();  // (s_len; without the cache the block reads its own `ranges` stores below)
   auto len_of = [&](int t) -> uint32_t {
     if (cached) return s_len[t];
+    if (tile_total != nullptr) return tile_total[t];
     const uint2 r = ranges[t];
     return r.y - r.x;
   };
@@ -1116,7 +1127,7 @@ static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, cons
   launch_chunks<false>(s, b, a);
   hipLaunchKernelGGL(group_colscan_kernel, dim3(b.groups), dim3(COLSCAN_WAVES * 64), 0, s, gx, gy, b.sgx,
                      (const uint32_t*)b.group_first, (const uint16_t*)b.chunk_cnt, b.chunk_pre, b.tile_total);
-  hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
+  hipLaunchKernelGGL(tile_worklist_kernel, dim3(2), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
                      im.queue_heads, im.work_est, (const uint32_t*)b.tile_total, b.tile_start);
   launch_chunks<true>(s, b, a);
 }
