@@ -48,7 +48,7 @@ __device__ __forceinline__ int f2i_sat(float v) {
 constexpr int RBITS = 8;
 constexpr int RBINS = 1 << RBITS;
 
-// `publish_dst` (first depth pass only): block 0 also reduces the per-block partials K1 left (num_rendered, range of the
+// `publish_dst` (first depth pass only): one EXTRA block reduces the per-block partials K1 left (num_rendered, range of the
 // depth keys) and writes the four words into the caller's pinned, device-mapped host buffer -- the readback of
 // gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before) and without a
 // header to clear in front of K1.
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(TH) sort_hist_kernel(const K* __restrict__ key
                                                                 uint32_t publish_count, uint32_t* __restrict__ publish_dst,
                                                                 uint32_t publish_seq) {
   __shared__ uint32_t h[RBINS];
-  if (publish_dst != nullptr && blockIdx.x == 0) {
+  if (publish_dst != nullptr && blockIdx.x == nblocks) {  // the EXTRA block of a publishing launch: it does nothing else
     __shared__ unsigned long long psum[TH / 64];
     __shared__ uint32_t pmax[TH / 64], pinv[TH / 64];
     __shared__ unsigned long long pgrp[TH / 64];
@@ -104,6 +104,7 @@ __global__ void __launch_bounds__(TH) sort_hist_kernel(const K* __restrict__ key
       // the host spins on this word (fine-grained pinned memory): no event, hence no barrier packet in the stream
       __hip_atomic_store(publish_dst + GEOM_HDR_FINAL, publish_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    return;
   }
   if (threadIdx.x < RBINS) h[threadIdx.x] = 0;
   __syncthreads();
@@ -273,8 +274,10 @@ static void radix_sort_pairs_th(hipStream_t s, K* const keys[2], uint32_t* const
   for (int p = p0; p < npass; ++p) {
     const uint32_t mask = (1u << digit_bits[p]) - 1u;
     const bool pub = p == p0 && publish_dst != nullptr;
-    hipLaunchKernelGGL((sort_hist_kernel<K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur], n, shift, mask, hist, nblocks,
-                       pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
+    // (a publishing launch has one block more: the reduction of K1's partials + the stores into the host's slot used to sit
+    // in front of block 0's histogram and made the first pass 2.5 us longer than the others)
+    hipLaunchKernelGGL((sort_hist_kernel<K, TH>), dim3(nblocks + (pub ? 1u : 0u)), dim3(TH), 0, s, (const K*)keys[cur], n, shift, mask,
+                       hist, nblocks, pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
       hipLaunchKernelGGL((sort_scatter_kernel<true, K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur],
@@ -437,8 +440,22 @@ __device__ __forceinline__ uint32_t group_local_rect(uint32_t x0, uint32_t y0, u
   const uint32_t ly0 = max(y0, by) - by, ly1 = min(y0 + h, by + GROUP_EDGE) - by;
   return lx0 | ((lx1 - 1u) << 3) | (ly0 << 6) | ((ly1 - 1u) << 9);
 }
+// Blocks behind the last Gaussian block (`nbg` on) write the padding value into every KEY slot of the radix pass's output side
+// (the scatter overwrites the real ones: what remains are the padding slots between the segments and behind the last one; a real
+// key never equals GROUP_PAD).  It is independent of everything this kernel does and used to sit in front of the histogram
+// kernel's own work (+1.5 us there).
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx, const Geom g, uint32_t* __restrict__ gkeys,
-                                                                 uint32_t* __restrict__ vals) {
+                                                                 uint32_t* __restrict__ vals, int nbg,
+                                                                 uint32_t* __restrict__ fill_dst, int64_t fill_n) {
+  if ((int)blockIdx.x >= nbg) {
+    const int64_t nb = (int64_t)gridDim.x - nbg, b = (int64_t)blockIdx.x - nbg;
+    const int64_t n4 = fill_n / 4;  // (the key arrays are 256-byte aligned)
+    uint4* const q = reinterpret_cast<uint4*>(fill_dst);
+    for (int64_t k = b * GAUSS_BLOCK + threadIdx.x; k < n4; k += nb * GAUSS_BLOCK) q[k] = make_uint4(GROUP_PAD, GROUP_PAD, GROUP_PAD, GROUP_PAD);
+    if (b == 0)
+      for (int64_t k = 4 * n4 + threadIdx.x; k < fill_n; k += GAUSS_BLOCK) fill_dst[k] = GROUP_PAD;
+    return;
+  }
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
   __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_xy[GAUSS_BLOCK], s_wh[GAUSS_BLOCK];
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
@@ -670,10 +687,8 @@ __global__ void __launch_bounds__(TH) group_hist_kernel(const uint32_t* __restri
   constexpr int NB = 1 << BITS;
   __shared__ uint32_t h[NB];
   for (int i = threadIdx.x; i < NB; i += TH) h[i] = 0;
-  {
-    const int64_t per = (fill_n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(lo + per, fill_n);
-    for (int64_t i = lo + threadIdx.x; i < hi; i += TH) fill_dst[i] = GROUP_PAD;
-  }
+  (void)fill_dst;  // (the padding of the sorted side is written by extra blocks of emit_groups_kernel since round 3)
+  (void)fill_n;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
   uint32_t kv[(SORT_KPB / TH)];
@@ -1101,7 +1116,9 @@ template <int BITS>
 static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, const Geom& g, const Binning& b, const Image& im) {
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   const int64_t padded = b.chunks * (int64_t)b.chunk;
-  hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0]);
+  const int fill_blocks = 512;  // (two per CU: 5 MB of padding at 1 M Gaussians)
+  hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg + fill_blocks), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0], nbg,
+                     b.gkey[1], padded);
   const bool wide = b.sort_blocks <= SORT_WIDE_MAX_BLOCKS;  // few blocks: 1024 threads per block (see radix_sort_pairs)
   if (wide)
     hipLaunchKernelGGL((group_hist_kernel<BITS, 1024>), dim3(b.sort_blocks), dim3(1024), 0, s, (const uint32_t*)b.gkey[0], b.G,
