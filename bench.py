@@ -267,7 +267,7 @@ def main():
         radii_t = torch.empty(P, dtype=torch.int32, device=dev)
         color = torch.empty((3, H, W), device=dev)
         depth = torch.empty((1, H, W), device=dev)
-        z = torch.zeros(P * 11, device=dev)
+        z = torch.empty(P * 11, device=dev)  # (cleared by the blend backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does)
         d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
         d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
         d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
@@ -286,7 +286,7 @@ def main():
         _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
         ev[3].record(s)
         _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
-                                                  p(d_con), p(d_op), p(d_col), flags))
+                                                  p(d_con), p(d_op), p(d_col), flags | 4))
         ev[4].record(s)
         _native.check("pbw", L.gsr_preprocess_backward(sp, P, ply_degree, M, W, H, p(params["xyz"]), p(params["features"]),
                                                        p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
