@@ -226,3 +226,32 @@ def test_bench_line_carries_the_contract_fields_and_the_gradient_row_mode():
             assert key in line, key
         assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0 and word in line["config"]["grad_rows"]
         assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def test_bench_two_ranks_share_one_gpu_and_take_the_exchange_path():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU:
+    `GSR_BENCH_SHARED_GPU=1` puts both ranks on GPU 0 with the gloo backend, so every line of the N > 1 bench path runs --
+    views sharded by rank, the touched-rows exchange, max-over-ranks timing, rank 0 printing the one line.  (The numbers of
+    such a run mean nothing; RCCL itself is covered at world size 1 and, where two GPUs exist, 2.)"""
+    import json
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSR_BENCH_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gaussians",
+                        "50000", "--width", "640", "--height", "368", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["views_per_step"] == 2 and cfg["parallelism"] == "dp2-views" and cfg["grad_exchange"] == "rgb"
+    assert cfg["grad_exchange_route"] in ("rows", "dense")
+    if cfg["grad_exchange_route"] == "rows":
+        assert len(cfg["grad_exchange_rows_per_view"]) == 2 and all(0 < c <= 50000 for c in cfg["grad_exchange_rows_per_view"])
