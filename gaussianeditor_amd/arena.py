@@ -17,7 +17,13 @@ buffer with head-room:
     every prune / append, exactly as in the reference (re-pointing `param.data` to a view of another shape leaves autograd's
     accumulator of the old shape behind: "invalid gradient ... expected shape"), and their state entries are re-keyed --
     dictionary operations, no device work.
-When an append does not fit, the arena grows once (new buffer of twice the capacity, one copy).
+When an append does not fit, the arena grows geometrically (new buffer of `growth` = 1.5 times the capacity, one copy).
+
+Footprint: two halves of `capacity` rows each, i.e. 2 x headroom x the live bytes (3 x at the default head-room of 1.5;
+~12 GB for 6 M SH3 Gaussians with their Adam moments), and while a grown buffer is being filled the old one is still alive:
+the peak at that moment is (2 + 2 x growth) x capacity rows.  That is the moment memory is tightest, so an allocation
+failure there is reported as such (RuntimeError naming the sizes) instead of surfacing as a bare HIP out-of-memory error;
+`OptimizerArena(..., headroom=, growth=)` / `RowArena(..., headroom=, growth=)` choose the trade.
 
 Results are bit-identical to `tensor[mask]` / `torch.cat` (the same kernels as densify.compact_rows / append_rows; tests).
 No CPU fallback.
@@ -42,7 +48,11 @@ class RowArena:
     """`tensors`: name -> tensor with leading dimension P (same P, same ROCm device, any dtype / trailing shape).  Their
     contents are copied into the arena once; `arena[name]` is from then on THE tensor (a (P, ...) view)."""
 
-    def __init__(self, tensors: Dict[str, torch.Tensor], capacity: Optional[int] = None, headroom: float = 1.5):
+    def __init__(self, tensors: Dict[str, torch.Tensor], capacity: Optional[int] = None, headroom: float = 1.5,
+                 growth: float = 1.5):
+        if not (headroom >= 1.0 and growth > 1.0):
+            raise ValueError("RowArena: need headroom >= 1 and growth > 1")
+        self.growth = float(growth)
         if not tensors:
             raise ValueError("RowArena: no tensors")
         first = next(iter(tensors.values()))
@@ -78,7 +88,13 @@ class RowArena:
             self._offsets[k] = off
             off += _align(self.capacity * self.row_bytes[k])
         self._half_bytes = off
-        self._buf = torch.empty(2 * off, dtype=torch.uint8, device=self.device)
+        try:
+            self._buf = torch.empty(2 * off, dtype=torch.uint8, device=self.device)
+        except torch.OutOfMemoryError as ex:
+            held = 0 if old is None else sum(int(t.numel()) * t.element_size() for t in old.values())
+            raise RuntimeError(f"RowArena: cannot allocate {2 * off / 2**30:.2f} GiB for {self.capacity} rows in two halves"
+                               f" (the {held / 2**30:.2f} GiB of live rows stay allocated until they are copied); construct "
+                               "the arena with a larger capacity up front, or with smaller headroom / growth") from ex
         self.allocations += 1
         self._live = 0
         if old is not None:
@@ -141,7 +157,7 @@ class RowArena:
         if n == 0:
             return self.P
         if self.P + n > self.capacity:
-            self._reserve(max(2 * self.capacity, self.P + n + 1024))  # (rare: one copy of everything)
+            self._reserve(max(int(self.growth * self.capacity), self.P + n + 1024))  # (rare: one copy of everything)
         L = _native.lib()
         keep_alive = []
         with torch.cuda.device(self.device):
@@ -170,7 +186,8 @@ class OptimizerArena:
     views (returned as {group name: Parameter}, like the reference's `_prune_optimizer` / `cat_tensors_to_optimizer`), the
     moments and `self.extra[...]` are the arena's new views."""
 
-    def __init__(self, optimizer: torch.optim.Optimizer, extra: Optional[Dict[str, torch.Tensor]] = None, headroom: float = 1.5):
+    def __init__(self, optimizer: torch.optim.Optimizer, extra: Optional[Dict[str, torch.Tensor]] = None, headroom: float = 1.5,
+                 growth: float = 1.5):
         self.optimizer = optimizer
         self.extra_names = list(extra or {})
         tensors: Dict[str, torch.Tensor] = {}
@@ -190,7 +207,7 @@ class OptimizerArena:
             tensors[name + ".exp_avg_sq"] = st["exp_avg_sq"]
         for k, t in (extra or {}).items():
             tensors["extra." + k] = t
-        self.arena = RowArena(tensors, headroom=headroom)
+        self.arena = RowArena(tensors, headroom=headroom, growth=growth)
         self.extra: Dict[str, torch.Tensor] = {}
         self._repoint()
 

@@ -53,25 +53,39 @@ constexpr int RBINS = 1 << RBITS;
 // gsr_preprocess without a copy command of its own (a 4 us blit kernel plus a 6 us bubble behind it before) and without a
 // header to clear in front of K1.
 // TH threads per block (256, or 1024 for sorts of few blocks: see radix_sort_pairs), SORT_KPB / TH keys per thread.
-template <class K, int TH>
+// WEIGHTED (the LAST depth pass of the grouped path): next to the digit counts the block leaves, in rows RBINS .. 2 RBINS - 1
+// of `hist`, the sum of the group counts of its keys per digit (rect32: the packed tile rectangles in the order of `keys`):
+// scanned by the same scan launch, they give the last scatter kernel every Gaussian's position in the emission order.
+template <class K, int TH, bool WEIGHTED = false>
 __global__ void __launch_bounds__(TH) sort_hist_kernel(const K* __restrict__ keys, int64_t n, int shift,
                                                                 uint32_t mask, uint32_t* __restrict__ hist,
                                                                 uint32_t nblocks, const uint4* __restrict__ publish_src,
                                                                 uint32_t publish_count, uint32_t* __restrict__ publish_dst,
-                                                                uint32_t publish_seq) {
+                                                                uint32_t publish_seq, const uint32_t* __restrict__ rect32) {
   __shared__ uint32_t h[RBINS];
+  __shared__ uint32_t hw[WEIGHTED ? RBINS : 1];
   if (publish_dst != nullptr && blockIdx.x == nblocks) {  // the EXTRA block of a publishing launch: it does nothing else
     __shared__ unsigned long long psum[TH / 64];
     __shared__ uint32_t pmax[TH / 64], pinv[TH / 64];
     __shared__ unsigned long long pgrp[TH / 64];
     unsigned long long sum = 0, gsum = 0;
     uint32_t kmax = 0, kinv = 0;
-    for (uint32_t i = threadIdx.x; i < publish_count; i += TH) {
-      const uint4 v = publish_src[i];
-      sum += v.x;
-      gsum += v.w;
-      kmax = max(kmax, v.y);
-      kinv = max(kinv, v.z);
+    // PUB_UNROLL partials per thread and round, their loads issued together (index clamped): at 6 M Gaussians a 256-thread
+    // block walks 23 438 partials, and one dependent load per round made this block 40 us -- the whole launch waited for it
+    constexpr int PUB_UNROLL = 8;
+    for (uint32_t base = threadIdx.x; base < publish_count; base += TH * PUB_UNROLL) {
+      uint4 v[PUB_UNROLL];
+#pragma unroll
+      for (int u = 0; u < PUB_UNROLL; ++u) v[u] = publish_src[min(base + (uint32_t)u * TH, publish_count - 1u)];
+#pragma unroll
+      for (int u = 0; u < PUB_UNROLL; ++u) {
+        if (base + (uint32_t)u * TH < publish_count) {
+          sum += v[u].x;
+          gsum += v[u].w;
+          kmax = max(kmax, v[u].y);
+          kinv = max(kinv, v[u].z);
+        }
+      }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -106,24 +120,38 @@ __global__ void __launch_bounds__(TH) sort_hist_kernel(const K* __restrict__ key
     }
     return;
   }
-  if (threadIdx.x < RBINS) h[threadIdx.x] = 0;
+  if (threadIdx.x < RBINS) {
+    h[threadIdx.x] = 0;
+    if (WEIGHTED) hw[threadIdx.x] = 0;
+  }
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * SORT_KPB;
   // all loads of a thread are issued back to back (unconditional, index clamped): the kernel is bound by memory latency,
   // not by bandwidth or the LDS atomics
-  uint32_t kv[(SORT_KPB / TH)];
+  uint32_t kv[(SORT_KPB / TH)], rv[WEIGHTED ? (SORT_KPB / TH) : 1];
 #pragma unroll
   for (int i = 0; i < (SORT_KPB / TH); ++i) {
     const int64_t k = base + (int64_t)i * TH + threadIdx.x;
     kv[i] = (uint32_t)keys[k < n ? k : n - 1];
+    if (WEIGHTED) rv[i] = rect32[k < n ? k : n - 1];
   }
 #pragma unroll
   for (int i = 0; i < (SORT_KPB / TH); ++i) {
     const int64_t k = base + (int64_t)i * TH + threadIdx.x;
-    if (k < n) atomicAdd(&h[(kv[i] >> shift) & mask], 1u);
+    if (k < n) {
+      const uint32_t d = (kv[i] >> shift) & mask;
+      atomicAdd(&h[d], 1u);
+      if (WEIGHTED) {
+        const uint32_t g = rect32_groups(rv[i]);
+        if (g != 0u) atomicAdd(&hw[d], g);
+      }
+    }
   }
   __syncthreads();
-  if (threadIdx.x < RBINS) hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+  if (threadIdx.x < RBINS) {
+    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (WEIGHTED) hist[(size_t)(RBINS + threadIdx.x) * nblocks + blockIdx.x] = hw[threadIdx.x];
+  }
 }
 
 // One block per bin; exclusive scan of that bin's nblocks counts in place.  Every thread takes SCAN_PER consecutive counts
@@ -277,7 +305,8 @@ static void radix_sort_pairs_th(hipStream_t s, K* const keys[2], uint32_t* const
     // (a publishing launch has one block more: the reduction of K1's partials + the stores into the host's slot used to sit
     // in front of block 0's histogram and made the first pass 2.5 us longer than the others)
     hipLaunchKernelGGL((sort_hist_kernel<K, TH>), dim3(nblocks + (pub ? 1u : 0u)), dim3(TH), 0, s, (const K*)keys[cur], n, shift, mask,
-                       hist, nblocks, pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq);
+                       hist, nblocks, pub ? publish_src : nullptr, publish_count, pub ? publish_dst : nullptr, publish_seq,
+                       (const uint32_t*)nullptr);
     hipLaunchKernelGGL(sort_scan_kernel, dim3(RBINS), dim3(SORT_THREADS), 0, s, hist, bin_total, nblocks);
     if (p == 0 && iota_first)
       hipLaunchKernelGGL((sort_scatter_kernel<true, K, TH>), dim3(nblocks), dim3(TH), 0, s, (const K*)keys[cur],
@@ -303,6 +332,214 @@ static void radix_sort_pairs(hipStream_t s, K* const keys[2], uint32_t* const va
   else
     radix_sort_pairs_th<K, SORT_THREADS>(s, keys, vals, n, npass, digit_bits, hist, bin_total, iota_first, p0, publish_src,
                                          publish_count, publish_dst, publish_seq);
+}
+
+// ----------------------------------------------------------------------------------
+// Grouped path (round 4): the depth sort carries the tile rectangle as a second payload, and its LAST pass leaves
+// everything the emission needs in depth order -- nothing is gathered or scanned afterwards (rounds 1-3: a gather kernel
+// of the 8-byte rectangles, 14 us at 1 M Gaussians and 116 us at 6 M, + a block-sum scan).
+//   LAST = false: sort_scatter_kernel + the payload (IOTA: packed from Geom::rect, read in index order);
+//   LAST = true:  additionally every Gaussian's position in the emission order, i.e. the exclusive prefix of the group
+//                 counts in depth order = (groups of all smaller digits) + (groups of this digit in earlier blocks: both
+//                 from the WEIGHTED histogram rows, scanned) + (groups of this digit ahead of it inside the block: a block
+//                 scan over the LDS-sorted slots); it goes where the sorted keys would (nobody reads them), and the block
+//                 stamps the header with the side that holds the order.
+// ----------------------------------------------------------------------------------
+template <bool LAST, bool IOTA, int TH>
+__global__ void __launch_bounds__(TH) depth_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ vals_in,
+                                                          const uint32_t* __restrict__ rect_in,
+                                                          const uint2* __restrict__ rect8,
+                                                          uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                          uint32_t* __restrict__ rect_out, int64_t n, int shift, uint32_t mask,
+                                                          const uint32_t* __restrict__ hist,
+                                                          const uint32_t* __restrict__ bin_total, uint32_t nblocks,
+                                                          uint32_t* __restrict__ hdr, uint32_t final_buf) {
+  constexpr int NW = TH / 64, ITEMS = SORT_KPB / TH;
+  __shared__ uint32_t cnt[NW][RBINS];
+  __shared__ uint32_t gbase[RBINS], lexcl[RBINS], wgbase[LAST ? RBINS : 1];
+  __shared__ uint32_t smem[TH / 64 + 1];
+  __shared__ uint32_t skey[LAST ? 4 : SORT_KPB];  // LAST: the sorted keys are not written, only their digit is needed (sdig)
+  __shared__ uint8_t sdig[LAST ? SORT_KPB : 4];   // (12 KB less: three blocks of the 256-thread form per CU instead of two)
+  __shared__ uint32_t sval[SORT_KPB];
+  __shared__ __align__(16) uint32_t srect[SORT_KPB];
+  __shared__ __align__(16) uint32_t spre[LAST ? SORT_KPB : 4];  // exclusive prefix of the group counts over the sorted slots
+  const int w = (int)(threadIdx.x >> 6), l = lane_id();
+  const int64_t bbase = (int64_t)blockIdx.x * SORT_KPB;
+  const int64_t wbase = bbase + (int64_t)w * (ITEMS * 64);
+  uint32_t key[ITEMS], val[ITEMS], rc[ITEMS];
+  uint16_t rank[ITEMS];
+  const uint64_t lt_mask = (1ull << l) - 1ull;
+  if (LAST && blockIdx.x == 0 && threadIdx.x == 0) hdr[GEOM_HDR_FINAL] = final_buf;  // for the emit kernel (gsr_bin)
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    const int64_t kc = k < n ? k : n - 1;  // unconditional loads (clamped), validity handled below
+    key[i] = keys_in[kc];
+    if (!IOTA) val[i] = vals_in[kc];
+    if (IOTA) {
+      // ONE 8-byte load per rectangle, consumed after all loads of the thread have been issued (a first version read
+      // .y, waited, and read .x only for a non-empty rectangle: ITEMS dependent round trips, 87 us at 6 M Gaussians)
+      const unsigned long long r8 = reinterpret_cast<const unsigned long long*>(rect8)[kc];
+      rc[i] = (uint32_t)r8;
+      val[i] = (uint32_t)(r8 >> 32);  // (parked: val = kc is recomputed below)
+    } else {
+      rc[i] = rect_in[kc];
+    }
+  }
+  if (IOTA) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int64_t k = wbase + (int64_t)i * 64 + l;
+      rc[i] = pack_rect32(rc[i], val[i]);
+      val[i] = (uint32_t)(k < n ? k : n - 1);
+    }
+  }
+  const bool owns_bin = threadIdx.x < RBINS;  // thread d < 256 owns digit d
+  const uint32_t my_hist = owns_bin ? hist[(size_t)threadIdx.x * nblocks + blockIdx.x] : 0u;
+  const uint32_t my_whist = (LAST && owns_bin) ? hist[(size_t)(RBINS + threadIdx.x) * nblocks + blockIdx.x] : 0u;
+  const uint32_t my_total = owns_bin ? bin_total[threadIdx.x] : 0u;
+  const uint32_t my_wtotal = (LAST && owns_bin) ? bin_total[RBINS + threadIdx.x] : 0u;
+  for (int i = threadIdx.x; i < NW * RBINS; i += TH) (&cnt[0][0])[i] = 0;
+  {
+    uint32_t tot;
+    const uint32_t run = block_excl_scan_u32<TH>(my_total, &tot, smem);
+    if (owns_bin) gbase[threadIdx.x] = run + my_hist;
+    if (LAST) {
+      const uint32_t wrun = block_excl_scan_u32<TH>(my_wtotal, &tot, smem);
+      if (owns_bin) wgbase[threadIdx.x] = wrun + my_whist;
+    }
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    const bool valid = k < n;
+    const uint32_t d = (key[i] >> shift) & mask;
+    uint64_t m = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < RBITS; ++b) {
+      const uint64_t bb = __ballot((d >> b) & 1u);
+      m &= ((d >> b) & 1u) ? bb : ~bb;
+    }
+    const uint32_t before = (uint32_t)__popcll(m & lt_mask);
+    uint32_t old = 0;
+    if (valid) old = cnt[w][d];
+    // all reads of this iteration precede the leader's write (one wave, program order)
+    if (valid && before == 0) cnt[w][d] = old + (uint32_t)__popcll(m);
+    rank[i] = (uint16_t)(old + before);
+  }
+  __syncthreads();
+  {
+    uint32_t run = 0;
+    if (owns_bin) {
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        const uint32_t c = cnt[i][threadIdx.x];
+        cnt[i][threadIdx.x] = run;
+        run += c;
+      }
+    }
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan_u32<TH>(run, &tot, smem);
+    if (owns_bin) lexcl[threadIdx.x] = ex;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int64_t k = wbase + (int64_t)i * 64 + l;
+    if (k < n) {
+      const uint32_t d = (key[i] >> shift) & mask;
+      const uint32_t lp = lexcl[d] + cnt[w][d] + rank[i];
+      if (LAST) sdig[lp] = (uint8_t)d;
+      else skey[lp] = key[i];
+      sval[lp] = val[i];
+      srect[lp] = rc[i];
+    }
+  }
+  __syncthreads();
+  const int nvalid = (int)min((int64_t)SORT_KPB, n - bbase);
+  if (LAST) {
+    // exclusive prefix of the group counts over the block-sorted slots: thread t takes slots [t ITEMS, (t + 1) ITEMS)
+    uint32_t g[ITEMS], sum = 0;
+    const int j0 = (int)threadIdx.x * ITEMS;
+#pragma unroll
+    for (int q = 0; q < ITEMS / 4; ++q) {
+      const uint4 r = reinterpret_cast<const uint4*>(srect + j0)[q];
+      g[4 * q] = r.x; g[4 * q + 1] = r.y; g[4 * q + 2] = r.z; g[4 * q + 3] = r.w;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      g[i] = j0 + i < nvalid ? rect32_groups(g[i]) : 0u;  // (slots behind the last key hold garbage)
+      sum += g[i];
+    }
+    uint32_t tot;
+    uint32_t run = block_excl_scan_u32<TH>(sum, &tot, smem);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      spre[j0 + i] = run;
+      run += g[i];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int j = i * TH + (int)threadIdx.x;
+    if (j < nvalid) {
+      const uint32_t kk = LAST ? 0u : skey[j];
+      const uint32_t d = LAST ? (uint32_t)sdig[j] : (kk >> shift) & mask;
+      const uint32_t first = lexcl[d];  // the digit's first slot in the block-sorted order (a digit that occurs: first <= j)
+      const uint32_t pos = gbase[d] + ((uint32_t)j - first);
+      keys_out[pos] = LAST ? wgbase[d] + (spre[j] - spre[first]) : kk;
+      vals_out[pos] = sval[j];
+      rect_out[pos] = srect[j];
+    }
+  }
+}
+
+// The depth sort of the grouped path: passes [p0, p1) (pass p reads side p & 1); `last`: pass p1 - 1 is the final one.
+template <int TH>
+static void depth_sort_grouped_th(hipStream_t s, int P, const Geom& g, int p0, int p1, bool last, uint32_t* publish_dst,
+                                  uint32_t publish_seq) {
+  const int64_t n = P;
+  const uint32_t nblocks = (uint32_t)((n + SORT_KPB - 1) / SORT_KPB);
+  const uint32_t npart = (uint32_t)((P + GAUSS_BLOCK - 1) / GAUSS_BLOCK);
+  uint32_t* const hdr = reinterpret_cast<uint32_t*>(g.total);
+  for (int p = p0; p < p1; ++p) {
+    const int cur = p & 1, shift = 8 * p;
+    const bool pub = p == p0 && publish_dst != nullptr, fin = last && p == p1 - 1;
+    // (the histogram kernel always runs 1024 threads wide: it holds 1 KB of LDS, and its extra publishing block walks
+    //  ceil(P / 256) partials -- 23 438 at 6 M Gaussians, 40 us with 256 threads and one load in flight per thread)
+    const dim3 gh(nblocks + (pub ? 1u : 0u)), gs(nblocks), bt(TH), bh(1024);
+    if (fin)
+      hipLaunchKernelGGL((sort_hist_kernel<uint32_t, 1024, true>), gh, bh, 0, s, (const uint32_t*)g.dkey[cur], n, shift, 255u, g.ghist,
+                         nblocks, pub ? g.k1_partials : nullptr, npart, pub ? publish_dst : nullptr, publish_seq,
+                         (const uint32_t*)g.drect[cur]);
+    else
+      hipLaunchKernelGGL((sort_hist_kernel<uint32_t, 1024, false>), gh, bh, 0, s, (const uint32_t*)g.dkey[cur], n, shift, 255u, g.ghist,
+                         nblocks, pub ? g.k1_partials : nullptr, npart, pub ? publish_dst : nullptr, publish_seq,
+                         (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(fin ? 2 * RBINS : RBINS), dim3(SORT_THREADS), 0, s, g.ghist, g.gbin_total, nblocks);
+#define GSR_DEPTH_SCATTER(LASTP, IOTAP)                                                                                          \
+  hipLaunchKernelGGL((depth_scatter_kernel<LASTP, IOTAP, TH>), gs, bt, 0, s, (const uint32_t*)g.dkey[cur],                       \
+                     (const uint32_t*)g.dval[cur], (const uint32_t*)g.drect[cur], (const uint2*)g.rect, g.dkey[cur ^ 1],         \
+                     g.dval[cur ^ 1], g.drect[cur ^ 1], n, shift, 255u, (const uint32_t*)g.ghist, (const uint32_t*)g.gbin_total, \
+                     nblocks, hdr, (uint32_t)(cur ^ 1))
+    if (fin && p == 0) GSR_DEPTH_SCATTER(true, true);
+    else if (fin) GSR_DEPTH_SCATTER(true, false);
+    else if (p == 0) GSR_DEPTH_SCATTER(false, true);
+    else GSR_DEPTH_SCATTER(false, false);
+#undef GSR_DEPTH_SCATTER
+  }
+}
+hipError_t launch_depth_passes_grouped(hipStream_t s, int P, const Geom& g, int p0, int p1, bool last, uint32_t* publish_dst,
+                                       uint32_t publish_seq) {
+  if ((uint32_t)(((int64_t)P + SORT_KPB - 1) / SORT_KPB) <= SORT_WIDE_MAX_BLOCKS)
+    depth_sort_grouped_th<1024>(s, P, g, p0, p1, last, publish_dst, publish_seq);
+  else
+    depth_sort_grouped_th<SORT_THREADS>(s, P, g, p0, p1, last, publish_dst, publish_seq);
+  return hipGetLastError();
 }
 
 // ----------------------------------------------------------------------------------
@@ -456,25 +693,24 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx
       for (int64_t k = 4 * n4 + threadIdx.x; k < fill_n; k += GAUSS_BLOCK) fill_dst[k] = GROUP_PAD;
     return;
   }
-  __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1];
-  __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_xy[GAUSS_BLOCK], s_wh[GAUSS_BLOCK];
+  __shared__ uint32_t s_off[GAUSS_BLOCK + 1], s_idx[GAUSS_BLOCK], s_rect[GAUSS_BLOCK];
+  __shared__ uint32_t s_first, s_end;
   const int i = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   const uint32_t fin = reinterpret_cast<const uint32_t*>(g.total)[GEOM_HDR_FINAL];  // side holding the depth order
+  // Everything in depth order, left by the last pass of the depth sort (depth_scatter_kernel<true>): the Gaussian, its
+  // packed tile rectangle and its first slot in the emission order -- three coalesced loads, no gather, no scan.
   const uint32_t idx = i < P ? g.dval[fin][i] : 0u;
-  // the tile rectangle of the Gaussian in depth order, left there by sorted_block_sums_kernel: no gather in this kernel
-  const uint32_t wh = i < P ? g.dkey[fin ^ 1u][i] : 0u;
-  const uint32_t xy = i < P ? g.dval[fin ^ 1u][i] : 0u;
-  const uint32_t w = wh & 0xffffu, h = wh >> 16, x0 = xy & 0xffffu, y0 = xy >> 16;
-  uint32_t n = 0;
-  if (w * h != 0u)
-    n = (((x0 + w - 1u) >> GROUP_SHIFT) - (x0 >> GROUP_SHIFT) + 1u) * (((y0 + h - 1u) >> GROUP_SHIFT) - (y0 >> GROUP_SHIFT) + 1u);
-  uint32_t total;
-  const uint32_t boff = g.block_offs[blockIdx.x];
-  const uint32_t off = block_excl_scan_u32<GAUSS_BLOCK>(n, &total, smem);
-  s_off[threadIdx.x] = off;
+  const uint32_t r32 = i < P ? g.drect[fin][i] : RECT32_NONE;
+  const uint32_t pre = i < P ? g.dkey[fin][i] : 0u;
+  const uint32_t n = rect32_groups(r32);
+  const int last = min(P - 1 - (int)blockIdx.x * GAUSS_BLOCK, GAUSS_BLOCK - 1);
+  if (threadIdx.x == 0) s_first = pre;
+  if ((int)threadIdx.x == last) s_end = pre + n;
+  __syncthreads();
+  const uint32_t boff = s_first, total = s_end - boff;
+  s_off[threadIdx.x] = i < P ? pre - boff : total;
   s_idx[threadIdx.x] = idx;
-  s_xy[threadIdx.x] = xy;
-  s_wh[threadIdx.x] = wh;
+  s_rect[threadIdx.x] = r32;
   if (threadIdx.x == 0) s_off[GAUSS_BLOCK] = total;
   __syncthreads();
   for (uint32_t s = threadIdx.x; s < total; s += GAUSS_BLOCK) {
@@ -485,8 +721,8 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx
       const uint32_t mid = (lo + hi) >> 1;
       if (s_off[mid] <= s) lo = mid; else hi = mid;
     }
-    const uint32_t k = s - s_off[lo], jxy = s_xy[lo], jwh = s_wh[lo];
-    const uint32_t jx = jxy & 0xffffu, jy = jxy >> 16, jw = jwh & 0xffffu, jh = jwh >> 16;
+    const uint32_t k = s - s_off[lo], jr = s_rect[lo];
+    const uint32_t jx = jr & 0xffu, jy = (jr >> 8) & 0xffu, jw = ((jr >> 16) & 0xffu) + 1u, jh = (jr >> 24) + 1u;
     const uint32_t g0x = jx >> GROUP_SHIFT, nsx = ((jx + jw - 1u) >> GROUP_SHIFT) - g0x + 1u;
     // row = k / nsx without an integer division (k, nsx < 2^24), one correction step each way
     uint32_t row = (uint32_t)((float)k * __builtin_amdgcn_rcpf((float)nsx));

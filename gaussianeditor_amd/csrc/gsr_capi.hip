@@ -106,7 +106,9 @@ inline int bin_legacy(int W, int H) {
     const char* e = getenv("GSR_BIN_LEGACY");
     return e != nullptr && e[0] == '1';
   }();
-  return (forced || group_count(W, H) > GROUP_MAX) ? 1 : 0;
+  // (the grouped path packs a tile rectangle into 32 bits: images of up to RECT32_EDGE tiles per side)
+  const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  return (forced || group_count(W, H) > GROUP_MAX || gx > RECT32_EDGE || gy > RECT32_EDGE) ? 1 : 0;
 }
 // What the blend / export entry points need of the binning scratch sits in front of everything sized by the number of
 // group instances, so they carve with G = 0.
@@ -214,7 +216,9 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   HostSlot* slot = host_slot(s, &slot_err);
   if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT /* device ordinal beyond the pool */ : hip_fail(slot_err);
   const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
-  GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
+  const int legacy = bin_legacy(W, H);
+  if (legacy) GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
+  else GSR_HIP(launch_depth_passes_grouped(s, P, a.g, 0, 2, false, slot->dev_words, seq));
   // Poll the generation word (an event would put a barrier packet into the stream -- a 6 us bubble -- and sleeping on
   // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED in time: after 5 ms (a long
   // queue of earlier work on the stream, or a failed launch) the thread stops burning a core and blocks in
@@ -244,10 +248,17 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   const uint32_t kmin = ~kinv;
   int nbits = 0;
   for (uint32_t d = total ? (kmax ^ kmin) : 0u; d; d >>= 1) ++nbits;
-  const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
-  if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
-  const int legacy = bin_legacy(W, H);
-  GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx, legacy ? 0 : (a.gx + GROUP_EDGE - 1) >> GROUP_SHIFT));
+  if (legacy) {
+    const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
+    if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
+    GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx, 0));
+  } else {
+    // The LAST pass also leaves what the emission of gsr_bin needs (depth_scatter_kernel<true>), and which pass that is
+    // is only known now: at least one pass follows the two that ran under the wait (a key range of <= 16 bits: its
+    // digit is the same for every key -- a stable pass that moves nothing).
+    const int passes = nbits <= 24 ? 3 : 4;
+    GSR_HIP(launch_depth_passes_grouped(s, P, a.g, 2, passes, true));
+  }
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
   counts_host[0] = (int64_t)total;
   counts_host[1] = legacy ? 0 : (int64_t)((uint64_t)w[GEOM_HDR_GROUPS] | ((uint64_t)w[GEOM_HDR_GROUPS + 1] << 32));

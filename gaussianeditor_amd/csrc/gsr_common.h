@@ -51,6 +51,10 @@ struct Geom {
   // depth ordering of the Gaussians (stable LSD radix sort of (depth bits, index); culled Gaussians last)
   uint32_t* dkey[2];     // (P)     ping-pong depth keys
   uint32_t* dval[2];     // (P)     ping-pong Gaussian indices; dval[header FINAL] holds the final order
+  // grouped path (round 4): the tile rectangle travels with the sort as a second 32-bit payload (pack_rect32), so that
+  // nothing is gathered afterwards; after the LAST pass drect[FINAL] holds the rectangles in depth order and dkey[FINAL]
+  // -- whose sorted keys nobody reads -- the exclusive prefix of the Gaussians' group counts in depth order
+  uint32_t* drect[2];    // (P)     ping-pong packed tile rectangles
   uint32_t* ghist;       // (256 * ceil(P/4096)) per-block digit counts of the depth sort
   uint32_t* gbin_total;  // (512)
   size_t bytes;
@@ -85,6 +89,7 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   const size_t nsb = ((size_t)P + 4096 - 1) / 4096;
   for (int i = 0; i < 2; ++i) { g.dkey[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)P); }
   for (int i = 0; i < 2; ++i) { g.dval[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)P); }
+  for (int i = 0; i < 2; ++i) { g.drect[i] = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * (size_t)P); }
   g.ghist = (uint32_t*)(p + off);      off += align_up(sizeof(uint32_t) * 512 * nsb);
   g.gbin_total = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * 512);
   g.bytes = off;
@@ -192,6 +197,22 @@ __host__ __device__ inline int sort_key_bits(int W, int H) {
 __host__ __device__ inline int64_t group_count(int W, int H) {
   const int64_t gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return ((gx + GROUP_EDGE - 1) >> GROUP_SHIFT) * ((gy + GROUP_EDGE - 1) >> GROUP_SHIFT);
+}
+// A tile rectangle in 32 bits, for images of up to RECT32_EDGE tiles per side (4096 pixels): x0 | y0 << 8 | (w - 1) << 16 |
+// (h - 1) << 24; RECT32_NONE = no tile (a real rectangle never has x0 = 255 AND w = 256).  It is the second payload of the
+// depth sort on the grouped path; larger images take the legacy path, which gathers the 8-byte rectangles.
+constexpr int RECT32_EDGE = 256;
+constexpr uint32_t RECT32_NONE = 0xffffffffu;
+__host__ __device__ inline uint32_t pack_rect32(uint32_t xy, uint32_t wh) {  // Geom::rect's two words
+  const uint32_t w = wh & 0xffffu, h = wh >> 16;  // (branch-free: a select, so that callers' loads are not made conditional)
+  const uint32_t r = (xy & 0xffu) | (((xy >> 16) & 0xffu) << 8) | (((w - 1u) & 0xffu) << 16) | (((h - 1u) & 0xffu) << 24);
+  return w * h == 0u ? RECT32_NONE : r;
+}
+// number of 8x8-tile groups the rectangle reaches (0 for RECT32_NONE)
+__host__ __device__ inline uint32_t rect32_groups(uint32_t r) {
+  if (r == RECT32_NONE) return 0u;
+  const uint32_t x0 = r & 0xffu, y0 = (r >> 8) & 0xffu, x1 = x0 + ((r >> 16) & 0xffu), y1 = y0 + (r >> 24);  // inclusive
+  return ((x1 >> GROUP_SHIFT) - (x0 >> GROUP_SHIFT) + 1u) * ((y1 >> GROUP_SHIFT) - (y0 >> GROUP_SHIFT) + 1u);
 }
 // Group instances per chunk: 1, 2, 4 or 8 batches of 64.  A chunk is one wave and one row of the per-chunk count tables.
 // A chunk wave's time is the sum of its memory and LDS round trips (measured: the kernels are latency bound at any

@@ -126,6 +126,10 @@ hipError_t launch_depth_passes(hipStream_t s, int P, const Geom& g, int p0, int 
 // sgx: groups per row when the grouped binning path follows (the depth-ordered rectangles are then group rectangles), 0 for
 // the legacy pair sort
 hipError_t launch_depth_finish(hipStream_t s, int P, const Geom& g, int passes, int gx, int sgx);
+// Grouped path: the same passes carrying the packed tile rectangle; `last`: pass p1 - 1 is the final one and leaves the
+// depth order, the rectangles in that order and every Gaussian's first slot of the emission (no launch_depth_finish).
+hipError_t launch_depth_passes_grouped(hipStream_t s, int P, const Geom& g, int p0, int p1, bool last,
+                                       uint32_t* publish_dst = nullptr, uint32_t publish_seq = 0);
 hipError_t launch_export_keys(hipStream_t s, int64_t R, int W, int H, const Binning& b, const Geom& g, uint64_t* keys);
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im);
 size_t knn_workspace_bytes(int P);

@@ -901,7 +901,7 @@ __global__ void __launch_bounds__(256) view_message_header_kernel(int64_t P, con
 constexpr int VIEW_BATCH = 8;  // views whose position maps are resident in LDS at a time
 // SPARSE (row_valid != null): a Gaussian no view sent a row for gets row_valid[g] = 0 and NOTHING is written to its gradient
 // rows (they keep whatever they held); the others get row_valid[g] = 1 and their sums.  The consumer treats invalid rows as
-// zero gradients (gsr_adam_step: `masked` tensors with row_mask = row_valid).  At 2 / 8 views 81 / 43 % of the rows are
+// zero gradients (gsr_adam_step_rows with grad_valid = row_valid: the moments still decay).  At 2 / 8 views 81 / 43 % of the rows are
 // invalid, and the dense write of 248 B per Gaussian is most of this kernel's time.
 template <bool SPARSE>
 __global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(int64_t P, int D, int M, int n_views,

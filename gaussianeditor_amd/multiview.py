@@ -42,6 +42,11 @@ from .diff_gaussian_rasterization import GaussianRasterizationSettings, Gaussian
 __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step", "batch_loss_scale",
            "densify_synchronized", "replicas_identical"]
 
+import os as _os
+
+#: GSR_DEBUG_PERSISTENT_ROWS=1: every backward into a `persistent_rows` bucket first checks that rows marked "holds zeros" do
+_DEBUG_ROWS = _os.environ.get("GSR_DEBUG_PERSISTENT_ROWS", "0") == "1"
+
 #: bucket layout per Gaussian: name -> number of floats (3M for the SH block is filled in at construction)
 _SLOTS = ("means3D", "sh", "scales", "rotations", "means2D", "opacities")
 
@@ -112,6 +117,23 @@ class GradBucket:
         # the span one fill clears for the two atomically accumulated gradients (means2D .. end of opacities)
         self._acc_span = (offs["means2D"], offs["opacities"] + P)
 
+    def check_persistent_rows(self) -> None:
+        """Debug (GSR_DEBUG_PERSISTENT_ROWS=1 runs it in front of every backward): the contract of `persistent_rows` is
+        enforced by the CALLER -- whoever writes into the bucket's gradients outside the backward / the exchange (a
+        regulariser added in place, a checkpointed gradient loaded, a custom exchange) must call invalidate_rows().  A row
+        with row_state == 0 that is not all-zero means somebody did not: the next backward would leave it as it is."""
+        if self.row_state is None:
+            return
+        stale = self.row_state == 0
+        for name in ("means3D", "scales", "rotations", "sh"):
+            v = self.views.get(name) if not (name == "sh" and self.sh_exchange == "rgb") else self.rgb
+            if v is None or int(v.shape[0]) != self.P:
+                continue
+            bad = stale & (v.reshape(self.P, -1) != 0).any(dim=1)
+            if bool(bad.any()):
+                raise RuntimeError(f"GradBucket(persistent_rows=True): {int(bad.sum())} rows of `{name}` are marked as holding "
+                                   "zeros but do not -- something wrote into the bucket's gradients without invalidate_rows()")
+
     def invalidate_rows(self) -> None:
         """Something other than the backward has written to the gradient tensors: every row is rewritten next time."""
         if self.row_state is not None:
@@ -122,7 +144,10 @@ class GradBucket:
             # asked last.  Only if every gradient the state stands for was answered with this bucket's own tensor in THIS
             # backward: a row that is not rewritten must be a row of a tensor that lives across iterations
             own = {"means3D", "scales", "rotations"} <= self._handed and ({"sh", "sh_rgb"} & self._handed)
-            return self.row_state if (self.row_state is not None and own and tuple(shape) == (self.P,)) else None
+            ok = self.row_state is not None and own and tuple(shape) == (self.P,)
+            if ok and _DEBUG_ROWS:
+                self.check_persistent_rows()
+            return self.row_state if ok else None
         if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the four accumulators)
             if self.on_blend_done is not None:
                 self.on_blend_done(shape)
@@ -418,6 +443,12 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
         color, radii, depth, grads = render_view_grads(settings, params["xyz"], params["opacity"], params["features"],
                                                        params["scaling"], params["rotation"], dL_dcolor, bucket,
                                                        after_forward=start_radii)
+    except BaseException:
+        # a backward / exchange that raised after start_counts ran must not leave its plan, host buffer and events behind:
+        # the next step's exchange would pair the stale plan with new gradients
+        bucket._pending_counts = None
+        bucket._cap_hint = None
+        raise
     finally:
         bucket.on_blend_done = None
     bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows, sparse=sparse, force_exchange=force_exchange)
@@ -454,22 +485,28 @@ def batch_loss_scale(world_size: int, rank: int = 0, per_step: str = "split") ->
 
 def replicas_identical(tensors, group=None) -> bool:
     """True iff every rank of `group` holds bit-identical copies of `tensors` (shapes included).  One MAX and one MIN
-    all-reduce over a small per-tensor fingerprint (element count + wrapping sums of the raw 32-bit words, which any
-    single differing word changes).  Collective: every rank must call it."""
+    all-reduce over a small per-tensor fingerprint (element count, the sum of the raw words and their sum weighted by
+    position, over the raw 16-bit words and exact modulo the prime 2^31 - 1: any single differing element -- a 1-ulp
+    divergence anywhere, in a tensor of any size -- changes it).  Collective: every rank must call it."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return True
     fp = []
     for t in tensors:
         raw = t.detach().contiguous().reshape(-1)
-        if raw.element_size() == 4:
-            w = raw.view(torch.int32).to(torch.int64)
-        elif raw.element_size() == 1:
-            w = raw.view(torch.uint8).to(torch.int64)
+        if raw.element_size() % 2 == 0:
+            w = raw.view(torch.int16).to(torch.int64) & 0xFFFF  # 16-bit words: two per float32 / int32, four per 8-byte element
         else:
-            w = raw.to(torch.float64).view(torch.int64)
-        pos = torch.arange(1, w.numel() + 1, dtype=torch.int64, device=w.device)
+            w = raw.view(torch.uint8).to(torch.int64)
+        # Every sum is EXACT: int64 arithmetic reduced modulo the prime 2^31 - 1 (every partial product and the final value
+        # fit an int64 and, exactly, a float64) -- never an int64 -> float64 cast of a large sum.  The positional weight is
+        # never zero (1 .. 65521) and a 16-bit word differs by less than the modulus, so a single differing word changes
+        # both sums; a differing 32-bit word (two adjacent halves, weights a and a + 1) always changes the weighted one.
+        M31 = (1 << 31) - 1
+        pos = torch.arange(w.numel(), dtype=torch.int64, device=w.device) % 65521 + 1
+        wm = w % M31
         fp += [torch.tensor(float(w.numel()), dtype=torch.float64, device=w.device).view(1),
-               w.sum().to(torch.float64).view(1), ((w * (pos % 65521)).sum() % (1 << 52)).to(torch.float64).view(1)]
+               (wm.sum() % M31).to(torch.float64).view(1),
+               (((wm * pos) % M31).sum() % M31).to(torch.float64).view(1)]
     mine = torch.cat(fp) if fp else torch.zeros(1, dtype=torch.float64)
     hi, lo = mine.clone(), mine.clone()
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)

@@ -130,7 +130,7 @@ class FusedMaskedAdam(torch.optim.Optimizer):
                 w_ptr = self._row_weight.data_ptr() if self._row_weight is not None else None
                 valid_ptr = self._grad_valid.data_ptr() if self._grad_valid is not None else None
                 with torch.cuda.device(dev):
-                    _native.check("gsr_adam_step", L.gsr_adam_step_rows(
+                    _native.check("gsr_adam_step_rows", L.gsr_adam_step_rows(
                         torch.cuda.current_stream(dev).cuda_stream, len(chunk), arr, step, float(betas[0]), float(betas[1]),
                         float(eps), mask_ptr, w_ptr, valid_ptr))
                 del keep

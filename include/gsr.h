@@ -161,8 +161,13 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
 /* K7 + K8 + K9: the whole backward.  Reference: Rasterizer::backward,
  * rasterizer_impl.cu:289-341 (BACKWARD::render then BACKWARD::preprocess).
  *   dL_dpix (3,H,W) in.
- *   Accumulated with atomics, MUST be zero-filled by the caller:
+ *   Accumulated with atomics, MUST be zero-filled by the caller (or cleared by the call: GSR_FLAG_CLEAR_GRADS):
  *       dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P), dL_dconic (P,4) [workspace].
+ *       These four arrays MUST live in ordinary (coarse-grained) device memory -- hipMalloc, torch's caching allocator --,
+ *       not in fine-grained / host-coherent allocations (hipMallocManaged, hipHostMalloc, hipExtMallocWithFlags(...
+ *       hipDeviceMallocFinegrained)): the library is built with -munsafe-fp-atomics, i.e. its float adds are the hardware's
+ *       global_atomic_add_f32, which is only defined on coarse-grained memory (on fine-grained memory the adds are silently
+ *       lost).  The same holds for `weights` / `cnt` of gsr_trace_weights.
  *   Fully written by the library (no need to zero): dL_dmeans3D (P,3), dL_dcov3D (P,6),
  *       dL_dsh (P,M,3) [NULL if shs == NULL], dL_dscales (P,3) and dL_drots (P,4) [NULL if scales == NULL].
  *   (The reference zero-fills all nine, rasterize_points.cu:120-128.) */
@@ -336,9 +341,11 @@ int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_
                                  int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out);
 /* The same sums, written only where a view sent a row: row_valid (P bytes, device; NULL = gsr_view_messages_accumulate)
  * receives 1 for the Gaussians some view touched and 0 for the others, whose rows of `out` are NOT written (they keep their
- * previous contents).  The consumer treats those rows as zero gradients -- gsr_adam_step with `masked` tensors and
- * row_mask = row_valid (AND the caller's own mask) does, and reads no gradient of an invalid row.  A view touches ~10 % of
- * the benchmark scene, so with 2 / 8 views 81 / 43 % of the 248 B per Gaussian are neither written here nor read there. */
+ * previous contents).  The consumer treats those rows as zero gradients: gsr_adam_step_rows with grad_valid = row_valid takes
+ * an invalid row's gradient as zeros WITHOUT reading it and still decays that row's moments, bit for bit what gsr_adam_step
+ * does on zero-filled gradients.  (NOT gsr_adam_step's `row_mask`: a masked row keeps its moments from decaying, which is the
+ * reference's apply_grad_mask semantics, not a zero gradient.)  A view touches ~10 % of the benchmark scene, so with 2 / 8
+ * views 81 / 43 % of the 248 B per Gaussian are neither written here nor read there. */
 int gsr_view_messages_accumulate_rows(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
                                       int64_t stride_words, int64_t cap, const float* means3D, const gsr_dense_grads* out,
                                       uint8_t* row_valid);
