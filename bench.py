@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the rasterizer hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--views V]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`, or started plainly:
      without WORLD_SIZE in the environment `--gpus N` re-executes itself under torch.distributed.run with N ranks on
      127.0.0.1, and refuses to run if fewer than N GPUs are visible -- it never reports n_gpus = 1 for --gpus N)
 
 Workload (BASELINE.json metric, config C4): synth-v1 scene, 1,000,000 Gaussians, SH degree 3
-(M = 16), 1920x1080, ring-v1 cameras; rank r renders view r (one view per GPU, weak scaling).
-A step = forward + backward of this rank's view through the drop-in L1 API + the gradient
-all-reduce (SUM over the flat bucket, MAX over radii); inputs are resident in HBM.
+(M = 16), 1920x1080, ring-v1 cameras.  Default: rank r renders view r (one view per GPU, weak scaling).
+`--views V` (V a multiple of N) fixes the batch instead: the V views of BASELINE configs[3] are dealt to the ranks in
+contiguous blocks, every rank renders V / N of them and packs one touched-rows message per view, ONE all-gather per step,
+the sums formed in ascending view order (gaussianeditor_amd/multiview.py: multiview_batch_step) -- strong scaling of the
+reference's own batch loop (threestudio/systems/GassuianEditor.py:165-207), bit-identical to it for every N.
+A step = forward + backward of this rank's view(s) through the drop-in L1 API + the gradient
+exchange (SUM over the views, MAX over radii); inputs are resident in HBM.
 
-One JSON line is printed by rank 0: the train rate is `value`; the forward-only rate
-(renders/s, Mpixels/s), the per-stage GPU times, the roofline of the dominant stage and
-the CPU baselines (the C++/OpenMP oracle and the PyTorch-CPU restatement) ride along in the
-same object.
+One JSON line is printed by rank 0: the train rate is `value`; the forward-only rate (renders/s, Mpixels/s), the
+per-stage GPU times, the roofline block of the dominant stage (section 8(d) bytes, the compulsory-byte model, counter
+traffic and VALU issue share), the other BASELINE configurations (`extra_configs`: 6 M forward, the 512^2 edit loop,
+tracing) and the CPU baselines ride along in the same object; N > 1 lines add `multi_gpu` (per-rank step times, exchange
+time and bytes, route, RCCL version).
 """
 from __future__ import annotations
 
@@ -33,10 +38,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+STAGES = ("preprocess", "bin", "blend_forward", "blend_backward", "preprocess_backward")
 
 
 def algorithmic_bytes(P, V, R, N, T, M):
-    """compulsory HBM bytes per stage for one view."""
+    """compulsory HBM bytes per stage for one view, as the survey wrote them (the contract figure:
+    per-INSTANCE gather terms for the blend stages)."""
     return {
         "preprocess": (48 + 12 * M) * P + 67 * V,            # K1+K2: params in, radii + survivor state out
         "bin": 36 * R + 16 * T,                              # K3 emit 12 + K4 sort 24 per instance, K5 ranges
@@ -44,6 +51,17 @@ def algorithmic_bytes(P, V, R, N, T, M):
         "blend_backward": 20 * N + 76 * R,                   # K7: pixel inputs 20; per instance 4 + 36 + 36
         "preprocess_backward": (103 + 12 * M) * V + (56 + 12 * M) * P,  # K8+K9
     }
+
+
+def compulsory_bytes(P, V, R, N, T, M):
+    """The same model with the blend stages' per-instance terms put right: a Gaussian's 48-byte gather
+    record has to cross the HBM interface once per VIEW, not once per (tile, Gaussian) instance, and its reduced gradient
+    (the four accumulators, 44 B) is written once per visible Gaussian -- an instance costs only its 4-byte list entry.
+    With section 8(d)'s figures a deep-tile scene (R = 49 x V) reported a fraction above 1 of the HBM peak."""
+    b = algorithmic_bytes(P, V, R, N, T, M)
+    b["blend_forward"] = 4 * R + 48 * V + 24 * N
+    b["blend_backward"] = 20 * N + 4 * R + (48 + 44) * V
+    return b
 
 
 def self_launch(n: int) -> None:
@@ -84,16 +102,256 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
+def workload_key(P, W, H, s0) -> str:
+    """Key of a workload in profiles/traffic_latest.json (tools/collect_counters.py writes the same)."""
+    return f"synth-v1:{int(P)}:{int(W)}x{int(H)}:s0={float(s0):g}"
+
+
+def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
+    """Per-stage GPU time of one view through the individual C-ABI calls (HIP events on the launch stream), plus what the
+    byte models need: num_rendered R, visible V, and the pixel-instances of the view (sum over tiles of pixels x list length:
+    SURVEY.md section 8(d) "flops (secondary)")."""
+    import ctypes
+
+    from gaussianeditor_amd import _native
+
+    L = _native.lib()
+    s = torch.cuda.current_stream(dev)
+    sp = s.cuda_stream
+    P, M = int(params["xyz"].shape[0]), int(params["features"].shape[1])
+    H, W = int(rs.image_height), int(rs.image_width)
+    tfx, tfy = float(rs.tanfovx), float(rs.tanfovy)
+    names = STAGES if backward else STAGES[:3]
+    acc = {k: 0.0 for k in names}
+    p = lambda t: t.data_ptr()  # noqa: E731
+    op_flat = params["opacity"].contiguous()
+    R = V = pix_inst = 0
+    for it in range(iters + 2):
+        gb, _, ib = _native.scratch_sizes(P, 0, W, H)
+        geom = torch.empty(gb, dtype=torch.uint8, device=dev)
+        img = torch.empty(ib, dtype=torch.uint8, device=dev)
+        radii_t = torch.empty(P, dtype=torch.int32, device=dev)
+        color = torch.empty((3, H, W), device=dev)
+        depth = torch.empty((1, H, W), device=dev)
+        if backward:
+            z = torch.empty(P * 11, device=dev)  # (cleared by the blend backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does)
+            d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
+            d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
+            d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
+        Rc = (ctypes.c_int64 * 2)()
+        ev[0].record(s)
+        _native.check("pre", L.gsr_preprocess(sp, P, D, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
+                                              p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
+                                              p(rs.campos), W, H, tfx, tfy, 0, 0, flags | (0 if backward else 8), p(radii_t),
+                                              p(geom), Rc))
+        ev[1].record(s)
+        R, Gi = int(Rc[0]), int(Rc[1])
+        _, bb, _ = _native.scratch_sizes(P, R, W, H, Gi)
+        binning = torch.empty(bb, dtype=torch.uint8, device=dev)
+        _native.check("bin", L.gsr_bin(sp, P, R, Gi, W, H, p(geom), p(binning), p(img)))
+        ev[2].record(s)
+        _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
+        ev[3].record(s)
+        if backward:
+            _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
+                                                      p(d_con), p(d_op), p(d_col), flags | 4))
+            ev[4].record(s)
+            _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
+                                                           p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
+                                                           p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom), p(d_m2),
+                                                           p(d_con), p(d_col), p(d_m3), p(d_cov), p(d_sh), p(d_sc), p(d_rot)))
+            ev[5].record(s)
+        torch.cuda.synchronize(dev)
+        if it >= 2:
+            for i, k in enumerate(names):
+                acc[k] += ev[i].elapsed_time(ev[i + 1])
+        if it == iters + 1:
+            V = int((radii_t > 0).sum().item())
+            T = ((W + 15) // 16) * ((H + 15) // 16)
+            rng = torch.empty((T, 2), dtype=torch.int32, device=dev)
+            _native.check("export_image", L.gsr_debug_export_image(sp, W, H, p(img), p(rng), None, None))
+            lens = (rng[:, 1] - rng[:, 0]).to(torch.int64)
+            gx = (W + 15) // 16
+            t = torch.arange(T, device=dev)
+            pw = torch.clamp(W - (t % gx) * 16, max=16)
+            ph = torch.clamp(H - (t // gx) * 16, max=16)
+            pix_inst = int((lens * pw * ph).sum().item())
+    return {k: acc[k] / iters for k in names}, R, V, pix_inst
+
+
+def load_counters(key):
+    """profiles/traffic_latest.json: per-launch HBM bytes and VALU wave-instructions per stage, measured with rocprofv3 PMC
+    passes on this workload (tools/collect_counters.py) and stamped with the hash of the kernel sources; stale (or absent)
+    -> (None, reason)."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    except Exception:
+        return None, "profiles/traffic_latest.json is missing"
+    if tj.get("csrc_sha16") != csrc_sha16():
+        return None, (f"stale: profiles/traffic_latest.json was measured on kernel sources {tj.get('csrc_sha16')}, "
+                      f"this build is {csrc_sha16()}")
+    w = tj.get("workloads", {}).get(key)
+    if w is None:
+        return None, f"profiles/traffic_latest.json holds no counters for {key}"
+    return w, tj.get("source")
+
+
+def roofline_block(stage_ms, ab, cb, dominant, counters, source, dev, pix_inst):
+    """The line's `roofline` object for the stage that takes the most time."""
+    t = stage_ms[dominant] * 1e-3
+    ach = ab[dominant] / t / 1e9
+    out = {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "model": "compulsory bytes (section 8(d), the blend stages' gather / gradient terms once per visible Gaussian instead "
+                    "of once per instance: bench.py compulsory_bytes) / stage time",
+           "frac": cb[dominant] / t / 1e9 / HBM_PEAK_GBS,
+           "achieved_8d": ach, "frac_8d": ach / HBM_PEAK_GBS,
+           "traffic": None, "frac_counter": None, "valu_issue_frac": None, "traffic_source": source}
+    out["achieved"] = cb[dominant] / t / 1e9
+    if counters is not None:
+        tb = counters.get("per_launch_bytes", {}).get(dominant)
+        vi = counters.get("valu_wave_insts", {}).get(dominant)
+        if tb is not None:
+            out["traffic"] = tb
+            out["frac_counter"] = tb / t / 1e9 / HBM_PEAK_GBS
+        if vi is not None:
+            prop = torch.cuda.get_device_properties(dev)
+            simds = prop.multi_processor_count * 4
+            clk = prop.clock_rate * 1e3  # Hz
+            # a SIMD issues at most one VALU instruction of a wave per 4 cycles (64 lanes over a 16-wide datapath)
+            out["valu_issue_frac"] = vi / (simds * t * clk / 4.0)
+            out["valu_wave_insts"] = vi
+    if dominant in ("blend_forward", "blend_backward"):
+        out["limiter"] = ("instruction issue / per-item latency, not HBM: see valu_issue_frac and pixel_instances_per_s "
+                          "(DESIGN.md section 3.1)")
+        out["pixel_instances_per_s"] = pix_inst / t
+    return out
+
+
+def extra_configs(dev, flags, budget_s=60.0):
+    """The other BASELINE.json configurations with the substitutes SURVEY.md section 8(d) prescribes, bounded to about a
+    minute (rank 0, N = 1 only): C2 = 6 M Gaussians forward at 1080p (stage times + roofline), C3 = the 512^2 edit loop
+    (SH render + override_color render + backward per step; and with the fused second image), C5 = tracing ms / view.
+    The same measurements as tools/bench_configs.py."""
+    from types import SimpleNamespace
+
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings
+    from gaussianeditor_amd.gaussian_renderer import camera2rasterizer, render
+    from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
+
+    t_begin = time.perf_counter()
+    out = {"note": "substitutes for assets that are not available offline (bicycle.ply, the bear scene, diffusion weights); "
+                   "tools/bench_configs.py measures the same"}
+    pipe = SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+
+    class PC:
+        def __init__(self, sc, grad=False):
+            self.t = {k: v.to(dev).requires_grad_(grad) for k, v in sc.items() if isinstance(v, torch.Tensor) and k != "bg"}
+            self.active_sh_degree, self.max_sh_degree = 3, 3
+
+        get_xyz = property(lambda s: s.t["xyz"])
+        get_opacity = property(lambda s: s.t["opacity"])
+        get_scaling = property(lambda s: s.t["scaling"])
+        get_rotation = property(lambda s: s.t["rotation"])
+        get_features = property(lambda s: s.t["features"])
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / steps
+
+    # ---- C3 / C5 on the headline scene at the editor's 512 x 512
+    sc = synth_scene(1_000_000, seed=0, s0=0.01)
+    bg = sc["bg"].to(dev)
+    pc = PC(sc, grad=True)
+    cam = ring_cameras(8, 512, 512)[0].to(dev)
+    G = seed_gradient(512, 512, 0).to(dev)
+    mask = (torch.rand(1_000_000, 1, device=dev) > 0.5).float().repeat(1, 3)
+
+    def edit_step():
+        a = render(cam, pc, pipe, bg)
+        with torch.no_grad():
+            render(cam, pc, pipe, bg, override_color=mask)  # the semantic pass (GassuianEditor.py:183-191)
+        (a["render"] * G).sum().backward()
+        for v in pc.t.values():
+            v.grad = None
+
+    def edit_step_fused():  # both images from ONE preprocessing / sort: render(..., semantic_color=mask)
+        a = render(cam, pc, pipe, bg, semantic_color=mask)
+        (a["render"] * G).sum().backward()
+        for v in pc.t.values():
+            v.grad = None
+
+    t = timed(edit_step, 30, 5)
+    out["C3_edit_loop_512_1M"] = {"ms_per_step": 1e3 * t, "what": "SH render + override_color render + backward, 1 M Gaussians"}
+    t = timed(edit_step_fused, 30, 5)
+    out["C3_edit_loop_512_1M_fused_semantic"] = {"ms_per_step": 1e3 * t}
+    cams = [c.to(dev) for c in ring_cameras(12, 512, 512)]
+    masks = [(torch.rand(1, 512, 512, device=dev) > 0.5).float() for _ in cams]
+    zero_bg = torch.zeros(3, device=dev)
+
+    def trace_all():
+        w = torch.zeros(1_000_000, 1, device=dev)
+        cnt = torch.zeros(1_000_000, 1, dtype=torch.int32, device=dev)
+        with torch.no_grad():
+            for c, m in zip(cams, masks):
+                camera2rasterizer(c, zero_bg).apply_weights(pc.get_xyz, None, pc.get_opacity, None, w, pc.get_scaling,
+                                                            pc.get_rotation, None, cnt, m)
+
+    t = timed(trace_all, 5, 1)
+    out["C5_apply_weights_12views_512_1M"] = {"ms_per_view": 1e3 * t / len(cams), "ms_total": 1e3 * t}
+    del pc, mask
+    torch.cuda.empty_cache()
+    # ---- C2: 6 M Gaussians, forward only, 1080p
+    if time.perf_counter() - t_begin < budget_s:
+        P6, W, H = 6_000_000, 1920, 1080
+        sc = synth_scene(P6, seed=0, s0=0.01)
+        cam = ring_cameras(8, W, H)[0]
+        params = {k: sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+        rs = GaussianRasterizationSettings(H, W, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), sc["bg"].to(dev), 1.0,
+                                           cam.world_view_transform.to(dev), cam.full_proj_transform.to(dev), 3,
+                                           cam.camera_center.to(dev), False, False)
+        st, R, V, pix = stage_times(dev, params, rs, None, 3, flags, 10, backward=False)
+        N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), 16
+        ab, cb = algorithmic_bytes(P6, V, R, N, T, M), compulsory_bytes(P6, V, R, N, T, M)
+        dom = max(st, key=st.get)
+        counters, src = load_counters(workload_key(P6, W, H, 0.01))
+        fwd_ms = sum(st.values())
+        out["C2_synth6M_1080p_forward"] = {
+            "forward_ms": fwd_ms, "renders_per_s": 1e3 / fwd_ms, "mpixels_per_s": N / fwd_ms / 1e3, "stage_ms": st,
+            "num_rendered": R, "visible": V,
+            "what": "sum of the three forward stages through the C ABI (HIP events), forward-only preprocess",
+            "hbm_fraction_forward": sum(cb[k] for k in st) / (fwd_ms * 1e-3) / (HBM_PEAK_GBS * 1e9),
+            "roofline": roofline_block(st, ab, cb, dom, counters, src, dev, pix)}
+        del params, sc
+        torch.cuda.empty_cache()
+    out["seconds"] = time.perf_counter() - t_begin
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--views", type=int, default=0,
+                    help="views per step of the WHOLE job (default 0 = one per GPU, weak scaling).  A multiple of --gpus: every "
+                         "rank renders views/gpus views per step and the batch is fixed as N grows (strong scaling of "
+                         "BASELINE configs[3]'s 8-view batch: --views 8)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--s0", type=float, default=0.01, help="synth-v1 median scale (0.01 = headline; 0.03-0.05 = deep tiles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the `extra_configs` block (6 M forward, edit loop, tracing)")
+    ap.add_argument("--train-only", action="store_true",
+                    help="profiling runs (tools/gpu_counters.sh): only the warm-up and the timed train iterations, nothing else "
+                         "is launched -- every kernel launch of the process belongs to a train iteration")
     ap.add_argument("--cpu-iters", type=int, default=15, help="oracle train iterations timed for cpu_baseline")
     ap.add_argument("--ply", type=str, default=None,
                     help="a 3DGS point cloud in the reference's save_ply layout (gaussiansplatting/scene/gaussian_model.py:"
@@ -120,6 +378,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    views = args.views if args.views > 0 else world
+    if views % world != 0:
+        raise SystemExit(f"--views {views} must be a multiple of --gpus {world}")
+    batch_mode = args.views > 0  # the fixed batch of --views views, dealt to the ranks (multiview_batch_step)
+    if batch_mode and (args.force_exchange or args.persistent_grads):
+        raise SystemExit("--views does not combine with --force-exchange / --persistent-grads")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the rasterizer has no CPU fallback)")
     # GSR_BENCH_SHARED_GPU=1 (testing only): run all ranks on GPU 0 with the gloo backend, to exercise the multi-rank
@@ -151,8 +415,8 @@ def main():
     gaussianeditor_amd.set_fast_exp(os.environ.get("GSR_FAST_EXP", "0") == "1")
     from gaussianeditor_amd import options
     flags = options.current_flags()
-    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
-    from gaussianeditor_amd.multiview import GradBucket, multiview_step, render_view_grads
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from gaussianeditor_amd.multiview import GradBucket, multiview_batch_step, multiview_step, views_of_rank
     from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
 
     P, W, H = args.gaussians, args.width, args.height
@@ -174,13 +438,23 @@ def main():
         sc = synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
         ply_degree = 3
     M = sc["features"].shape[1]
-    cam = ring_cameras(8, W, H)[rank % 8]
-    tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    ring = ring_cameras(8, W, H)
     params = {k: sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
     G = seed_gradient(H, W, 0).to(dev)
-    rs = GaussianRasterizationSettings(H, W, tfx, tfy, sc["bg"].to(dev), 1.0, cam.world_view_transform.to(dev),
-                                       cam.full_proj_transform.to(dev), ply_degree, cam.camera_center.to(dev), False, False)
-    bucket = GradBucket(P, M, dev, sh_exchange="rgb" if args.force_exchange else "auto", persistent_rows=args.persistent_grads)
+
+    def settings_of(view):
+        cam_ = ring[view % 8]
+        return GaussianRasterizationSettings(H, W, math.tan(cam_.FoVx / 2), math.tan(cam_.FoVy / 2), sc["bg"].to(dev), 1.0,
+                                             cam_.world_view_transform.to(dev), cam_.full_proj_transform.to(dev), ply_degree,
+                                             cam_.camera_center.to(dev), False, False)
+
+    my_views = list(views_of_rank(views, world, rank))
+    cam = ring[my_views[0] % 8]
+    tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
+    rs = settings_of(my_views[0])
+    rs_list = [settings_of(v) for v in my_views]
+    bucket = GradBucket(P, M, dev, sh_exchange="rgb" if (args.force_exchange or batch_mode) else "auto",
+                        persistent_rows=args.persistent_grads)
 
     def sync_all():
         if world > 1:
@@ -194,17 +468,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ---------------- train step: fwd + bwd + all-reduce ----------------
+    # ---------------- train step: fwd + bwd + exchange ----------------
     route = {"last": "local"}
     # GSR_BENCH_ROWS=0|1 (testing): force the dense / the touched-rows form of the exchange instead of choosing by bytes
     rows_env = os.environ.get("GSR_BENCH_ROWS")
     rows_mode = "auto" if rows_env is None else (rows_env == "1")
+    marks_log = []
 
-    def train_step():
-        # forward, radii MAX all-reduce started, backward, gradient exchange (gaussianeditor_amd/multiview.py)
-        color, radii, depth, grads = multiview_step(rs, params, G, bucket, rows=True if args.force_exchange else rows_mode,
-                                                    force_exchange=args.force_exchange)
+    def train_step(record=False):
+        marks = {} if record else None
+        if batch_mode:
+            # the fixed batch: this rank's block of views, one message per view, one all-gather (multiview_batch_step)
+            _, radii, _, _ = multiview_batch_step(rs_list, params, [G] * len(rs_list), bucket, marks=marks)
+        else:
+            # forward, radii MAX all-reduce started, backward, gradient exchange (gaussianeditor_amd/multiview.py)
+            _, radii, _, _ = multiview_step(rs, params, G, bucket, rows=True if args.force_exchange else rows_mode,
+                                            force_exchange=args.force_exchange, marks=marks)
         route["last"] = bucket.last_route
+        if record:
+            marks_log.append(marks)
         return radii
 
     exchange = bucket.sh_exchange
@@ -220,96 +502,84 @@ def main():
     t0 = time.perf_counter()
     step_ev[0].record(cur)
     for i in range(args.steps):
-        radii = train_step()
+        train_step(record=True)
         step_ev[i + 1].record(cur)
     sync_all()
     train_s = max_over_ranks(time.perf_counter() - t0)
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
+    local_ms = [step_ev[i].elapsed_time(m["local_done"]) for i, m in enumerate(marks_log) if m and "local_done" in m]
+    exch_ms = [m["local_done"].elapsed_time(m["step_done"]) for m in marks_log if m and "step_done" in m]
 
-    # ---------------- forward only ----------------
-    rast = GaussianRasterizer(rs)
-    m2d = torch.zeros_like(params["xyz"])
+    # ---------------- multi-GPU diagnostics: every rank's view of the step ----------------
+    multi_gpu = None
+    if world > 1 or args.force_exchange:
+        lx = bucket.last_exchange if route["last"] == "rows" else None
+        mine = torch.tensor([percentile(step_ms, 0.5) or 0.0, percentile(local_ms, 0.5) or 0.0, percentile(exch_ms, 0.5) or 0.0,
+                             float((lx or {}).get("bytes_sent", 0)), float((lx or {}).get("bytes_received", 0))],
+                            dtype=torch.float64, device=dev)
+        if world > 1:
+            allr = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+        else:
+            allr = [mine]
+        per_rank = [[float(x) for x in r.tolist()] for r in allr]
+        try:
+            nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception as ex:  # (a build without the binding)
+            nccl_version = f"unavailable ({type(ex).__name__})"
+        multi_gpu = {
+            "world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            "backend": dist.get_backend() if dist.is_initialized() else None,
+            "rccl_version": nccl_version,
+            "shared_gpu_test_run": shared,
+            "views_per_step": views, "views_per_rank": len(my_views),
+            "route": route["last"],
+            "per_rank": {"step_ms_gpu": [r[0] for r in per_rank],
+                         "local_ms_gpu": [r[1] for r in per_rank],
+                         "exchange_ms_gpu": [r[2] for r in per_rank],
+                         "bytes_sent_per_step": [int(r[3]) for r in per_rank],
+                         "bytes_received_per_step": [int(r[4]) for r in per_rank]},
+            "note": "medians over the timed steps of HIP events on each rank's launch stream: step = local (forward + backward "
+                    "of the rank's views, incl. packing) + exchange (collectives + the accumulate kernel); bytes are the "
+                    "touched-rows messages of the last step (0 on the dense route: its all-reduce moves the whole bucket)",
+        }
 
-    def fwd_step():
-        with torch.no_grad():
-            return rast(params["xyz"], m2d, params["opacity"], shs=params["features"], scales=params["scaling"],
-                        rotations=params["rotation"])
+    fwd_s, fwd_ms = None, []
+    stage_ms, ab, cb, R, V, pix_inst = {}, {}, {}, 0, 0, 0
+    if not args.train_only:
+        # ---------------- forward only ----------------
+        rast = GaussianRasterizer(rs)
+        m2d = torch.zeros_like(params["xyz"])
 
-    for _ in range(max(2, args.warmup // 2)):
-        fwd_step()
-    sync_all()
-    fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    fwd_ev[0].record(cur)
-    for i in range(args.steps):
-        fwd_step()
-        fwd_ev[i + 1].record(cur)
-    sync_all()
-    fwd_s = max_over_ranks(time.perf_counter() - t0)
-    fwd_ms = [fwd_ev[i].elapsed_time(fwd_ev[i + 1]) for i in range(args.steps)]
+        def fwd_step():
+            with torch.no_grad():
+                return rast(params["xyz"], m2d, params["opacity"], shs=params["features"], scales=params["scaling"],
+                            rotations=params["rotation"])
 
-    # ---------------- per-stage GPU time (HIP events on the launch stream), rank-local ----------------
-    L = _native.lib()
-    s = torch.cuda.current_stream(dev)
-    sp = s.cuda_stream
-    import ctypes
-    e = torch.empty(0, device=dev)
-    names = ("preprocess", "bin", "blend_forward", "blend_backward", "preprocess_backward")
-    acc = {k: 0.0 for k in names}
-    p = lambda t: t.data_ptr()  # noqa: E731
-    op_flat = params["opacity"].contiguous()
-    R = V = 0
-    stage_iters = max(5, min(args.steps, 20))
-    for it in range(stage_iters + 2):
-        gb, _, ib = _native.scratch_sizes(P, 0, W, H)
-        geom = torch.empty(gb, dtype=torch.uint8, device=dev)
-        img = torch.empty(ib, dtype=torch.uint8, device=dev)
-        radii_t = torch.empty(P, dtype=torch.int32, device=dev)
-        color = torch.empty((3, H, W), device=dev)
-        depth = torch.empty((1, H, W), device=dev)
-        z = torch.empty(P * 11, device=dev)  # (cleared by the blend backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does)
-        d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
-        d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
-        d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-        Rc = (ctypes.c_int64 * 2)()
-        ev[0].record(s)
-        _native.check("pre", L.gsr_preprocess(sp, P, ply_degree, M, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
-                                              p(op_flat), p(params["features"]), None, None, p(rs.viewmatrix), p(rs.projmatrix),
-                                              p(rs.campos), W, H, tfx, tfy, 0, 0, flags, p(radii_t), p(geom), Rc))
-        ev[1].record(s)
-        R, Gi = int(Rc[0]), int(Rc[1])
-        _, bb, _ = _native.scratch_sizes(P, R, W, H, Gi)
-        binning = torch.empty(bb, dtype=torch.uint8, device=dev)
-        _native.check("bin", L.gsr_bin(sp, P, R, Gi, W, H, p(geom), p(binning), p(img)))
-        ev[2].record(s)
-        _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
-        ev[3].record(s)
-        _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
-                                                  p(d_con), p(d_op), p(d_col), flags | 4))
-        ev[4].record(s)
-        _native.check("pbw", L.gsr_preprocess_backward(sp, P, ply_degree, M, W, H, p(params["xyz"]), p(params["features"]),
-                                                       p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
-                                                       p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom), p(d_m2),
-                                                       p(d_con), p(d_col), p(d_m3), p(d_cov), p(d_sh), p(d_sc), p(d_rot)))
-        ev[5].record(s)
-        torch.cuda.synchronize(dev)
-        if it >= 2:
-            for i, k in enumerate(names):
-                acc[k] += ev[i].elapsed_time(ev[i + 1])
-        V = int((radii_t > 0).sum().item())
-    stage_ms = {k: acc[k] / stage_iters for k in names}
-    ab = algorithmic_bytes(P, V, R, N, T, M)
-    dominant = max(stage_ms, key=stage_ms.get)
-    ach = ab[dominant] / (stage_ms[dominant] * 1e-3) / 1e9  # GB/s
+        for _ in range(max(2, args.warmup // 2)):
+            fwd_step()
+        sync_all()
+        fwd_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        t0 = time.perf_counter()
+        fwd_ev[0].record(cur)
+        for i in range(args.steps):
+            fwd_step()
+            fwd_ev[i + 1].record(cur)
+        sync_all()
+        fwd_s = max_over_ranks(time.perf_counter() - t0)
+        fwd_ms = [fwd_ev[i].elapsed_time(fwd_ev[i + 1]) for i in range(args.steps)]
+
+        # ---------------- per-stage GPU time (HIP events on the launch stream), rank-local ----------------
+        stage_ms, R, V, pix_inst = stage_times(dev, params, rs, G, ply_degree, flags, max(5, min(args.steps, 20)))
+        ab, cb = algorithmic_bytes(P, V, R, N, T, M), compulsory_bytes(P, V, R, N, T, M)
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N == 1) ----------------
     # Both legs are BOUNDED: the C++/OpenMP oracle runs one iteration, then as many more as fit ~12 s (at most
     # --cpu-iters); the PyTorch-CPU restatement runs in a subprocess (its own thread pool -- sharing the process with the
     # oracle's OpenMP runtime on a 256-thread host oversubscribes it into a crawl) with a hard timeout, blends every 8th
-    # non-empty tile and scales the blend time up.
+    # non-empty tile and scales the blend time up (anchor, measured once in full: profiles/r04_a_torch_cpu_full.md).
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.train_only:
         from oracle import cpu as O
 
         cam0 = cam
@@ -342,7 +612,8 @@ def main():
         import subprocess
 
         # (32 threads at most: the restatement is torch's stable argsort, gathers and per-tile cumprod, whose intra-op
-        #  parallelism saturates there; the oracle leg above uses every core)
+        #  parallelism saturates there -- measured in full on the 256-thread host: 8.0 s per render with 32 threads, 55.4 s
+        #  with 128, profiles/r04_a_torch_cpu_full.md; the oracle leg above uses every core)
         threads = max(1, min(32, os.cpu_count() or 1))
         stride = 8
         try:
@@ -358,30 +629,24 @@ def main():
                                           f"blending) on the same view: preprocess + sort of all {tj['num_rendered']} instances "
                                           f"{tj['prepare_s']:.2f} s, blending of {tj['tiles_blended']} of {tj['tiles_nonempty']} "
                                           f"non-empty tiles (every {stride}th) {tj['blend_s_sampled']:.2f} s, scaled to all tiles; "
-                                          f"{threads} threads (the intra-op parallelism of argsort / gather / cumprod saturates "
-                                          f"there on this {os.cpu_count()}-thread host; the oracle leg uses all cores)"}
+                                          f"{threads} threads",
+                                "anchor": "measured in full once (all 1 696 non-empty tiles of this view): 8.02 s per render = "
+                                          "0.125 renders/s with 32 threads, 55.4 s with 128 threads on the 256-thread EPYC 9575F "
+                                          "host (profiles/r04_a_torch_cpu_full.md)"}
         except Exception as ex:  # the second leg must never cost the bench line
             cpu["torch_cpu"] = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
 
-    # HBM traffic of the dominant kernel: bench.py cannot read PMC counters itself; it reports the per-launch value
-    # measured with rocprofv3 on this same workload and committed under profiles/ (null for any other workload).
-    # The file is stamped with a hash of the kernel sources it was measured on (tools/stamp_traffic.py); when the sources
-    # have changed since, the number is stale: `traffic` is then null and `traffic_source` says so.
-    traffic, traffic_src = None, None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        if tj["workload"] == {"gaussians": P, "width": W, "height": H} and dominant in tj["per_launch_bytes"]:
-            if tj.get("csrc_sha16") == csrc_sha16():
-                traffic, traffic_src = tj["per_launch_bytes"][dominant], tj["source"]
-            else:
-                traffic_src = (f"stale: profiles/traffic_latest.json was measured on kernel sources {tj.get('csrc_sha16')}, "
-                               f"this build is {csrc_sha16()}")
-    except Exception:
-        pass
+    rows_per_view = bucket.last_counts if route["last"] == "rows" else None
+    extra = None
+    # (only next to the headline workload: a bench line of another workload -- tests, --ply, deep tiles -- stays short)
+    is_headline = args.ply is None and (P, W, H) == (1_000_000, 1920, 1080) and args.s0 == 0.01 and not batch_mode
+    if rank == 0 and world == 1 and is_headline and not (args.no_extra_configs or args.train_only or args.force_exchange):
+        del bucket
+        torch.cuda.empty_cache()
+        extra = extra_configs(dev, flags)
 
     if rank == 0:
-        iters_per_s = world * args.steps / train_s
-        renders_per_s = world * args.steps / fwd_s
+        iters_per_s = views * args.steps / train_s
         out = {
             "metric": "train iters/sec (fwd+bwd of one 1080p view per GPU + grad all-reduce), 1M Gaussians @1080p",
             "value": iters_per_s,
@@ -392,37 +657,51 @@ def main():
             "ms_per_step": 1e3 * train_s / args.steps,
             "step_ms_gpu": {"median": percentile(step_ms, 0.5), "p10": percentile(step_ms, 0.1), "p90": percentile(step_ms, 0.9),
                             "note": "HIP events around every timed step on the launch stream of rank 0"},
-            "forward_ms_gpu": {"median": percentile(fwd_ms, 0.5), "p10": percentile(fwd_ms, 0.1), "p90": percentile(fwd_ms, 0.9)},
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if batch_mode else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if args.ply is None else "file (scene) + synthetic cameras / pixel gradient",
-            "config": {"workload": (f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, one view per GPU "
-                                    "(BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)")
+            "config": {"workload": (f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, "
+                                    + (f"a fixed batch of {views} views per step dealt to the ranks" if batch_mode else "one view per GPU")
+                                    + " (BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)")
                        if args.ply is None else
                        (f"{os.path.basename(args.ply)}: {P} Gaussians SH{ply_degree} (M={M}) loaded from the reference's save_ply "
                         f"layout{' (fitted to the unit ball)' if args.ply_fit else ''}, {W}x{H}, ring-v1 8 views "
                         "(BASELINE.json configs[1] shape when the file is bicycle/point_cloud.ply)"),
-                       "gaussians": P, "width": W, "height": H, "views_per_step": world, "parallelism": f"dp{world}-views",
+                       "gaussians": P, "width": W, "height": H, "views_per_step": views, "views_per_rank": len(my_views),
+                       "parallelism": f"dp{world}-views",
                        "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
                        "synth_s0": args.s0,
                        "grad_exchange": exchange + (" (forced on one rank: development run)" if args.force_exchange else ""),
                        "grad_exchange_route": route["last"],
                        "grad_rows": "persistent: zero rows rewritten only when they do not hold zeros already (--persistent-grads)"
                        if args.persistent_grads else "every row of every gradient written every iteration",
-                       "grad_exchange_rows_per_view": bucket.last_counts if route["last"] == "rows" else None,
-                       "num_rendered": R, "visible": V, "sort_key_bits": int(L.gsr_sort_key_bits(W, H))},
-            "forward_renders_per_s": renders_per_s,
-            "forward_mpixels_per_s": renders_per_s * N / 1e6,
-            "forward_ms": 1e3 * fwd_s / args.steps,
-            "stage_ms": stage_ms,
-            "stage_algorithmic_bytes": ab,
-            "hbm_fraction_train_iter": (sum(ab.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src},
-            "cpu_baseline": cpu,
+                       "grad_exchange_rows_per_view": rows_per_view,
+                       "num_rendered": R, "visible": V, "pixel_instances": pix_inst,
+                       "sort_key_bits": int(_native.lib().gsr_sort_key_bits(W, H))},
         }
+        if multi_gpu is not None:
+            out["multi_gpu"] = multi_gpu
+        if not args.train_only:
+            renders_per_s = world * args.steps / fwd_s
+            dominant = max(stage_ms, key=stage_ms.get)
+            counters, src = load_counters(workload_key(P, W, H, args.s0)) if args.ply is None else (None, "not a synth-v1 workload")
+            out.update({
+                "forward_ms_gpu": {"median": percentile(fwd_ms, 0.5), "p10": percentile(fwd_ms, 0.1), "p90": percentile(fwd_ms, 0.9)},
+                "forward_renders_per_s": renders_per_s,
+                "forward_mpixels_per_s": renders_per_s * N / 1e6,
+                "forward_ms": 1e3 * fwd_s / args.steps,
+                "stage_ms": stage_ms,
+                "stage_algorithmic_bytes": ab,
+                "stage_compulsory_bytes": cb,
+                "hbm_fraction_train_iter": (len(my_views) * sum(cb.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
+                "hbm_fraction_train_iter_8d": (len(my_views) * sum(ab.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
+                "roofline": roofline_block(stage_ms, ab, cb, dominant, counters, src, dev, pix_inst),
+                "cpu_baseline": cpu,
+            })
+            if extra is not None:
+                out["extra_configs"] = extra
         print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

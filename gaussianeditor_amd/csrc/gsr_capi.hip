@@ -99,6 +99,32 @@ HostSlot* host_slot(hipStream_t stream, hipError_t* err) {
   return h;
 }
 
+// Guard against the one misuse of GSR_FLAG_FORWARD_ONLY that nothing on the device can report: a backward on a geometry
+// state whose gsr_preprocess skipped what only the backward reads.  gsr_preprocess notes (geom pointer -> forward-only?) in
+// a small fixed-size table, the backward entry points look their `geom` up and refuse with GSR_ERR_BAD_ARGUMENT instead of
+// reading uninitialised memory.  Best effort by construction -- an entry is overwritten by the next gsr_preprocess on the
+// same buffer and may be evicted by one on another buffer that hashes to its slot (then the misuse goes unnoticed, as it did
+// before); a state that was COPIED elsewhere is unknown.  No device work, no synchronisation.
+struct GeomNote {
+  const void* geom = nullptr;
+  bool forward_only = false;
+};
+constexpr size_t GEOM_NOTES = 1024;
+std::mutex g_notes_mutex;
+GeomNote g_notes[GEOM_NOTES];
+inline size_t note_slot(const void* p) { return (size_t)(((uintptr_t)p >> 8) * 0x9E3779B97F4A7C15ull >> 54) % GEOM_NOTES; }
+inline void note_geom(const void* geom, bool forward_only) {
+  std::lock_guard<std::mutex> lock(g_notes_mutex);
+  GeomNote& n = g_notes[note_slot(geom)];
+  n.geom = geom;
+  n.forward_only = forward_only;
+}
+inline bool geom_is_forward_only(const void* geom) {
+  std::lock_guard<std::mutex> lock(g_notes_mutex);
+  const GeomNote& n = g_notes[note_slot(geom)];
+  return n.geom == geom && n.forward_only;
+}
+
 // Which binning path an image takes (gsr_binning.hip): a function of the image size only, so that gsr_scratch_sizes,
 // gsr_preprocess, gsr_bin and the blend entry points of one view agree.  GSR_BIN_LEGACY=1 (tests) forces the pair sort.
 inline int bin_legacy(int W, int H) {
@@ -207,6 +233,7 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   a.tile_bounds = (flags & GSR_FLAG_TILE_BOUNDS_ALPHA) ? 1 : 0;
   a.radii = radii;
   a.g = carve_geom(geom, P);
+  note_geom(geom, a.forward_only != 0);
   GSR_HIP(launch_preprocess(s, a));
   // The one blocking readback of the path (reference: cudaMemcpy, rasterizer_impl.cu:236-239).  K1 already holds
   // num_rendered (and the range of the depth keys); the first kernel behind it -- the histogram of the first depth-sort
@@ -339,7 +366,8 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                        const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
                        float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags) {
-  if (flags & ~GSR_FLAG_ALL) return GSR_ERR_BAD_ARGUMENT;
+  // (a backward of a view whose forward was declared forward-only: the flags of one view travel together)
+  if ((flags & ~GSR_FLAG_ALL) || (flags & GSR_FLAG_FORWARD_ONLY)) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0) return GSR_OK;
   if (R == 0) {  // nothing to blend: the accumulators stay zero -- or become zero
     if (flags & GSR_FLAG_CLEAR_GRADS) {
@@ -379,6 +407,8 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
+  // this geometry state was left by gsr_preprocess(GSR_FLAG_FORWARD_ONLY): what K8+K9 reads of it was never written
+  if (shs && geom_is_forward_only(geom)) return GSR_ERR_BAD_ARGUMENT;
   if (!dL_dmeans2D || !dL_dconic || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
   if (shs && ((!dL_dsh && !dL_drgb) || !campos)) return GSR_ERR_BAD_ARGUMENT;
   if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;

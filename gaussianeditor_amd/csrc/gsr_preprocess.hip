@@ -193,25 +193,80 @@ __device__ __forceinline__ void sh_color_dir_derivatives(int D, float x, float y
 // Additionally produces the per-block sum of tiles_touched (first level of K2).
 // ----------------------------------------------------------------------------------
 
+// The SH records of a wave's 64 Gaussians, loaded WAVE-COOPERATIVELY (round 4): consecutive lanes read consecutive 16-byte
+// pieces of the 64 x 192-byte block (12 fully coalesced 1 KB loads), stage them in an LDS tile whose rows are 13 float4 apart
+// (conflict-free row reads), and every lane then picks up ITS row.  One row per thread straight from memory -- 12 dwordx4 at a
+// 192-byte stride between lanes -- runs at 4.55 TB/s whatever the occupancy (tools/microbench/rows192.hip); the rows of
+// culled Gaussians are not fetched (their pieces are redirected to a live row of the wave: a line that is fetched anyway).
+// NV = float4 needed per row for the active degree: 3 (D + 1)^2 floats = 3, 12, 27, 48 -> 1, 3, 7, 12.
+#ifndef GSR_K1_COOP_SH
+#define GSR_K1_COOP_SH 1  // 0: one row per thread (A/B builds)
+#endif
+constexpr int SH_ROW_F4 = 13;
+template <int NV>
+__device__ __forceinline__ void load_sh_rows_coop(const float* __restrict__ shs, int row0, int nrows, uint64_t live_mask,
+                                                  float4* __restrict__ tile, int lane, V3 (&sh)[16]) {
+  const float4* __restrict__ q = reinterpret_cast<const float4*>(shs) + (size_t)row0 * 12;
+  const int spare = (int)__builtin_ctzll(live_mask);  // a live row of this wave (the caller guarantees live_mask != 0)
+  float4 v[NV];
+  int dst[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int e = k * 64 + lane, r = e / NV, c = e - NV * r;  // piece c of row r
+    const bool want = r < nrows && ((live_mask >> r) & 1ull) != 0ull;
+    v[k] = q[(want ? r : spare) * 12 + c];  // unconditional (a predicated load makes hipcc wait at its issue point)
+    dst[k] = want ? r * SH_ROW_F4 + c : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (dst[k] >= 0) tile[dst[k]] = v[k];
+  __builtin_amdgcn_wave_barrier();
+  float f[48];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    if (i < NV) {
+      const float4 t = tile[lane * SH_ROW_F4 + i];
+      f[4 * i] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
+    } else {
+      f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) sh[k] = {f[3 * k], f[3 * k + 1], f[3 * k + 2]};
+  __builtin_amdgcn_wave_barrier();
+}
+
 // (70 VGPRs would allow 7 waves per SIMD; with one 192-byte SH row per thread that many waves thrash the caches --
-//  tools/microbench/rows192.hip: 4.55 TB/s at 2-4 waves per SIMD, 4.16 at 6, 3.24 at 8 -- so the kernel is held at 4: -3 us)
-__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_kernel(const PreArgs a) {
+//  tools/microbench/rows192.hip: 4.55 TB/s at 2-4 waves per SIMD, 4.16 at 6, 3.24 at 8 -- so the kernel is held at 4: -3 us.
+//  With the cooperative SH load the four 13 KB tiles of a block let three blocks share a CU: 3 waves per SIMD.)
+#if GSR_K1_COOP_SH
+#define GSR_K1_WAVES 3
+#else
+#define GSR_K1_WAVES 4
+#endif
+__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES, 4))) preprocess_kernel(const PreArgs a) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1], ssum[GAUSS_BLOCK / 64];
   __shared__ uint32_t skmax[2];
+#if GSR_K1_COOP_SH
+  __shared__ float4 sh_rows[GAUSS_BLOCK / 64][64 * SH_ROW_F4];
+#endif
   if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   uint32_t my_tiles = 0, my_groups = 0;  // tiles touched; 8x8-tile groups touched (gsr_binning.hip: group instances)
   uint32_t kmax = 0u, kinv = 0u;  // max of the depth key / of its complement over the visible Gaussians of the wave
+  Cam cam;
+  load_cam(cam, a.viewmatrix, a.projmatrix, a.skip_color || a.colors_precomp ? nullptr : a.campos);
+  const float* view = cam.view;
+  const float* proj = cam.proj;
+  // ---- geometry (forward.cu:182-237): everything up to the colour.  `live` = the Gaussian survives every cull.
+  bool live = false;
+  int my_radius_i = 0;
+  float my_depth = 0.f, my_radius = 0.f, conx = 0.f, cony = 0.f, conz = 0.f, pix = 0.f, piy = 0.f;
+  V3 p = {0.f, 0.f, 0.f};
+  uint2 my_rect = make_uint2(0u, 0u);  // tile rectangle (origin, width | height << 16); width * height == tiles_touched
   if (idx < a.P) {
-    Cam cam;
-    load_cam(cam, a.viewmatrix, a.projmatrix, a.skip_color || a.colors_precomp ? nullptr : a.campos);
-    const float* view = cam.view;
-    const float* proj = cam.proj;
-    int my_radius_i = 0;
-    float my_depth = 0.f;
-    uint2 my_rect = make_uint2(0u, 0u);  // tile rectangle (origin, width | height << 16); width * height == tiles_touched
     do {
-      const V3 p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+      p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       // in_frustum, auxiliary.h:139-164: only the near test survives
       const V3 p_view = {view[0] * p.x + view[4] * p.y + view[8] * p.z + view[12],
                          view[1] * p.x + view[5] * p.y + view[9] * p.z + view[13],
@@ -251,14 +306,16 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       const float det = (cx * cz - cy * cy);
       if (det == 0.0f) break;
       const float det_inv = 1.f / det;
-      const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+      conx = cz * det_inv;
+      cony = -cy * det_inv;
+      conz = cx * det_inv;
       const float mid = 0.5f * (cx + cz);
       const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
       const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-      const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+      my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
       // ndc2Pix in double, auxiliary.h:41-44
-      const float pix = (float)((((double)projx + 1.0) * (double)a.W - 1.0) * 0.5);
-      const float piy = (float)((((double)projy + 1.0) * (double)a.H - 1.0) * 0.5);
+      pix = (float)((((double)projx + 1.0) * (double)a.W - 1.0) * 0.5);
+      piy = (float)((((double)projy + 1.0) * (double)a.H - 1.0) * 0.5);
       uint32_t minx, miny, maxx, maxy;
       const int radius_i = f2i_sat(my_radius);
       get_rect(pix, piy, radius_i, a.gx, a.gy, minx, miny, maxx, maxy);
@@ -307,8 +364,34 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
         my_rect = make_uint2(minx | (miny << 16), (maxx - minx) | ((maxy - miny) << 16));
         my_groups = (((maxx - 1u) >> GROUP_SHIFT) - (minx >> GROUP_SHIFT) + 1u) * (((maxy - 1u) >> GROUP_SHIFT) - (miny >> GROUP_SHIFT) + 1u);
       }
-
-      // colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
+      my_radius_i = radius_i;
+      my_depth = p_view.z;
+      my_tiles = ntiles;
+      live = true;
+    } while (false);
+  }
+  // ---- colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
+  const bool from_sh = !a.skip_color && a.colors_precomp == nullptr;
+  V3 sh[16];
+#if GSR_K1_COOP_SH
+  const bool coop = from_sh && a.M == 16;  // (uniform) the standard 192-byte record
+  if (coop) {
+    const uint64_t live_mask = __ballot(live);
+    if (live_mask != 0ull) {
+      const int wv = (int)(threadIdx.x >> 6), row0 = (int)(blockIdx.x * GAUSS_BLOCK) + wv * 64;
+      const int nrows = min(64, a.P - row0), lane = lane_id();
+      switch (a.D) {  // (uniform)
+        case 0: load_sh_rows_coop<1>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
+        case 1: load_sh_rows_coop<3>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
+        case 2: load_sh_rows_coop<7>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
+        default: load_sh_rows_coop<12>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
+      }
+    }
+  }
+#else
+  const bool coop = false;
+#endif
+  if (live) {
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!a.skip_color) {
         if (a.colors_precomp != nullptr) {
@@ -319,8 +402,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
           V3 dir = {p.x - cam.campos[0], p.y - cam.campos[1], p.z - cam.campos[2]};
           const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
           dir = {dir.x / len, dir.y / len, dir.z / len};
-          V3 sh[16];
-          load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
+          if (!coop) load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
           V3 result = SH_C0 * sh[0];
           if (a.D > 0) {
             const float x = dir.x, y = dir.y, z = dir.z;
@@ -356,12 +438,10 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       }
       // forward.cu:250-255
       a.g.rec0[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
-      a.g.rec1[idx] = make_float4(pix, piy, p_view.z, my_radius);
+      a.g.rec1[idx] = make_float4(pix, piy, my_depth, my_radius);
       a.g.rec2[idx] = col;
-      my_radius_i = radius_i;
-      my_depth = p_view.z;
-      my_tiles = ntiles;
-    } while (false);
+  }
+  if (idx < a.P) {
     a.radii[idx] = my_radius_i;
     a.g.rect[idx] = my_tiles ? my_rect : make_uint2(0u, 0u);  // written for every Gaussian: the binning reads nothing else of it
     // key of the depth ordering (gsr_binning.hip): depth bits, culled Gaussians after every live one

@@ -39,7 +39,8 @@ import torch.distributed as dist
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 
-__all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step", "batch_loss_scale",
+__all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step", "multiview_batch_step", "views_of_rank",
+           "batch_loss_scale",
            "densify_synchronized", "replicas_identical"]
 
 import os as _os
@@ -111,6 +112,7 @@ class GradBucket:
         self._cap_hint = None  # message capacity the next touched-rows exchange speculates on (rows)
         self.last_route = None  # what the last multiview_step's exchange did: "local" | "rows" | "sparse" | "dense"
         self.last_counts = None  # touched rows per view, as gathered by the last touched-rows exchange
+        self.last_exchange = None  # multiview_batch_step: views, rows per message, bytes sent / received by this rank
         for name in slots:
             cnt = int(torch.Size(shapes[name]).numel())
             self.views[name] = self.flat[offs[name]:offs[name] + cnt].view(shapes[name])
@@ -334,6 +336,8 @@ def _exchange_touched_rows(bucket: GradBucket, group, n: int, force: bool) -> Op
     if recv is None or max(counts) > cap:
         cap = max(max(counts), 1)
         recv = send_messages(plan, cap)
+    bucket.last_exchange = {"views": n, "views_local": 1, "message_rows": int(cap), "bytes_sent": int(recv.shape[1]) * 4,
+                            "bytes_received": int(recv.numel()) * 4}
     sh = torch.empty((P, bucket.M, 3), dtype=torch.float32, device=dev)
     # one kernel: per Gaussian, the views' rows added in ascending view order (zeros where no view touched it)
     # (`sparse_rows` buckets: only for the Gaussians some view touched, marked in bucket.row_valid)
@@ -418,8 +422,17 @@ def allreduce_view_grads(bucket: GradBucket, radii: Optional[torch.Tensor] = Non
     return mode
 
 
+def _mark(marks, name, dev):
+    """`marks` (a dict, optional argument of the step functions): an event on the launch stream at the named point, so that a
+    caller (bench.py) can tell the local render time from the exchange time without adding any synchronisation."""
+    if marks is not None and dev.type == "cuda":
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(dev))
+        marks[name] = ev
+
+
 def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, torch.Tensor], dL_dcolor: torch.Tensor,
-                   bucket: GradBucket, group=None, rows="auto", sparse="auto", force_exchange: bool = False):
+                   bucket: GradBucket, group=None, rows="auto", sparse="auto", force_exchange: bool = False, marks=None):
     """One data-parallel iteration for this rank's view: forward, backward, gradient all-reduce.
     `params`: xyz, opacity, features, scaling, rotation (activated, as the rasterizer consumes them).
     After the call `bucket.views[...]` hold the batch-summed gradients on every rank and
@@ -451,11 +464,205 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
         raise
     finally:
         bucket.on_blend_done = None
+    _mark(marks, "local_done", bucket.flat.device)
     bucket.last_route = allreduce_view_grads(bucket, None, group, rows=rows, sparse=sparse, force_exchange=force_exchange)
     for batch_max, work in pending:
         work.wait()
         radii = batch_max
+    _mark(marks, "step_done", bucket.flat.device)
     return color, radii, depth, grads
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# K views on N ranks (round 4): the reference's batch loop, sharded
+# ----------------------------------------------------------------------------------------------------------------------
+def views_of_rank(num_views: int, world_size: int, rank: int) -> range:
+    """The contiguous block of global view indices rank `rank` renders when a batch of `num_views` views is dealt to
+    `world_size` ranks: views [r K / N, (r + 1) K / N) -- ranks in ascending order hold ascending views, so the ranks'
+    messages, concatenated in rank order by the all-gather, are the views in ascending global order."""
+    K, N, r = int(num_views), int(world_size), int(rank)
+    if N < 1 or not 0 <= r < N or K < N or K % N != 0:
+        raise ValueError("views_of_rank: need world_size >= 1, 0 <= rank < world_size and num_views a multiple of world_size")
+    per = K // N
+    return range(r * per, (r + 1) * per)
+
+
+def _relayout_message(src: torch.Tensor, P: int, cap_src: int, dst: torch.Tensor, cap_dst: int) -> None:
+    """Copy a packed view message laid out for `cap_src` rows into the layout for `cap_dst` >= its count (include/gsr.h:
+    header of 4 + ceil(P / 1024) words, then SoA segments of cap rows: index 1, means3D 3, scales 3, rotations 4, means2D 3,
+    opacities 1, rgb 3 words per row).  Rows beyond the count are padding on both sides."""
+    head = 4 + (int(P) + 1023) // 1024
+    dst[:head].copy_(src[:head])
+    n = min(int(cap_src), int(cap_dst))
+    off = 0
+    for w in (1, 3, 3, 4, 3, 1, 3):
+        dst[head + off * cap_dst: head + off * cap_dst + w * n].copy_(src[head + off * cap_src: head + off * cap_src + w * n])
+        off += w
+
+
+def multiview_batch_step(settings_list, params: Dict[str, torch.Tensor], dL_dcolor_list, bucket: GradBucket, group=None,
+                         marks=None):
+    """One iteration over a batch of K views of which THIS rank renders `settings_list` (its block of the batch, in ascending
+    global view order: `views_of_rank`) -- the reference's loop over `batch["camera"]` (threestudio/systems/GassuianEditor.py:
+    165-207: every view rendered, the gradients accumulated by autograd view after view, radii combined with torch.max
+    :175-178), sharded over the ranks of `group`.
+
+    Every local view is rendered forward + backward into the bucket and, before the next view overwrites it, packed into a
+    touched-rows message; the ranks all-gather their messages ONCE per step (rank order = global view order) and one kernel
+    adds all K messages per Gaussian in ascending view order (`gsr_view_messages_accumulate`).  The sums are therefore those
+    of a single process accumulating views 0 .. K - 1 one after the other, bit for bit, whatever N is -- including N = 1,
+    where nothing is communicated at all -- and identical on every replica.
+
+    The host never waits inside the loop over the views: the messages are sized by speculation (1.5 x the largest count of
+    the previous step), the plan of a view's touched rows runs on a side stream underneath its K8+K9, the pack kernel follows
+    on the launch stream behind a GPU-side wait, and the true counts -- every message's header carries its own -- are read
+    ONCE per step, after the all-gather has been enqueued and before the accumulate kernel.  A first step, and a step in
+    which some view outgrew the speculation (the same decision on every rank: it is taken from the gathered counts), runs
+    the exact form instead: one host read per view underneath that view's K8+K9, messages of exactly the needed size.
+
+    The bucket must be in the "rgb" exchange mode (the messages carry the colour gradient; the SH gradient is rebuilt).
+    Returns (colors, radii, depths, grads): lists for this rank's views, the batch-max radii, and the batch-summed gradients
+    (`bucket.views`).  `bucket.last_counts` holds the touched rows of all K views, `bucket.last_exchange` what was sent."""
+    k_local = len(settings_list)
+    if k_local < 1 or len(dL_dcolor_list) != k_local:
+        raise ValueError("multiview_batch_step: one pixel gradient per local view, at least one view")
+    if bucket.sh_exchange != "rgb":
+        raise RuntimeError('multiview_batch_step: construct the bucket with GradBucket(..., sh_exchange="rgb")')
+    out = None
+    if bucket._cap_hint is not None:
+        out = _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, int(bucket._cap_hint))
+    if out is None:  # no speculation yet, or it was too small: the exact form
+        out = _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, None)
+    return out
+
+
+def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spec_cap):
+    k_local = len(settings_list)
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    n = dist.get_world_size(group) if multi else 1
+    P, dev = bucket.P, bucket.flat.device
+    grads5 = [bucket.views[name] for name in _ROW_SEGS]
+    on_gpu = dev.type == "cuda"
+    speculate = spec_cap is not None
+    state = {}
+
+    def after_blend(acc4):  # between K7 and K8+K9 of a local view: mask + count on a side stream, underneath K8+K9
+        if not on_gpu:
+            plan, mine = _C.view_message_plan_blend(acc4)
+            state.update(plan=plan, count=mine, planned=None, done=None)
+            return
+        main = torch.cuda.current_stream(dev)
+        if bucket._side_stream is None:
+            bucket._side_stream = torch.cuda.Stream(device=dev)
+        side = bucket._side_stream
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            plan, mine = _C.view_message_plan_blend(acc4)
+            planned = torch.cuda.Event()
+            planned.record(side)
+            host, done = mine, None
+            if not speculate:
+                host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+                host.copy_(mine, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+        for t in plan[:2]:
+            if t is not None:
+                t.record_stream(main)
+        state.update(plan=plan, count=host, planned=planned, done=done)
+
+    cap = spec_cap
+    words = _C.view_message_words(P, cap) if speculate else 0
+    send = torch.empty((k_local, words), dtype=torch.float32, device=dev) if speculate else None
+    tight, counts, colors, depths = [], [], [], []
+    radii_max = None
+    bucket.on_blend_done = after_blend
+    try:
+        for v in range(k_local):
+            color, radii, depth, _ = render_view_grads(settings_list[v], params["xyz"], params["opacity"], params["features"],
+                                                       params["scaling"], params["rotation"], dL_dcolor_list[v], bucket)
+            colors.append(color)
+            depths.append(depth)
+            radii_max = radii.clone() if radii_max is None else torch.maximum(radii_max, radii, out=radii_max)
+            if state["planned"] is not None:
+                torch.cuda.current_stream(dev).wait_event(state["planned"])  # GPU-side: the pack kernel reads the plan
+            if speculate:
+                _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, cap, send[v])
+            else:
+                if state["done"] is not None:
+                    state["done"].synchronize()  # the side stream only: this view's K8+K9 still runs on the launch stream
+                c = max(int(state["count"].item()), 1)
+                counts.append(c)
+                m = torch.empty(_C.view_message_words(P, c), dtype=torch.float32, device=dev)
+                _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, c, m)
+                tight.append((m, c))
+    finally:
+        bucket.on_blend_done = None
+    _mark(marks, "local_done", dev)
+    recv = None
+    if speculate:
+        # the true counts sit in the messages' headers (word 3); the all-gather of the messages is enqueued BEFORE they are
+        # read, so the host's one wait of the step runs underneath the collective
+        mine = send[:, 3].contiguous().view(torch.int32).to(torch.int64)
+        if multi:
+            recv = torch.empty((n * k_local, words), dtype=torch.float32, device=dev)
+            if dist.get_backend(group) == "nccl":
+                dist.all_gather_into_tensor(recv, send, group=group)  # rank-major = global view order
+            else:
+                parts = [torch.empty_like(send) for _ in range(n)]
+                dist.all_gather(parts, send.contiguous(), group=group)
+                recv.copy_(torch.cat(parts))
+            all_counts = [int(c) for c in recv[:, 3].contiguous().view(torch.int32).tolist()]
+        else:
+            recv = send
+            all_counts = [int(c) for c in mine.tolist()]
+        if max(all_counts) > cap:
+            return None  # some message was cut short: every rank sees the same counts and re-runs the step in its exact form
+    else:
+        # all ranks agree on one capacity: the largest count of the whole batch (one tiny all-gather)
+        if multi:
+            mine = torch.tensor(counts, dtype=torch.int64, device=dev)
+            gathered = [torch.empty_like(mine) for _ in range(n)]
+            dist.all_gather(gathered, mine, group=group)
+            all_counts = [int(c) for c in torch.cat(gathered).tolist()]
+        else:
+            all_counts = list(counts)
+        cap = max(max(all_counts), 1)
+        words = _C.view_message_words(P, cap)
+        send = torch.empty((k_local, words), dtype=torch.float32, device=dev)
+        for v, (m, c) in enumerate(tight):
+            _relayout_message(m, P, c, send[v], cap)
+        if multi:
+            recv = torch.empty((n * k_local, words), dtype=torch.float32, device=dev)
+            if dist.get_backend(group) == "nccl":
+                dist.all_gather_into_tensor(recv, send, group=group)
+            else:
+                parts = [torch.empty_like(send) for _ in range(n)]
+                dist.all_gather(parts, send.contiguous(), group=group)
+                recv.copy_(torch.cat(parts))
+        else:
+            recv = send
+    if multi:
+        dist.all_reduce(radii_max, op=dist.ReduceOp.MAX, group=group)
+    bucket.last_counts = all_counts
+    bucket._cap_hint = (int(1.5 * max(max(all_counts), 1)) + 1023) // 1024 * 1024  # identical on every rank
+    sh = torch.empty((P, bucket.M, 3), dtype=torch.float32, device=dev)
+    _C.view_messages_accumulate(recv, P, cap, bucket.sh_degree, bucket.M, bucket.means3D_ref, grads5 + [sh],
+                                row_valid=bucket.row_valid)
+    bucket.views["sh"] = sh
+    if bucket.row_state is not None:
+        if bucket.row_valid is not None:
+            bucket.row_state.copy_(bucket.row_valid)
+        else:
+            bucket.invalidate_rows()
+    bucket.last_route = "rows"
+    bucket.last_exchange = {"views": n * k_local, "views_local": k_local, "message_rows": int(cap), "speculated": bool(speculate),
+                            "bytes_sent": int(send.numel() * 4) if multi else 0,
+                            "bytes_received": int(recv.numel() * 4) if multi else 0}
+    _mark(marks, "step_done", dev)
+    return colors, radii_max, depths, dict(bucket.views)
 
 
 # ----------------------------------------------------------------------------------------------------------------------

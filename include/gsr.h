@@ -89,7 +89,10 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *       work list, while that one workgroup runs: 14 us instead of 8 + 9 at 10^6 Gaussians, and one launch less);
  *   GSR_FLAG_FORWARD_ONLY (read by gsr_preprocess) no gsr_preprocess_backward / gsr_backward will be called on the geometry
  *       state this call leaves: the 48 bytes per Gaussian only the backward reads (the colour's derivative by the view
- *       direction) are neither computed nor written.  A backward on such a state reads uninitialised memory: the Python
+ *       direction) are neither computed nor written.  A backward on such a state would read uninitialised memory; it is
+ *       refused with GSR_ERR_BAD_ARGUMENT where the library can tell: when the flag is passed on to gsr_blend_backward /
+ *       gsr_backward, and when `geom` is the buffer the most recent gsr_preprocess on it left forward-only (a host-side
+ *       note per geometry buffer, no device read; a state copied to another buffer is not recognised).  The Python
  *       binding sets the flag exactly for renders none of whose inputs requires a gradient;
  *   GSR_FLAG_FAST_EXP    (read by the blend / trace entry points) exp(power) is evaluated with the hardware's
  *                        v_exp_f32 (2^x, 1 ulp) on power * log2(e) instead of the exactly specified polynomial

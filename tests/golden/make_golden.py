@@ -8,6 +8,9 @@ modules (only possible where /root/reference exists; the fixtures themselves are
                   Simple_Camera composition (scene/cameras.py:92-95) -> pins the host-side matrix conventions
 """
 import importlib.util
+import sys as _sys
+
+_sys.dont_write_bytecode = True  # the reference tree is read-only input: no __pycache__ there
 import math
 import os
 

@@ -146,3 +146,32 @@ def test_no_cpu_fallback():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "libgsr_oracle" not in src and "gsro_" not in src, f
+
+
+def test_forward_only_flag_is_refused_by_the_backward_entry_points():
+    """a backward declared with GSR_FLAG_FORWARD_ONLY is an argument error (checked before any device
+    work, so it runs here without a GPU); the buffer-level guard is covered on the GPU (test_gpu_round4.py)."""
+    import ctypes
+
+    from gaussianeditor_amd import _native
+
+    L = _native.lib()
+    one = ctypes.c_void_p(256)  # never dereferenced: the flags are rejected first
+    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, one, one, one, 8)
+    assert st == -1 and b"bad argument" in L.gsr_status_string(st)
+    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, one, one, one, 8 | 4)
+    assert st == -1
+
+
+def test_header_states_the_memory_and_alignment_contracts():
+    """The C-ABI footguns live in include/gsr.h, not only in the Makefile."""
+    hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    assert "coarse-grained" in hdr and "munsafe-fp-atomics" in hdr
+    assert "256-byte aligned" in hdr
+    assert "forward-only" in hdr and "GSR_ERR_BAD_ARGUMENT" in hdr
+
+
+def test_the_test_process_never_writes_bytecode_into_the_reference_tree():
+    import sys
+
+    assert sys.dont_write_bytecode and os.environ.get("PYTHONDONTWRITEBYTECODE") == "1"

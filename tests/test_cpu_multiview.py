@@ -504,3 +504,91 @@ def test_speculative_message_size_is_exact_when_it_overflows(oracle, tmp_path):
         want_sh = g["dL_dsh"].reshape(1500, 16, 3) if want_sh is None else want_sh + g["dL_dsh"].reshape(1500, 16, 3)
     for r in range(world):
         assert np.array_equal(z[r]["flat"], want_flat.astype(np.float32)) and np.array_equal(z[r]["sh"], want_sh.astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 4: a batch of K = 8 views on N = 1 / 2 / 4 ranks (the reference loops over the whole batch in one
+# process, threestudio/systems/GassuianEditor.py:165-207)
+# ----------------------------------------------------------------------------------------------------------------------
+KB = 8
+
+
+def _worker_batch(rank, world, port, out_dir, steps):
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pytest as _pt
+
+    import oracle_backend
+    from gaussianeditor_amd.multiview import GradBucket, multiview_batch_step, views_of_rank
+
+    mpatch = _pt.MonkeyPatch()
+    oracle_backend.install(mpatch)
+    try:
+        mine = list(views_of_rank(KB, world, rank))
+        cases = [make_case(P, W, H, seed=5, s0=0.05, view=v, nviews=KB) for v in mine]
+        sc = cases[0]["sc"]
+        params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+        bucket = GradBucket(P, 16, "cpu", sh_exchange="rgb")
+        for step in range(steps):  # (a second step runs on the speculated message size of the first)
+            if step == 2:  # a third step whose speculation is far too small: it must notice and re-run in the exact form
+                bucket._cap_hint = 16
+            Gs = [seed_gradient(H, W, 100 + v + 1000 * step) * H * W for v in mine]
+            colors, radii, depths, grads = multiview_batch_step([settings(c, "cpu") for c in cases], params, Gs, bucket)
+        assert len(colors) == len(mine) and bucket.last_route == "rows" and len(bucket.last_counts) == KB
+        assert bucket.last_exchange["speculated"] == (steps == 2)  # first step and overflowing step: exact; second: speculated
+        assert bucket.last_exchange["views"] == KB and bucket.last_exchange["views_local"] == len(mine)
+        np.savez(os.path.join(out_dir, f"batch_w{world}_r{rank}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
+                 radii=radii.numpy(), counts=np.array(bucket.last_counts))
+    finally:
+        mpatch.undo()
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_views_of_rank_deals_contiguous_ascending_blocks():
+    from gaussianeditor_amd.multiview import views_of_rank
+
+    for n in (1, 2, 4, 8):
+        dealt = [v for r in range(n) for v in views_of_rank(8, n, r)]
+        assert dealt == list(range(8))
+    with pytest.raises(ValueError):
+        views_of_rank(8, 3, 0)
+    with pytest.raises(ValueError):
+        views_of_rank(2, 4, 0)
+
+
+@pytest.mark.parametrize("steps", [1, 2, 3])
+def test_batch_of_eight_views_on_1_2_4_ranks_is_bit_identical_to_the_single_process_loop(oracle, tmp_path, steps):
+    out = {}
+    for world in (1, 2, 4):
+        if world == 1:
+            _worker_batch(0, 1, 0, str(tmp_path), steps)
+        else:
+            mp.spawn(_worker_batch, args=(world, _free_port(), str(tmp_path), steps), nprocs=world, join=True)
+        rs = [np.load(tmp_path / f"batch_w{world}_r{r}.npz") for r in range(world)]
+        for r in rs[1:]:  # replicas agree bit for bit
+            for k in ("flat", "sh", "radii", "counts"):
+                assert np.array_equal(rs[0][k], r[k]), (world, k)
+        out[world] = rs[0]
+    for world in (2, 4):  # ... and with the single process that rendered all eight views itself
+        for k in ("flat", "sh", "radii", "counts"):
+            assert np.array_equal(out[1][k], out[world][k]), (world, k)
+    # the single process's sums ARE the reference's loop: per-view gradients added one after the other, view 0 first
+    step = steps - 1
+    tot = sh = rad = None
+    for v in range(KB):
+        case = make_case(P, W, H, seed=5, s0=0.05, view=v, nviews=KB)
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v + 1000 * step) * H * W)
+        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dmeans2D",
+                                                          "dL_dopacity")])
+        tot = flat if tot is None else tot + flat
+        sh = g["dL_dsh"] if sh is None else sh + g["dL_dsh"]
+        rad = f["radii"] if rad is None else np.maximum(rad, f["radii"])
+    assert np.array_equal(out[1]["flat"], tot)
+    assert np.array_equal(out[1]["sh"], sh.reshape(out[1]["sh"].shape))
+    assert np.array_equal(out[1]["radii"], rad)
