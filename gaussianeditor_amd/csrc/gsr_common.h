@@ -38,10 +38,12 @@ struct Geom {
   float4* rec0;
   float4* rec1;
   float4* rec2;
-  // d(colour)/d(view direction) of the SH colour, one float4 per direction component (x, y, z; .w unused): K1 has the
-  // Gaussian's SH record in registers anyway, K8+K9 needs nothing else of it (backward.cu:88-136) -- 48 bytes stored and
-  // re-read instead of the 12 M-byte record streamed a second time (192 B at M = 16)
-  float4* dcol[3];
+  // d(colour)/d(view direction) of the SH colour, three floats per direction component (x, y, z): K1 has the
+  // Gaussian's SH record in registers anyway, K8+K9 needs nothing else of it (backward.cu:88-136) -- 36 bytes stored and
+  // re-read instead of the 12 M-byte record streamed a second time (192 B at M = 16).  Written only for Gaussians that
+  // survive every cull, only when the backward will run (GSR_FLAG_FORWARD_ONLY) and only for D > 0 (degree 0 has no
+  // direction dependence: K8+K9 takes zeros without reading).  Round 3 kept float4s (48 B).
+  float* dcol[3];
   uint2* rect;           // (P)     tile rectangle, written for every Gaussian: x = minx | miny << 16, y = width | height << 16 (0 if culled)
   uint8_t* clamped;      // (P)     bit ch set <=> SH colour channel ch was clamped at 0
   uint32_t* block_sums;  // (nb)    sum of tiles_touched per 256-Gaussian block, in DEPTH-SORTED Gaussian order
@@ -81,7 +83,7 @@ __host__ __device__ inline Geom carve_geom(void* base, int P) {
   g.rec0 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec1 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
   g.rec2 = (float4*)(p + off);         off += align_up(sizeof(float4) * (size_t)P);
-  for (int i = 0; i < 3; ++i) { g.dcol[i] = (float4*)(p + off); off += align_up(sizeof(float4) * (size_t)P); }
+  for (int i = 0; i < 3; ++i) { g.dcol[i] = (float*)(p + off); off += align_up(sizeof(float) * 3 * (size_t)P); }
   g.rect = (uint2*)(p + off);          off += align_up(sizeof(uint2) * (size_t)P);
   g.clamped = (uint8_t*)(p + off);     off += align_up((size_t)P);
   g.block_sums = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * nb);

@@ -39,7 +39,7 @@ struct PreBwdArgs {
   float scale_modifier;
   const float* cov3D_precomp;  // (P,6) or null: then recomputed from scales / rotations as K1 did (never stored)
   const uint8_t* clamped;
-  const float4* dcol[3];       // Geom::dcol: d(RGB)/d(dir) left by K1 (read instead of the SH record)
+  const float* dcol[3];        // Geom::dcol: d(RGB)/d(dir) left by K1, 3 floats per Gaussian each (read instead of the SH record)
   const float* viewmatrix;
   const float* projmatrix;
   const float* campos;

@@ -193,63 +193,15 @@ __device__ __forceinline__ void sh_color_dir_derivatives(int D, float x, float y
 // Additionally produces the per-block sum of tiles_touched (first level of K2).
 // ----------------------------------------------------------------------------------
 
-// The SH records of a wave's 64 Gaussians, loaded WAVE-COOPERATIVELY (round 4): consecutive lanes read consecutive 16-byte
-// pieces of the 64 x 192-byte block (12 fully coalesced 1 KB loads), stage them in an LDS tile whose rows are 13 float4 apart
-// (conflict-free row reads), and every lane then picks up ITS row.  One row per thread straight from memory -- 12 dwordx4 at a
-// 192-byte stride between lanes -- runs at 4.55 TB/s whatever the occupancy (tools/microbench/rows192.hip); the rows of
-// culled Gaussians are not fetched (their pieces are redirected to a live row of the wave: a line that is fetched anyway).
-// NV = float4 needed per row for the active degree: 3 (D + 1)^2 floats = 3, 12, 27, 48 -> 1, 3, 7, 12.
-#ifndef GSR_K1_COOP_SH
-#define GSR_K1_COOP_SH 1  // 0: one row per thread (A/B builds)
-#endif
-constexpr int SH_ROW_F4 = 13;
-template <int NV>
-__device__ __forceinline__ void load_sh_rows_coop(const float* __restrict__ shs, int row0, int nrows, uint64_t live_mask,
-                                                  float4* __restrict__ tile, int lane, V3 (&sh)[16]) {
-  const float4* __restrict__ q = reinterpret_cast<const float4*>(shs) + (size_t)row0 * 12;
-  const int spare = (int)__builtin_ctzll(live_mask);  // a live row of this wave (the caller guarantees live_mask != 0)
-  float4 v[NV];
-  int dst[NV];
-#pragma unroll
-  for (int k = 0; k < NV; ++k) {
-    const int e = k * 64 + lane, r = e / NV, c = e - NV * r;  // piece c of row r
-    const bool want = r < nrows && ((live_mask >> r) & 1ull) != 0ull;
-    v[k] = q[(want ? r : spare) * 12 + c];  // unconditional (a predicated load makes hipcc wait at its issue point)
-    dst[k] = want ? r * SH_ROW_F4 + c : -1;
-  }
-#pragma unroll
-  for (int k = 0; k < NV; ++k)
-    if (dst[k] >= 0) tile[dst[k]] = v[k];
-  __builtin_amdgcn_wave_barrier();
-  float f[48];
-#pragma unroll
-  for (int i = 0; i < 12; ++i) {
-    if (i < NV) {
-      const float4 t = tile[lane * SH_ROW_F4 + i];
-      f[4 * i] = t.x; f[4 * i + 1] = t.y; f[4 * i + 2] = t.z; f[4 * i + 3] = t.w;
-    } else {
-      f[4 * i] = f[4 * i + 1] = f[4 * i + 2] = f[4 * i + 3] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < 16; ++k) sh[k] = {f[3 * k], f[3 * k + 1], f[3 * k + 2]};
-  __builtin_amdgcn_wave_barrier();
-}
-
 // (70 VGPRs would allow 7 waves per SIMD; with one 192-byte SH row per thread that many waves thrash the caches --
 //  tools/microbench/rows192.hip: 4.55 TB/s at 2-4 waves per SIMD, 4.16 at 6, 3.24 at 8 -- so the kernel is held at 4: -3 us.
-//  With the cooperative SH load the four 13 KB tiles of a block let three blocks share a CU: 3 waves per SIMD.)
-#if GSR_K1_COOP_SH
-#define GSR_K1_WAVES 3
-#else
-#define GSR_K1_WAVES 4
-#endif
-__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(GSR_K1_WAVES, 4))) preprocess_kernel(const PreArgs a) {
+//  Round 4 measured the alternative K8+K9 uses for its stores -- the wave's 64 records loaded cooperatively, 12 coalesced
+//  1 KB loads into an LDS tile, every lane then reading its row -- on the same box: preprocess stage 139 -> 161 us at 1 M
+//  Gaussians, 602 -> 703 us at 6 M (the 53 KB of tiles leave three blocks per CU, and the rows cross LDS on top of the
+//  memory round trip): commit 4aadae3 holds it, profiles/r04_b_k1_and_chain.md the table.)
+__global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_kernel(const PreArgs a) {
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1], ssum[GAUSS_BLOCK / 64];
   __shared__ uint32_t skmax[2];
-#if GSR_K1_COOP_SH
-  __shared__ float4 sh_rows[GAUSS_BLOCK / 64][64 * SH_ROW_F4];
-#endif
   if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
   const int idx = (int)(blockIdx.x * GAUSS_BLOCK + threadIdx.x);
   uint32_t my_tiles = 0, my_groups = 0;  // tiles touched; 8x8-tile groups touched (gsr_binning.hip: group instances)
@@ -371,26 +323,6 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
     } while (false);
   }
   // ---- colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
-  const bool from_sh = !a.skip_color && a.colors_precomp == nullptr;
-  V3 sh[16];
-#if GSR_K1_COOP_SH
-  const bool coop = from_sh && a.M == 16;  // (uniform) the standard 192-byte record
-  if (coop) {
-    const uint64_t live_mask = __ballot(live);
-    if (live_mask != 0ull) {
-      const int wv = (int)(threadIdx.x >> 6), row0 = (int)(blockIdx.x * GAUSS_BLOCK) + wv * 64;
-      const int nrows = min(64, a.P - row0), lane = lane_id();
-      switch (a.D) {  // (uniform)
-        case 0: load_sh_rows_coop<1>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
-        case 1: load_sh_rows_coop<3>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
-        case 2: load_sh_rows_coop<7>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
-        default: load_sh_rows_coop<12>(a.shs, row0, nrows, live_mask, sh_rows[wv], lane, sh); break;
-      }
-    }
-  }
-#else
-  const bool coop = false;
-#endif
   if (live) {
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!a.skip_color) {
@@ -402,7 +334,8 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
           V3 dir = {p.x - cam.campos[0], p.y - cam.campos[1], p.z - cam.campos[2]};
           const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
           dir = {dir.x / len, dir.y / len, dir.z / len};
-          if (!coop) load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
+          V3 sh[16];
+          load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
           V3 result = SH_C0 * sh[0];
           if (a.D > 0) {
             const float x = dir.x, y = dir.y, z = dir.z;
@@ -421,12 +354,12 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
               }
             }
           }
-          if (!a.forward_only) {  // what the backward needs of the SH record (see Geom::dcol)
+          if (!a.forward_only && a.D > 0) {  // what the backward needs of the SH record (see Geom::dcol)
             V3 ddx, ddy, ddz;
             sh_color_dir_derivatives(a.D, dir.x, dir.y, dir.z, sh, ddx, ddy, ddz);
-            a.g.dcol[0][idx] = make_float4(ddx.x, ddx.y, ddx.z, 0.f);
-            a.g.dcol[1][idx] = make_float4(ddy.x, ddy.y, ddy.z, 0.f);
-            a.g.dcol[2][idx] = make_float4(ddz.x, ddz.y, ddz.z, 0.f);
+            *reinterpret_cast<V3*>(a.g.dcol[0] + 3 * (size_t)idx) = ddx;  // (12-byte records: one dwordx3 store each)
+            *reinterpret_cast<V3*>(a.g.dcol[1] + 3 * (size_t)idx) = ddy;
+            *reinterpret_cast<V3*>(a.g.dcol[2] + 3 * (size_t)idx) = ddz;
           }
           result = {result.x + 0.5f, result.y + 0.5f, result.z + 0.5f};
           a.g.clamped[idx] = (uint8_t)((result.x < 0 ? 1 : 0) | (result.y < 0 ? 2 : 0) | (result.z < 0 ? 4 : 0));
@@ -697,8 +630,13 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
       // d(RGB)/d(dir): K1 evaluated it from the SH record it held (sh_color_dir_derivatives) -- the record itself is not read
       // again (192 B per Gaussian at M = 16 against these 48)
-      const float4 d0 = a.dcol[0][idx], d1 = a.dcol[1][idx], d2 = a.dcol[2][idx];
-      const V3 dRGBdx = {d0.x, d0.y, d0.z}, dRGBdy = {d1.x, d1.y, d1.z}, dRGBdz = {d2.x, d2.y, d2.z};
+      // (degree 0: the colour does not depend on the direction, K1 wrote nothing)
+      V3 dRGBdx = {0.f, 0.f, 0.f}, dRGBdy = {0.f, 0.f, 0.f}, dRGBdz = {0.f, 0.f, 0.f};
+      if (a.D > 0) {
+        dRGBdx = *reinterpret_cast<const V3*>(a.dcol[0] + 3 * (size_t)idx);
+        dRGBdy = *reinterpret_cast<const V3*>(a.dcol[1] + 3 * (size_t)idx);
+        dRGBdz = *reinterpret_cast<const V3*>(a.dcol[2] + 3 * (size_t)idx);
+      }
       const uint8_t cl = a.clamped[idx];
       V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
       nonzero_in = nonzero_in || dL_dRGB.x != 0.f || dL_dRGB.y != 0.f || dL_dRGB.z != 0.f;

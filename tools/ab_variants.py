@@ -60,7 +60,7 @@ def main():
             if p.returncode != 0:
                 rows.append((name, None, "SMOKE FAILED: " + (p.stderr.strip().splitlines() or ["?"])[-1]))
                 continue
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--steps", steps, "--warmup", "10"]
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra-configs", "--steps", steps, "--warmup", "10"]
                            + extra, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         line = next((ln for ln in reversed(p.stdout.splitlines()) if ln.startswith("{")), None)
         if p.returncode != 0 or line is None:
