@@ -343,6 +343,8 @@ def main():
                     help="views per step of the WHOLE job (default 0 = one per GPU, weak scaling).  A multiple of --gpus: every "
                          "rank renders views/gpus views per step and the batch is fixed as N grows (strong scaling of "
                          "BASELINE configs[3]'s 8-view batch: --views 8)")
+    ap.add_argument("--no-view-pipeline", action="store_true",
+                    help="with --views: render a rank's views one after the other on one stream (A/B of the two-stream pipelining)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -406,6 +408,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 
+    # Several views per rank: multiview_batch_step pipelines successive views on two streams (view v + 1's forward under
+    # view v's backward); the persistent blend kernels then run 2 waves per SIMD instead of 4, which leaves register space
+    # for the other stream's kernels (tools/pipeline_probe.py: 0.61 -> 0.52 ms per view; both knobs are read once, at
+    # the library's / the module's first use, and neither changes a result).
+    if args.no_view_pipeline:
+        os.environ["GSR_VIEW_PIPELINE"] = "0"
+    elif batch_mode and views // world > 1:
+        os.environ.setdefault("GSR_BLEND_WAVES_PER_SIMD", "2")
     import gaussianeditor_amd
     from gaussianeditor_amd import _native
 
@@ -671,6 +681,8 @@ def main():
                         "(BASELINE.json configs[1] shape when the file is bicycle/point_cloud.ply)"),
                        "gaussians": P, "width": W, "height": H, "views_per_step": views, "views_per_rank": len(my_views),
                        "parallelism": f"dp{world}-views",
+                       "view_pipeline": bool(batch_mode and len(my_views) > 1 and not args.no_view_pipeline),
+                       "blend_waves_per_simd": int(os.environ.get("GSR_BLEND_WAVES_PER_SIMD", "4")),
                        "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
                        "synth_s0": args.s0,
                        "grad_exchange": exchange + (" (forced on one rank: development run)" if args.force_exchange else ""),

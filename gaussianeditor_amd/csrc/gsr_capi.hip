@@ -136,6 +136,17 @@ inline int bin_legacy(int W, int H) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return (forced || group_count(W, H) > GROUP_MAX || gx > RECT32_EDGE || gy > RECT32_EDGE) ? 1 : 0;
 }
+// Checkpoint stride of the forward blend in 64-entry chunks (GSR_CK_CHUNKS: tests use 1 or 2 to segment small scenes;
+// 0 turns checkpoints -- and with them the backward's list segments -- off).  Read once; never changes a result beyond the
+// backward's summation order.
+inline int checkpoint_chunks() {
+  static const int v = [] {
+    const char* e = getenv("GSR_CK_CHUNKS");
+    const int c = e != nullptr ? atoi(e) : CK_CHUNKS_DEFAULT;
+    return c < 0 ? 0 : (c > 1024 ? 1024 : c);
+  }();
+  return v;
+}
 // What the blend / export entry points need of the binning scratch sits in front of everything sized by the number of
 // group instances, so they carve with G = 0.
 inline Binning carve_binning_view(const void* binning, int64_t R, int W, int H) {
@@ -166,6 +177,11 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.final_T = im.final_T;
   a.n_contrib = im.n_contrib;
   a.queue = im.queue_heads + (size_t)queue_kind * QUEUE_LINES * QUEUE_STRIDE;
+  a.ck_table = im.ck_table;
+  a.ck_counter = im.ck_counter;
+  a.tile_maxc = im.tile_maxc;
+  a.ck_pool = im.ck_pool;
+  a.ck_chunks = checkpoint_chunks();
   return a;
 }
 }  // namespace
@@ -337,6 +353,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   a.final_T = nullptr;
   a.n_contrib = nullptr;
   a.work_est = nullptr;
+  a.ck_table = nullptr;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;

@@ -111,12 +111,24 @@ struct Image {
   uint32_t* work_order; // (T)  tile ids: non-empty tiles, longest list first (bucketed), then the empty tiles
   uint32_t* work_meta;  // [0] = number of non-empty tiles
   uint32_t* work_est;   // (T,4) entries the forward blend evaluated per (tile, quadrant): the backward's work estimate
-  uint32_t* bwd_order;  // (2T) items of the backward blend (a tile, or half of a heavy tile): most forward work first,
-                        //      tiles without any work dropped
+  uint32_t* bwd_order;  // (2T + CK_POOL) items of the backward blend (a tile, half of a heavy tile, or a list segment of a deep
+                        //      one): most forward work first, tiles without any work dropped
   uint32_t* bwd_meta;   // [0] = number of tiles in bwd_order
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
+  // Checkpoints of the forward blend (round 4): the backward can then walk a deep tile's list as independent SEGMENTS in
+  // separate work items.  The state of a pixel in front of list position k * stride (transmittance, accumulated colour)
+  // is one float4; a checkpoint of a tile is 256 of them (a pool slot).  Slots are handed out on demand by the forward
+  // (only tiles whose pixels are still live that deep ever take one).
+  uint32_t* ck_table;   // (T x CK_MAX) entry k >= 1: 1 + pool slot of the checkpoint in front of position k * stride; entry 0:
+                        //      the tile's FINAL state (transmittance, accumulated colour); 0 = none; > CK_POOL = pool exhausted
+  uint32_t* ck_counter; // [0] = pool slots handed out
+  uint32_t* tile_maxc;  // (T)  largest last-contributor position + 1 over the tile's pixels (what the backward walks)
+  float4* ck_pool;      // (CK_POOL x 256)
   size_t bytes;
 };
+constexpr int CK_MAX = 16;        // checkpoints per tile (beyond that depth the last segment is simply longer)
+constexpr int CK_POOL = 4096;     // pool slots (4 KB each: 16 MB)
+constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions)
 __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   char* p = (char*)base;
   const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -129,9 +141,13 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * T);
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 4 * T);
-  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * 2 * T);
+  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + 4096 /* CK_POOL */));
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
+  im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 16 /* CK_MAX */ * T);
+  im.ck_counter = (uint32_t*)(p + off); off += 256;
+  im.tile_maxc = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
+  im.ck_pool = (float4*)(p + off);      off += align_up(sizeof(float4) * 256 * 4096 /* CK_POOL */);
   im.bytes = off;
   return im;
 }

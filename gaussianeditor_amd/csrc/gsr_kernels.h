@@ -95,6 +95,12 @@ struct BlendArgs {
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
+  // forward checkpoints / backward list segments (Image::ck_*); ck_table == null: none (auxiliary render, tracing)
+  uint32_t* ck_table;
+  uint32_t* ck_counter;
+  uint32_t* tile_maxc;
+  float4* ck_pool;
+  int ck_chunks;   // checkpoint stride in 64-entry chunks
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile_items;  // debug (backward): 4 x u64 per (tile, half) after the workgroup records, or null
   uint64_t* profile;

@@ -45,6 +45,9 @@ __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview
 
 import os as _os
 
+#: GSR_VIEW_PIPELINE=0: multiview_batch_step renders its views one after the other on the launch stream (default: two streams)
+_VIEW_PIPELINE = _os.environ.get("GSR_VIEW_PIPELINE", "1") != "0"
+
 #: GSR_DEBUG_PERSISTENT_ROWS=1: every backward into a `persistent_rows` bucket first checks that rows marked "holds zeros" do
 _DEBUG_ROWS = _os.environ.get("GSR_DEBUG_PERSISTENT_ROWS", "0") == "1"
 
@@ -109,6 +112,7 @@ class GradBucket:
         self.on_blend_done = None
         self._pending_counts = None
         self._side_stream = None
+        self._view_streams = None  # multiview_batch_step: the two streams successive views alternate on
         self._cap_hint = None  # message capacity the next touched-rows exchange speculates on (rows)
         self.last_route = None  # what the last multiview_step's exchange did: "local" | "rows" | "sparse" | "dense"
         self.last_counts = None  # touched rows per view, as gathered by the last touched-rows exchange
@@ -196,23 +200,25 @@ class GradBucket:
         return {k: v for k, v in self.views.items() if self.sh_exchange == "direct" or k != "sh"}
 
 
-def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
-                      dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None, after_forward=None):
-    """Forward + backward of ONE view through the drop-in L1 API with `dL_dcolor` as the
-    pixel gradient.  Returns (color, radii, depth, grads) where grads has the six
-    rasterizer-input gradients (views of `bucket` when one is given).  `after_forward(radii)` is called between the
-    forward and the backward (multiview_step starts the radii's MAX all-reduce there, so that it overlaps the backward)."""
+def _view_forward(settings, means3D, opacities, shs, scales, rotations):
+    """Forward of one view through the drop-in L1 API -> (color, radii, depth, leaves): what `_view_backward` needs."""
     leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
     m3, sh, op, sc, rot = leaves
     # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
     # not zero-filled here (the reference's render() does: gaussian_renderer/__init__.py:60-69)
     m2 = torch.empty_like(m3).requires_grad_(True)
     color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
-    if after_forward is not None:
-        after_forward(radii)
+    return color, radii, depth, leaves + [m2]
+
+
+def _view_backward(settings, state, dL_dcolor, bucket):
+    """Backward of the view `_view_forward` rendered, with `dL_dcolor` as the pixel gradient -> the six rasterizer-input
+    gradients (views of `bucket` when one is given)."""
+    color, radii, depth, leaves = state
+    m3, sh, op, sc, rot, m2 = leaves
     if bucket is not None:
         bucket.attach(color)
-    # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by allreduce_view_grads)
+    # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by the exchange)
     g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
     grads = dict(zip(names, g))
@@ -230,6 +236,20 @@ def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacitie
         bucket.means3D_ref = m3.detach()
         bucket.campos = settings.campos.detach().reshape(3).to(torch.float32)
         grads["sh"] = None
+    return grads
+
+
+def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
+                      dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None, after_forward=None):
+    """Forward + backward of ONE view through the drop-in L1 API with `dL_dcolor` as the
+    pixel gradient.  Returns (color, radii, depth, grads) where grads has the six
+    rasterizer-input gradients (views of `bucket` when one is given).  `after_forward(radii)` is called between the
+    forward and the backward (multiview_step starts the radii's MAX all-reduce there, so that it overlaps the backward)."""
+    state = _view_forward(settings, means3D, opacities, shs, scales, rotations)
+    color, radii, depth, _ = state
+    if after_forward is not None:
+        after_forward(radii)
+    grads = _view_backward(settings, state, dL_dcolor, bucket)
     return color.detach(), radii, depth.detach(), grads
 
 
@@ -579,8 +599,50 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
     tight, counts, colors, depths = [], [], [], []
     radii_max = None
     bucket.on_blend_done = after_blend
+    # Two-stream VIEW PIPELINING (speculative form, several views on this rank): view v + 1's forward -- K1, the depth sort,
+    # the binning: one bandwidth kernel and a chain of small latency-bound ones -- is enqueued on the other stream right
+    # after view v's backward, whose K7 is bound by VALU issue, so the two overlap; the host blocks in the forward's one
+    # readback meanwhile.  The backward of view v + 1 waits (on the GPU) until view v's message has been packed: the bucket
+    # is the one buffer all backwards write.  Results do not depend on the schedule.  Measured on one MI355X
+    # (tools/pipeline_probe.py, profiles/r04_c_pipelining.md): 0.61 -> 0.52 ms per view with the blend kernels at 2 waves
+    # per SIMD, 1.13 -> 0.96 ms on deep tiles.  GSR_VIEW_PIPELINE=0 turns it off.
+    pipeline = speculate and on_gpu and k_local > 1 and _VIEW_PIPELINE
     try:
-        for v in range(k_local):
+        if pipeline:
+            main = torch.cuda.current_stream(dev)
+            if bucket._view_streams is None:
+                bucket._view_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            S = bucket._view_streams
+            for st_ in S:
+                st_.wait_stream(main)
+            args = (params["xyz"], params["opacity"], params["features"], params["scaling"], params["rotation"])
+            with torch.cuda.stream(S[0]):
+                fstate = _view_forward(settings_list[0], *args)
+            packed_prev, all_radii = None, []
+            for v in range(k_local):
+                with torch.cuda.stream(S[v % 2]):
+                    if packed_prev is not None:
+                        S[v % 2].wait_event(packed_prev)  # the bucket is free: view v - 1's message holds its rows
+                    _view_backward(settings_list[v], fstate, dL_dcolor_list[v], bucket)
+                    colors.append(fstate[0].detach())
+                    depths.append(fstate[2].detach())
+                    all_radii.append(fstate[1])
+                    if state["planned"] is not None:
+                        S[v % 2].wait_event(state["planned"])
+                    _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, cap, send[v])
+                    packed_prev = torch.cuda.Event()
+                    packed_prev.record(S[v % 2])
+                if v + 1 < k_local:
+                    with torch.cuda.stream(S[(v + 1) % 2]):
+                        fstate = _view_forward(settings_list[v + 1], *args)  # underneath view v's backward
+            for st_ in S:
+                main.wait_stream(st_)
+            radii_max = all_radii[0].clone()
+            for r in all_radii[1:]:
+                torch.maximum(radii_max, r, out=radii_max)
+            for t in colors + depths + all_radii:
+                t.record_stream(main)
+        for v in range(0 if not pipeline else k_local, k_local):
             color, radii, depth, _ = render_view_grads(settings_list[v], params["xyz"], params["opacity"], params["features"],
                                                        params["scaling"], params["rotation"], dL_dcolor_list[v], bucket)
             colors.append(color)
