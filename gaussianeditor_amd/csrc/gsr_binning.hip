@@ -683,11 +683,14 @@ __device__ __forceinline__ uint32_t group_local_rect(uint32_t x0, uint32_t y0, u
 // kernel's own work (+1.5 us there).
 __global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx, const Geom g, uint32_t* __restrict__ gkeys,
                                                                  uint32_t* __restrict__ vals, int nbg,
-                                                                 uint32_t* __restrict__ fill_dst, int64_t fill_n) {
+                                                                 uint32_t* __restrict__ fill_dst, int64_t fill_n,
+                                                                 uint4* __restrict__ zero_dst, int64_t zero_n4) {
   if ((int)blockIdx.x >= nbg) {
     const int64_t nb = (int64_t)gridDim.x - nbg, b = (int64_t)blockIdx.x - nbg;
     const int64_t n4 = fill_n / 4;  // (the key arrays are 256-byte aligned)
     uint4* const q = reinterpret_cast<uint4*>(fill_dst);
+    // (the forward blend's checkpoint table, its slot counter and the tiles' walk depths start every view at zero)
+    for (int64_t k = b * GAUSS_BLOCK + threadIdx.x; k < zero_n4; k += nb * GAUSS_BLOCK) zero_dst[k] = make_uint4(0u, 0u, 0u, 0u);
     for (int64_t k = b * GAUSS_BLOCK + threadIdx.x; k < n4; k += nb * GAUSS_BLOCK) q[k] = make_uint4(GROUP_PAD, GROUP_PAD, GROUP_PAD, GROUP_PAD);
     if (b == 0)
       for (int64_t k = 4 * n4 + threadIdx.x; k < fill_n; k += GAUSS_BLOCK) fill_dst[k] = GROUP_PAD;
@@ -1348,13 +1351,14 @@ static void launch_chunks(hipStream_t s, const Binning& b, const GroupArgs& a) {
   }
 }
 
+static int64_t checkpoint_state_words(const Image& im);
 template <int BITS>
 static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, const Geom& g, const Binning& b, const Image& im) {
   const int nbg = (P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   const int64_t padded = b.chunks * (int64_t)b.chunk;
   const int fill_blocks = 512;  // (two per CU: 5 MB of padding at 1 M Gaussians)
   hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg + fill_blocks), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0], nbg,
-                     b.gkey[1], padded);
+                     b.gkey[1], padded, reinterpret_cast<uint4*>(im.ck_table), checkpoint_state_words(im) / 4);
   const bool wide = b.sort_blocks <= SORT_WIDE_MAX_BLOCKS;  // few blocks: 1024 threads per block (see radix_sort_pairs)
   if (wide)
     hipLaunchKernelGGL((group_hist_kernel<BITS, 1024>), dim3(b.sort_blocks), dim3(1024), 0, s, (const uint32_t*)b.gkey[0], b.G,
@@ -1385,8 +1389,17 @@ static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, cons
   launch_chunks<true>(s, b, a);
 }
 
+// The words between Image::ck_table and the end of Image::tile_maxc (table, slot counter, walk depths: contiguous sections).
+static int64_t checkpoint_state_words(const Image& im) {
+  return (int64_t)((reinterpret_cast<const char*>(im.ck_pool) - reinterpret_cast<const char*>(im.ck_table)) / 4);
+}
+
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
+  if (R <= 0 || b.legacy) {  // (the grouped path clears the checkpoint state in its emit launch)
+    hipError_t e = hipMemsetAsync(im.ck_table, 0, sizeof(uint32_t) * (size_t)checkpoint_state_words(im), s);
+    if (e != hipSuccess) return e;
+  }
   if (R <= 0) {
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
     if (e != hipSuccess) return e;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
   // culling.  The item code passed on is quad | sub << 2, decoded by the item function.
   constexpr uint32_t split = (uint32_t)SPLIT;  // chosen by the launcher from the number of tiles of the image
   constexpr uint32_t per_tile = 4u * split;
-  auto run_item = [&](uint32_t x, uint32_t q) -> bool {
+  auto run_item = [&](uint32_t x, uint32_t q) __attribute__((always_inline)) -> bool {
     const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
     const uint32_t e_x = nempty > x ? (nempty - x + 7u) / 8u : 0u;
     if (q >= per_tile * n_x + e_x) return false;
@@ -342,10 +342,38 @@ struct ChunkWalker {
   }
 };
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
+
+// Pool slot (1-based) of checkpoint k of a tile, handed out on first demand: the waves of a tile (its quadrants, or the
+// sub-items of a cut quadrant) write their own pixels into ONE slot, so the first to arrive takes a slot from the pool and
+// publishes it with a compare-and-swap; a wave that loses the race uses the winner's (its own slot stays unused).  Values
+// above CK_POOL: the pool is exhausted, no checkpoint -- the backward then walks the tile in one piece.
+__device__ __forceinline__ uint32_t checkpoint_slot(const BlendArgs& a, uint32_t tile, uint32_t k) {
+  uint32_t v = 0;
+  if (lane_id() == 0) {
+    uint32_t* e = a.ck_table + (size_t)tile * CK_MAX + k;
+    v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v == 0u) {
+      // (checkpoint 1 takes TWO consecutive slots: the first holds the tile's FINAL state, written at the end of the item
+      //  by every wave that wrote a checkpoint -- no second table entry, no second resolve)
+      const uint32_t mine = __hip_atomic_fetch_add(a.ck_counter, k == 1u ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+      uint32_t expected = 0u;
+      const bool won = __hip_atomic_compare_exchange_strong(e, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+      v = won ? mine : expected;
+    }
+  }
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
+template <bool PROFILE, bool AUX, int SPLIT, bool FAST, bool CKPT>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
                                              uint64_t* prof_cyc) {
   PixelWave pw;
@@ -374,6 +402,14 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const f32x2 pfx2 = {pfx, pfx}, pfy2 = {pfy, pfy};
   f32x2 C01 = {0.f, 0.f}, C2D = {0.f, 0.f};  // (C0, C1), (C2, D)
+  // Checkpoints for the backward's list segments (Image::ck_*): in front of list position k * stride the state of every
+  // pixel that is still live -- transmittance and accumulated colour -- goes into the tile's slot k.  Only waves that walk
+  // that deep with live pixels ever do this (87 of the benchmark view's 1 633 tiles).
+  // (CKPT: a template switch, chosen per view by the host -- views with short lists run the kernel without any of this)
+  constexpr bool ckpt = CKPT && !AUX;
+  const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));  // pixel inside its tile
+  uint32_t ck_next = ckpt ? (uint32_t)a.ck_chunks : 0xffffffffu, ck_k = 1u;
+  uint32_t ck_first = 0u;  // the slot pair of checkpoint 1 (0: none written)
   auto stage = [&](uint32_t slot, float hA, float nB, float hC, float op, float x, float y, float z, float r, float g,
                    float b, float pos) {
     float* q = sp + (slot >> 1) * FWD_PAIR + (slot & 1u);
@@ -391,6 +427,20 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
     for (; walk.valid(); walk.advance()) {
       const uint64_t live_m = __ballot(!done);
       if (live_m == 0) break;
+      if (ckpt && walk.chunk == ck_next) {  // (uniform; never for walks shorter than the stride)
+        if (ck_k < (uint32_t)CK_MAX) {
+          const uint32_t slot = checkpoint_slot(a, (uint32_t)pw.tile, ck_k);
+          const uint32_t rec = ck_k == 1u ? slot + 1u : slot;  // (1-based pool slot of this checkpoint's records)
+          if (rec <= (uint32_t)CK_POOL) {
+            if (!done) a.ck_pool[(size_t)(rec - 1u) * (TILE * TILE) + pidx] = make_float4(T, C01.x, C01.y, C2D.x);
+            if (ck_k == 1u) ck_first = slot;
+            // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
+            if (lane == 0) atomicAdd(&a.ck_work[(size_t)pw.tile * CK_MAX + ck_k], evaluated);
+          }
+        }
+        ck_next += (uint32_t)a.ck_chunks;
+        ck_k++;
+      }
       uint64_t tc0 = 0;
       if (PROFILE) {
         tc0 = __builtin_amdgcn_s_memtime();
@@ -551,6 +601,13 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   const float C0 = C01.x, C1 = C01.y, C2 = C2D.x, D = C2D.y;
   // (the sub-items of a cut quadrant report the largest of their counts: they walk the same list)
   if (a.work_est != nullptr && lane == 0) atomicMax(&a.work_est[4u * tile + quad], evaluated);
+  if (ckpt) {
+    // how deep the backward will walk this tile, and -- for the pixels some checkpoint was written for -- the FINAL state
+    // (slot 0): with it a list segment's backward knows what lies behind its last position
+    const uint32_t deep = wave_max_u32(pw.inside ? last_contributor : 0u);
+    if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
+    if (ck_first != 0u && pw.inside) a.ck_pool[(size_t)(ck_first - 1u) * (TILE * TILE) + pidx] = make_float4(T, C0, C1, C2);
+  }
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
     if (a.final_T != nullptr) {  // (null in an auxiliary render: the state the backward needs stays that of the main one)
@@ -564,16 +621,18 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   }
 }
 
-template <bool PROFILE, bool AUX, int SPLIT, bool FAST>
+template <bool PROFILE, bool AUX, int SPLIT, bool FAST, bool CKPT>
 __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_forward_kernel(const BlendArgs a) {
   uint64_t t_start = 0;
   uint32_t prof_visited = 0, prof_items = 0;
   uint64_t prof_cyc[4] = {0, 0, 0, 0};
   if (PROFILE) t_start = __builtin_amdgcn_s_memtime();
-  run_work_queue<SPLIT>(a, true, [&](uint32_t tile, uint32_t quad, bool empty) {
+  // (always_inline: past a size threshold hipcc stops inlining the item function into the work loop's two call sites and
+  //  CALLS it -- the 300-byte argument block then travels through scratch memory)
+  run_work_queue<SPLIT>(a, true, [&](uint32_t tile, uint32_t quad, bool empty) __attribute__((always_inline)) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE, AUX, SPLIT, FAST>(a, tile, quad, prof_visited, prof_cyc);
+      forward_item<PROFILE, AUX, SPLIT, FAST, CKPT>(a, tile, quad, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
       for (uint32_t q = 0; q < 4; ++q) {
@@ -612,12 +671,6 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)
   }
 }
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-  return v;
-}
-
 // ----------------------------------------------------------------------------------
 // K7: renderCUDA (backward), DGR/cuda_rasterizer/backward.cu:399-557.
 // ----------------------------------------------------------------------------------
@@ -631,7 +684,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile (or two quadrants of a heavy one)
 constexpr uint32_t BWD_ITEM_HALF = 0x80000000u;   // item code: the workgroup handles one half of the tile ...
 constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead of {0,1}
-constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
+// ... or (round 4) ONE LIST SEGMENT of a deep tile: positions [seg * stride, (seg + 1) * stride) of its list, the last
+// segment up to the tile's deepest contributor.  The pixels that still contribute behind the segment start from the
+// forward's checkpoint in front of its upper end instead of from their final state (backward_tile).
+constexpr uint32_t BWD_ITEM_SEG = 0x10000000u;
+constexpr int BWD_SEG_SHIFT = 20, BWD_NSEG_SHIFT = 24;  // 4 bits each: segment index, number of segments - 1
+constexpr uint32_t BWD_ITEM_TILE = 0x000fffffu;   // (images of up to 2^20 tiles)
 
 
 // One tile, processed by a 4-wave workgroup (wave w = quadrant w).  The four waves walk the tile's list
@@ -641,7 +699,7 @@ constexpr uint32_t BWD_ITEM_TILE = 0x3fffffffu;
 // the CU.  The global float atomics execute at the memory side on this chip and were the largest single
 // cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
 // 2-3 of a tile's 4 quadrants.
-template <int ABLATE, bool FAST>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
+template <int ABLATE, bool FAST, bool SEG>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
 __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
                                               float4 (*s2)[WAVE], uint32_t* sid, float4* sco, float (*sacc)[WAVE],
                                               uint32_t* s_maxc) {
@@ -650,6 +708,8 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
   // the upper / lower 8x4 pixels of its two quadrants
   const bool half_item = (tile & BWD_ITEM_HALF) != 0u;
   const uint32_t part = (tile & BWD_ITEM_PART) ? 1u : 0u;
+  const bool seg_item = SEG && (tile & BWD_ITEM_SEG) != 0u;  // (SEG: a template switch -- the work list of a view without checkpoints holds no such item)
+  const uint32_t seg = (tile >> BWD_SEG_SHIFT) & 15u, nseg_m1 = (tile >> BWD_NSEG_SHIFT) & 15u;
   tile &= BWD_ITEM_TILE;
   PixelWave pw;
   const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
@@ -669,6 +729,11 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
   const uint32_t tile_max = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
   __syncthreads();
   if (tile_max == 0) return 0u;  // uniform over the workgroup
+  // the list positions this item walks: all of [0, tile_max), or one segment of them
+  const uint32_t stride = (uint32_t)a.ck_chunks * WAVE;
+  const uint32_t seg_lo = seg_item ? seg * stride : 0u;
+  const uint32_t seg_hi = (seg_item && seg != nseg_m1) ? min(tile_max, (seg + 1u) * stride) : tile_max;
+  if (seg_lo >= seg_hi) return 0u;  // (uniform)
 
   float dpx[3] = {0.f, 0.f, 0.f};
   if (live) {
@@ -685,9 +750,23 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
   float B_acc = 0.f, last_cdot = 0.f;  // sum_ch accum_rec[ch]*dL_dpixel[ch], sum_ch last_color[ch]*dL_dpixel[ch]
   float last_alpha = 0.f;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  if (seg_item && last_contributor > seg_hi) {
+    // This pixel still contributes BEHIND the segment: it enters at position seg_hi - 1 with the state the sequential walk
+    // would have there.  T in front of position seg_hi is the forward's checkpoint; the colour recurrence (accum_rec,
+    // backward.cu:515) at that point is the colour of everything behind, over that transmittance:
+    //   accum_rec = (C_final - C(seg_hi)) / T(seg_hi),  with nothing pending (last_alpha = 0).
+    const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
+    // (table entry k: 1-based pool slot of checkpoint k; entry 1 is a PAIR: the final state first, checkpoint 1 behind it)
+    const uint32_t s_fin = a.ck_table[(size_t)tile * CK_MAX + 1u];
+    const uint32_t s_ck = seg == 0u ? s_fin + 1u : a.ck_table[(size_t)tile * CK_MAX + seg + 1u];
+    const float4 ck = a.ck_pool[(size_t)(s_ck - 1u) * (TILE * TILE) + pidx];
+    const float4 fin = a.ck_pool[(size_t)(s_fin - 1u) * (TILE * TILE) + pidx];
+    T = ck.x;
+    B_acc = ((fin.y - ck.y) * dpx[0] + (fin.z - ck.z) * dpx[1] + (fin.w - ck.w) * dpx[2]) / ck.x;
+  }
 
-  // back to front over positions [0, tile_max) of the tile's list, all four waves in the same chunks
-  ChunkWalker<false> walk(a, range.x, tile_max);
+  // back to front over the item's positions [seg_lo, seg_hi) of the tile's list, all four waves in the same chunks
+  ChunkWalker<false> walk(a, range.x + seg_lo, seg_hi - seg_lo);
   for (; walk.valid(); walk.advance()) {
     __syncthreads();  // (A) the previous chunk's flush is complete: sacc is zero again, sid is free
     const uint32_t csize = walk.chunk_size();
@@ -695,10 +774,10 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
       sid[lane] = walk.cur.id;
       sco[lane] = walk.cur.r0;
     }
-    const uint32_t pos = walk.lane_pos();
+    const uint32_t pos = seg_lo + walk.lane_pos();
     // pixels that can still use an entry of this chunk: their last contributor lies above the chunk's lowest position;
     // the cull rectangle is their bounding box (the first chunks of a long list are walked for a few stragglers only)
-    const uint32_t chunk_lo = tile_max - min(tile_max, (walk.chunk + 1u) * (uint32_t)WAVE);
+    const uint32_t chunk_lo = seg_hi - min(seg_hi - seg_lo, (walk.chunk + 1u) * (uint32_t)WAVE);
     const uint64_t live_m = __ballot(last_contributor > chunk_lo);
     bool keep = false;
     if (live_m != 0) {
@@ -858,10 +937,10 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
       }
     }
   }
-  return tile_max;
+  return seg_hi - seg_lo;
 }
 
-template <int ABLATE, bool FAST>
+template <int ABLATE, bool FAST, bool SEG>
 __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[WAVE];
@@ -882,7 +961,7 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t tile) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    const uint32_t tmax = backward_tile<ABLATE, FAST>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
+    const uint32_t tmax = backward_tile<ABLATE, FAST, SEG>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
     if (prof) {
       const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
       if (a.profile_items != nullptr && threadIdx.x == 0 && a.work_est != nullptr) {
@@ -1025,7 +1104,7 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
 
 template <int C, int SPLIT, bool FAST>
 __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
-  run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) { trace_item<C, SPLIT, FAST>(a, tile, quad); });
+  run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) __attribute__((always_inline)) { trace_item<C, SPLIT, FAST>(a, tile, quad); });
 }
 
 // Work list of the backward blend: tiles ordered by the work the FORWARD blend measured for them (entries evaluated,
@@ -1047,10 +1126,14 @@ struct ClearArgs {
   float* ptr[4];
   long long n[4];  // floats
 };
+template <bool SEG>
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
                                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                                 uint32_t workgroups, int allow_halves,  // allow_halves: 0, or the threshold in 1/8 of a fair share
-                                                                const ClearArgs clear) {
+                                                                const ClearArgs clear, const uint32_t* __restrict__ tile_maxc,
+                                                                const uint32_t* __restrict__ ck_table,
+                                                                const uint32_t* __restrict__ ck_work, uint32_t stride,
+                                                                int seg_share) {  // seg_share: 0, or the threshold in 1/8 of a fair share
   if (blockIdx.x != 0) {
     const long long nb = (long long)gridDim.x - 1, b = (long long)blockIdx.x - 1;
 #pragma unroll
@@ -1083,7 +1166,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   constexpr int BWD_SUB = 16, NCNT = (BWD_BUCKETS + 1) * BWD_SUB;
   __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];
-  __shared__ uint32_t s_threshold;
+  __shared__ uint32_t s_threshold, s_seg_threshold;
   const uint32_t sub = threadIdx.x & (BWD_SUB - 1);
   for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
   // The kernel is one block between the forward and the backward blend, i.e. a chain of dependent round trips: the
@@ -1092,11 +1175,17 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   constexpr int EST_REG = 8;
   const bool in_regs = T <= 1024 * EST_REG;
   uint4 er[EST_REG];
+  uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
+  const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && stride != 0u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
     const int t = (int)threadIdx.x + 1024 * j;
     er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[t < T ? t : T - 1] : make_uint4(0u, 0u, 0u, 0u);
-    if (t >= T) er[j] = make_uint4(0u, 0u, 0u, 0u);
+    deep[j] = (in_regs && segments && T > 0) ? tile_maxc[t < T ? t : T - 1] : 0u;
+    if (t >= T) {
+      er[j] = make_uint4(0u, 0u, 0u, 0u);
+      deep[j] = 0u;
+    }
   }
   auto est_of = [&](int t, int j) -> uint4 { return in_regs ? er[j] : reinterpret_cast<const uint4*>(est)[t]; };
   // total work -> the weight above which a tile is cut
@@ -1112,10 +1201,36 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
   uint32_t total;
   (void)block_excl_scan_u32<1024>(mine, &total, smem);
-  if (threadIdx.x == 0)
+  if (threadIdx.x == 0) {
     s_threshold = allow_halves ? max(64u, (uint32_t)((uint64_t)total * (uint32_t)allow_halves / (8u * max(workgroups, 1u)))) : 0xffffffffu;
+    s_seg_threshold = segments ? max(64u, (uint32_t)((uint64_t)total * (uint32_t)seg_share / (8u * max(workgroups, 1u)))) : 0xffffffffu;
+  }
   __syncthreads();
-  const uint32_t threshold = s_threshold;
+  const uint32_t threshold = s_threshold, seg_threshold = s_seg_threshold;
+  // List segments: a tile the backward walks deeper than one checkpoint stride AND whose work is a sizeable share of a
+  // workgroup's becomes one item per stride, provided the forward left every checkpoint the segments start from (and the
+  // tile's final state); they run in different workgroups at the same time.  -> number of segments (1 = not cut).
+  auto segments_of = [&](int t, uint32_t w, uint32_t dp) -> uint32_t {
+    if (w < seg_threshold || dp <= stride) return 1u;
+    const uint32_t ns = min((dp + stride - 1u) / stride, (uint32_t)CK_MAX);
+    const uint32_t* row = ck_table + (size_t)t * CK_MAX;
+    const uint32_t* wrow = ck_work + (size_t)t * CK_MAX;
+    bool ok = true;
+    uint32_t prev = 0u, largest = 0u;
+    for (uint32_t k = 1; k < ns; ++k) {  // (entry 1 is a slot PAIR: final state + checkpoint 1)
+      const uint32_t v = row[k], at = min(wrow[k], w);
+      ok = ok && v != 0u && v + (k == 1u ? 1u : 0u) <= (uint32_t)CK_POOL;
+      largest = max(largest, at > prev ? at - prev : 0u);
+      prev = at;
+    }
+    largest = max(largest, w - prev);
+    // (a cut only pays if it really divides the work: a tile whose front segment holds nearly all of it stays whole)
+    return (ok && (uint64_t)largest * 5u <= (uint64_t)w * 4u) ? ns : 1u;
+  };
+  uint32_t nseg[EST_REG];
+#pragma unroll
+  for (int j = 0; j < EST_REG; ++j)
+    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y + er[j].z + er[j].w, deep[j]) : 1u;
   auto bucket_of = [](uint32_t w) -> uint32_t {
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
@@ -1125,16 +1240,28 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
 #pragma unroll
       for (int j = 0; j < EST_REG; ++j) {
         const int t = (int)threadIdx.x + 1024 * j;
-        if (t < T) fn(t, er[j]);
+        if (t < T) fn(t, er[j], nseg[j]);
       }
     } else {
-      for (int t = threadIdx.x; t < T; t += 1024) fn(t, reinterpret_cast<const uint4*>(est)[t]);
+      for (int t = threadIdx.x; t < T; t += 1024) {
+        const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u);
+      }
     }
   };
   (void)est_of;
-  for_each_tile([&](int, const uint4 e) {
+  // work of segment j of a cut tile: what the forward evaluated between checkpoints j and j + 1 (the front segment holds
+  // most of it: the deep positions of a list are walked for a few stragglers)
+  auto seg_work = [&](int t, uint32_t w, uint32_t ns, uint32_t j) -> uint32_t {
+    const uint32_t* row = ck_work + (size_t)t * CK_MAX;
+    const uint32_t lo = j == 0u ? 0u : min(row[j], w), hi = j + 1u == ns ? w : min(row[j + 1u], w);
+    return max(hi > lo ? hi - lo : 0u, 1u);
+  };
+  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
     const uint32_t w = e.x + e.y + e.z + e.w;
-    if (w >= threshold) {
+    if (ns > 1u) {
+      for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u);
+    } else if (w >= threshold) {
       atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
       atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u);
     } else {
@@ -1161,9 +1288,13 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  for_each_tile([&](int t, const uint4 e) {
+  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
     const uint32_t w = e.x + e.y + e.z + e.w;
-    if (w >= threshold) {
+    if (ns > 1u) {
+      for (uint32_t j = 0; j < ns; ++j)
+        order[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
+            (uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT);
+    } else if (w >= threshold) {
       order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
       order[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
     } else {
@@ -1232,18 +1363,22 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   const unsigned grid = blend_grid_size(false, s), quads = 4u * (unsigned)(a.gx * a.gy);
   const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
   const dim3 g(grid), b(WAVE);
-#define GSR_FWD_LAUNCH(AUXV, FASTV)                                                                        \
-  do {                                                                                                     \
-    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 1, FASTV>), g, b, 0, s, a);       \
-    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 2, FASTV>), g, b, 0, s, a);  \
-    else hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 4, FASTV>), g, b, 0, s, a);                  \
+#define GSR_FWD_LAUNCH(AUXV, FASTV, CKV)                                                                        \
+  do {                                                                                                          \
+    if (split == 1) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 1, FASTV, CKV>), g, b, 0, s, a);       \
+    else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 2, FASTV, CKV>), g, b, 0, s, a);  \
+    else hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 4, FASTV, CKV>), g, b, 0, s, a);                  \
   } while (0)
+  // checkpoints for the backward's list segments: only where the caller (gsr_capi.hip: segments_pay) handed the tables over
+  const bool ck = a.ck_table != nullptr && a.ck_chunks > 0 && a.colors3 == nullptr && !a.profile;
   if (a.profile)
-    hipLaunchKernelGGL((blend_forward_kernel<true, false, 1, false>), g, b, 0, s, a);
+    hipLaunchKernelGGL((blend_forward_kernel<true, false, 1, false, false>), g, b, 0, s, a);
   else if (a.colors3 != nullptr) {
-    if (a.fast_exp) GSR_FWD_LAUNCH(true, true); else GSR_FWD_LAUNCH(true, false);
+    if (a.fast_exp) GSR_FWD_LAUNCH(true, true, false); else GSR_FWD_LAUNCH(true, false, false);
+  } else if (ck) {
+    if (a.fast_exp) GSR_FWD_LAUNCH(false, true, true); else GSR_FWD_LAUNCH(false, false, true);
   } else {
-    if (a.fast_exp) GSR_FWD_LAUNCH(false, true); else GSR_FWD_LAUNCH(false, false);
+    if (a.fast_exp) GSR_FWD_LAUNCH(false, true, false); else GSR_FWD_LAUNCH(false, false, false);
   }
 #undef GSR_FWD_LAUNCH
   return hipGetLastError();
@@ -1254,6 +1389,9 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   a.units = (int)blend_units(BWD_WAVES, s);
   // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
   static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
+  // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
+  static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
+  bool seg_items = false;  // the work list holds list-segment items (views whose forward left checkpoints)
   ClearArgs clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
   if (a.clear_grads) {
     const long long P = a.P;
@@ -1265,8 +1403,18 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   if (own_list && a.work_est != nullptr) {
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
     const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : 0u;  // (1 .. 8 per CU: the same 14 us)
-    hipLaunchKernelGGL(backward_worklist_kernel, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est, a.bwd_order,
-                       a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear);
+    // GSR_BWD_SEG: tiles above this many eighths of a fair share are cut into list segments where the forward left
+    // checkpoints (0: never; tests use 1)
+    static const int seg_share = [] { const char* e = getenv("GSR_BWD_SEG"); return e ? atoi(e) : 5; }();
+    seg_items = a.ck_table != nullptr && a.ck_chunks > 0 && seg_share > 0 && ablate == 0;
+    if (seg_items)
+      hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
+                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear, (const uint32_t*)a.tile_maxc,
+                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, seg_share);
+    else
+      hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
+                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
     a.work_order = a.bwd_order;
     a.work_meta = a.bwd_meta;
   } else {
@@ -1276,18 +1424,21 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
       if (me != hipSuccess) return me;
     }
   }
-  // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
-  static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size(true, s) / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
-    case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false>), g, b, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false>), g, b, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((blend_backward_kernel<3, false>), g, b, 0, s, a); break;
-    case 4: hipLaunchKernelGGL((blend_backward_kernel<4, false>), g, b, 0, s, a); break;
+    case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false, false>), g, b, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false, false>), g, b, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((blend_backward_kernel<3, false, false>), g, b, 0, s, a); break;
+    case 4: hipLaunchKernelGGL((blend_backward_kernel<4, false, false>), g, b, 0, s, a); break;
     default:
-      if (a.fast_exp) hipLaunchKernelGGL((blend_backward_kernel<0, true>), g, b, 0, s, a);
-      else hipLaunchKernelGGL((blend_backward_kernel<0, false>), g, b, 0, s, a);
+      if (seg_items) {
+        if (a.fast_exp) hipLaunchKernelGGL((blend_backward_kernel<0, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((blend_backward_kernel<0, false, true>), g, b, 0, s, a);
+      } else {
+        if (a.fast_exp) hipLaunchKernelGGL((blend_backward_kernel<0, true, false>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((blend_backward_kernel<0, false, false>), g, b, 0, s, a);
+      }
       break;
   }
   return hipGetLastError();

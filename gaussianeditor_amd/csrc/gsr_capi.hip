@@ -155,8 +155,22 @@ inline Binning carve_binning_view(const void* binning, int64_t R, int W, int H) 
 // Scratch buffers are accessed with 16-byte vector loads at 256-byte aligned section offsets.
 inline bool misaligned(const void* p) { return ((uintptr_t)p & 255u) != 0; }
 
+// Do forward checkpoints / backward list segments pay for this view?  They shorten the backward's longest items where
+// lists are walked DEEP (deep-tile scenes: blend backward 449 -> 343 us); on views whose heavy tiles are dense rather than
+// deep they only cost (the benchmark view: +11 us in the backward, checkpoints written by 87 tiles).  The decision must be
+// the same in gsr_blend_forward and gsr_blend_backward of a view, so it is a function of what both receive: the mean list
+// length per tile, R / T (benchmark view 593, deep-tile scene 5 993).  GSR_CK_MIN_LIST overrides the threshold (tests: 0).
+inline bool segments_pay(int64_t R, int W, int H) {
+  static const int64_t min_list = [] {
+    const char* e = getenv("GSR_CK_MIN_LIST");
+    return e != nullptr ? (int64_t)atoll(e) : (int64_t)2048;
+  }();
+  const int64_t T = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  return checkpoint_chunks() > 0 && R >= min_list * T;
+}
+
 inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
-                                 int queue_kind) {
+                                 int queue_kind, int64_t R) {
   BlendArgs a;
   memset(&a, 0, sizeof(a));
   a.W = W;
@@ -177,11 +191,14 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.final_T = im.final_T;
   a.n_contrib = im.n_contrib;
   a.queue = im.queue_heads + (size_t)queue_kind * QUEUE_LINES * QUEUE_STRIDE;
-  a.ck_table = im.ck_table;
-  a.ck_counter = im.ck_counter;
-  a.tile_maxc = im.tile_maxc;
-  a.ck_pool = im.ck_pool;
-  a.ck_chunks = checkpoint_chunks();
+  if (segments_pay(R, W, H)) {
+    a.ck_table = im.ck_table;
+    a.ck_work = im.ck_work;
+    a.ck_counter = im.ck_counter;
+    a.tile_maxc = im.tile_maxc;
+    a.ck_pool = im.ck_pool;
+    a.ck_chunks = checkpoint_chunks();
+  }
   return a;
 }
 }  // namespace
@@ -329,7 +346,7 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0, R);
   a.out_color = out_color;
   a.out_depth = out_depth;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
@@ -345,7 +362,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0, R);
   a.colors3 = colors;
   a.out_color = out_color;
   a.out_depth = out_depth;
@@ -371,7 +388,7 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(image, W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 0, R);
   a.out_color = out_color;
   a.out_depth = out_depth;
   a.profile = records;
@@ -401,7 +418,7 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Image im = carve_image(const_cast<void*>(image), W, H);
   const Binning b = carve_binning_view(binning, R, W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1, R);
   a.dL_dpix = dL_dpix;
   a.dL_dmean2D = dL_dmeans2D;
   a.dL_dconic = dL_dconic;
@@ -466,7 +483,7 @@ int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int 
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1);
+  BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1, R);
   a.dL_dpix = dL_dpix;
   a.dL_dmean2D = dL_dmeans2D;
   a.dL_dconic = dL_dconic;
@@ -652,7 +669,7 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
-  BlendArgs a = make_blend_args(W, H, g, b, im, nullptr, 2);
+  BlendArgs a = make_blend_args(W, H, g, b, im, nullptr, 2, R);
   a.C = C;
   a.image_weights = image_weights;
   a.weights = weights;

@@ -119,8 +119,10 @@ struct Image {
   // separate work items.  The state of a pixel in front of list position k * stride (transmittance, accumulated colour)
   // is one float4; a checkpoint of a tile is 256 of them (a pool slot).  Slots are handed out on demand by the forward
   // (only tiles whose pixels are still live that deep ever take one).
-  uint32_t* ck_table;   // (T x CK_MAX) entry k >= 1: 1 + pool slot of the checkpoint in front of position k * stride; entry 0:
-                        //      the tile's FINAL state (transmittance, accumulated colour); 0 = none; > CK_POOL = pool exhausted
+  uint32_t* ck_table;   // (T x CK_MAX) entry k >= 1: 1 + pool slot of the checkpoint in front of position k * stride (entry 1: a PAIR
+                        //      of slots, the tile's FINAL state first); 0 = none; > CK_POOL = pool exhausted; entry 0 unused
+  uint32_t* ck_work;    // (T x CK_MAX) entry k: entries the forward had evaluated in the tile when it reached checkpoint k (summed
+                        //      over its quadrants): how a deep tile's backward work splits over its list segments
   uint32_t* ck_counter; // [0] = pool slots handed out
   uint32_t* tile_maxc;  // (T)  largest last-contributor position + 1 over the tile's pixels (what the backward walks)
   float4* ck_pool;      // (CK_POOL x 256)
@@ -145,6 +147,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
   im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 16 /* CK_MAX */ * T);
+  im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * 16 /* CK_MAX */ * T);
   im.ck_counter = (uint32_t*)(p + off); off += 256;
   im.tile_maxc = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
   im.ck_pool = (float4*)(p + off);      off += align_up(sizeof(float4) * 256 * 4096 /* CK_POOL */);

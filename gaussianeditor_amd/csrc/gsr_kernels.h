@@ -97,6 +97,7 @@ struct BlendArgs {
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
   // forward checkpoints / backward list segments (Image::ck_*); ck_table == null: none (auxiliary render, tracing)
   uint32_t* ck_table;
+  uint32_t* ck_work;
   uint32_t* ck_counter;
   uint32_t* tile_maxc;
   float4* ck_pool;

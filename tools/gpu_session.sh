@@ -1,10 +1,11 @@
 #!/bin/bash
 # Development / measurement session on the GPU box (run through gpurun from the repo root):
-#   gpurun --timeout 2400 -- 'bash tools/gpu_session.sh r03_f'
-# Writes everything under gpurun_out/<tag>_*: the -m gpu suite, smoke(), the bench lines (headline with cpu_baseline, deep
-# tiles, 6 M Gaussians, the two opt-in flags, the forced one-rank exchange), rocprofv3 kernel statistics + timelines, the PMC
-# passes (FETCH_SIZE / WRITE_SIZE separately, two SQ groups: never combined with any other trace domain), the local costs of
-# the exchange, the other BASELINE configurations and the densification surgery.
+#   gpurun --timeout 2700 -- 'bash tools/gpu_session.sh r04_s'
+# Writes everything under gpurun_out/<tag>_*: the -m gpu suite, smoke(), the bench lines (headline with cpu_baseline and
+# extra_configs, deep tiles, 6 M Gaussians, the fixed 8-view batch with and without view pipelining, the two opt-in flags, the
+# forced one-rank exchange), rocprofv3 kernel statistics + timelines for the three workloads, the PMC passes
+# (tools/gpu_counters.sh: FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU in separate runs, never combined with another trace
+# domain) BEFORE the bench lines that quote them, the other BASELINE configurations and the densification surgery.
 TAG=${1:-session}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -12,11 +13,14 @@ R=$GRAFT_REPO_ROOT
 O=gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $O/${TAG}_pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1
+bash tools/gpu_counters.sh ${TAG} > $O/${TAG}_counters.log 2>&1
 timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 timeout 300 python bench.py --steps 100 --s0 0.05 --no-cpu-baseline > $O/${TAG}_bench_deep_s005.json 2>> $O/${TAG}_bench.err
 timeout 300 python bench.py --steps 50 --gaussians 6000000 --no-cpu-baseline > $O/${TAG}_bench_6m.json 2>> $O/${TAG}_bench.err
-GSR_TILE_BOUNDS=alpha timeout 300 python bench.py --steps 100 --no-cpu-baseline > $O/${TAG}_bench_alpha_bounds.json 2>> $O/${TAG}_bench.err
-GSR_FAST_EXP=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline > $O/${TAG}_bench_fast_exp.json 2>> $O/${TAG}_bench.err
+timeout 300 python bench.py --views 8 --steps 50 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_views8.json 2>> $O/${TAG}_bench.err
+timeout 300 python bench.py --views 8 --steps 50 --warmup 10 --no-cpu-baseline --no-view-pipeline > $O/${TAG}_bench_views8_serial.json 2>> $O/${TAG}_bench.err
+GSR_TILE_BOUNDS=alpha timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_alpha_bounds.json 2>> $O/${TAG}_bench.err
+GSR_FAST_EXP=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_fast_exp.json 2>> $O/${TAG}_bench.err
 timeout 300 python bench.py --steps 100 --force-exchange --no-cpu-baseline > $O/${TAG}_bench_forced_exchange.json 2>> $O/${TAG}_bench.err
 prof() { # name, rocprof args ... -- bench args
   name=$1; shift
@@ -24,18 +28,15 @@ prof() { # name, rocprof args ... -- bench args
   (cd /tmp && timeout 400 rocprofv3 "$@" > /dev/null 2>&1)
   find $R/$O/$name -name "*.db" | head -1
 }
-DB=$(prof ${TAG}_kt --kernel-trace --stats -d $R/$O/${TAG}_kt -o p -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline)
-python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB -6 >> $O/${TAG}_kernel_stats.md 2>&1
-DB=$(prof ${TAG}_ktd --kernel-trace --stats -d $R/$O/${TAG}_ktd -o p -- python $R/bench.py --steps 10 --warmup 2 --s0 0.05 --no-cpu-baseline)
-python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_deep_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB -6 >> $O/${TAG}_deep_kernel_stats.md 2>&1
-DB=$(prof ${TAG}_ktx --kernel-trace --stats -d $R/$O/${TAG}_ktx -o p -- python $R/bench.py --steps 10 --warmup 2 --force-exchange --no-cpu-baseline)
-python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_forced_exchange_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB -6 >> $O/${TAG}_forced_exchange_kernel_stats.md 2>&1
-for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"; do
-  n=$(echo $grp | cut -d' ' -f1)
-  DB=$(prof ${TAG}_pmc_$n --kernel-trace --pmc $grp -d $R/$O/${TAG}_pmc_$n -o p -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline)
-  (echo "== $grp"; python tools/rocpd_pmc.py $DB) > $O/${TAG}_pmc_$n.txt 2>&1
-done
-rm -rf $O/${TAG}_kt $O/${TAG}_ktd $O/${TAG}_ktx $O/${TAG}_pmc_*/
+DB=$(prof ${TAG}_kt --kernel-trace --stats -d $R/$O/${TAG}_kt -o p -- python $R/bench.py --train-only --steps 10 --warmup 2)
+python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB 2 >> $O/${TAG}_kernel_stats.md 2>&1
+DB=$(prof ${TAG}_ktd --kernel-trace --stats -d $R/$O/${TAG}_ktd -o p -- python $R/bench.py --train-only --steps 10 --warmup 2 --s0 0.05)
+python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_deep_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB 2 >> $O/${TAG}_deep_kernel_stats.md 2>&1
+DB=$(prof ${TAG}_kt6 --kernel-trace --stats -d $R/$O/${TAG}_kt6 -o p -- python $R/bench.py --train-only --steps 10 --warmup 2 --gaussians 6000000)
+python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_6m_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB 2 >> $O/${TAG}_6m_kernel_stats.md 2>&1
+DB=$(prof ${TAG}_ktx --kernel-trace --stats -d $R/$O/${TAG}_ktx -o p -- python $R/bench.py --train-only --steps 10 --warmup 2 --force-exchange)
+python tools/rocpd_kernel_stats.py $DB > $O/${TAG}_forced_exchange_kernel_stats.md 2>&1; python tools/rocpd_timeline.py $DB 2 >> $O/${TAG}_forced_exchange_kernel_stats.md 2>&1
+rm -rf $O/${TAG}_kt $O/${TAG}_ktd $O/${TAG}_kt6 $O/${TAG}_ktx
 timeout 300 python tools/touched_fraction.py > $O/${TAG}_touched_fraction.txt 2>&1
 timeout 600 python tools/bench_configs.py > $O/${TAG}_other_configs.txt 2>&1
 timeout 300 python tools/bench_densify.py > $O/${TAG}_densify.txt 2>&1
@@ -43,4 +44,6 @@ timeout 120 python tools/bench_binning.py --oracle > $O/${TAG}_binning.txt 2>&1
 timeout 120 python tools/bench_binning.py --s0 0.05 >> $O/${TAG}_binning.txt 2>&1
 timeout 120 python tools/bench_binning.py --width 512 --height 512 >> $O/${TAG}_binning.txt 2>&1
 timeout 120 python tools/bench_binning.py --gaussians 6000000 >> $O/${TAG}_binning.txt 2>&1
+timeout 300 python tools/pipeline_probe.py > $O/${TAG}_pipeline.txt 2>&1
+GSR_BLEND_WAVES_PER_SIMD=2 timeout 300 python tools/pipeline_probe.py >> $O/${TAG}_pipeline.txt 2>&1
 tail -3 $O/${TAG}_pytest.txt; cat $O/${TAG}_smoke.txt | tail -2; tail -c 600 $O/${TAG}_bench.json
