@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) emit_groups_kernel(int P, int sgx
     const int64_t nb = (int64_t)gridDim.x - nbg, b = (int64_t)blockIdx.x - nbg;
     const int64_t n4 = fill_n / 4;  // (the key arrays are 256-byte aligned)
     uint4* const q = reinterpret_cast<uint4*>(fill_dst);
-    // (the forward blend's checkpoint table, its slot counter and the tiles' walk depths start every view at zero)
+    // (the forward blend's per-checkpoint work counts and the tiles' walk depths start every view at zero)
     for (int64_t k = b * GAUSS_BLOCK + threadIdx.x; k < zero_n4; k += nb * GAUSS_BLOCK) zero_dst[k] = make_uint4(0u, 0u, 0u, 0u);
     for (int64_t k = b * GAUSS_BLOCK + threadIdx.x; k < n4; k += nb * GAUSS_BLOCK) q[k] = make_uint4(GROUP_PAD, GROUP_PAD, GROUP_PAD, GROUP_PAD);
     if (b == 0)
@@ -790,7 +790,8 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
                                                             uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                             uint32_t* __restrict__ queues, uint32_t* __restrict__ est,
                                                             const uint32_t* __restrict__ tile_total,
-                                                            uint32_t* __restrict__ tile_start) {
+                                                            uint32_t* __restrict__ tile_start, uint32_t* __restrict__ ck_table,
+                                                            uint32_t n_ck_tiles) {
   // Counting sort of the tiles by bucket.  Most tiles of an image fall into a handful of buckets, and LDS atomics on one
   // address serialise, so every bucket has WORK_SUB counters (chosen by the thread's lane): the order inside a bucket is
   // free anyway, and the sort's time stops growing with the number of tiles per bucket.
@@ -899,8 +900,12 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
   }
   __syncthreads();
   for (int t = threadIdx.x; t < T; t += 1024) {
-    const uint32_t pos = atomicAdd(&cnt[bucket_of(len_of(t)) * WORK_SUB + sub], 1u);
+    const uint32_t len = len_of(t);
+    const uint32_t pos = atomicAdd(&cnt[bucket_of(len) * WORK_SUB + sub], 1u);
     order[pos] = (uint32_t)t;
+    // the tiles with the longest lists own checkpoint slots (Image::ck_table): the forward blend writes its state there
+    // every few hundred list positions, the backward walks such a tile's list as independent segments
+    ck_table[t] = (len != 0u && pos < n_ck_tiles) ? pos : CK_NONE;
   }
   // per-quadrant work counters of the forward blend (the items of a quadrant combine their counts with atomicMax)
   for (int i = threadIdx.x; i < 4 * T; i += 1024) est[i] = 0u;
@@ -1358,7 +1363,7 @@ static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, cons
   const int64_t padded = b.chunks * (int64_t)b.chunk;
   const int fill_blocks = 512;  // (two per CU: 5 MB of padding at 1 M Gaussians)
   hipLaunchKernelGGL(emit_groups_kernel, dim3(nbg + fill_blocks), dim3(GAUSS_BLOCK), 0, s, P, b.sgx, g, b.gkey[0], b.gval[0], nbg,
-                     b.gkey[1], padded, reinterpret_cast<uint4*>(im.ck_table), checkpoint_state_words(im) / 4);
+                     b.gkey[1], padded, reinterpret_cast<uint4*>(im.ck_work), checkpoint_state_words(im) / 4);
   const bool wide = b.sort_blocks <= SORT_WIDE_MAX_BLOCKS;  // few blocks: 1024 threads per block (see radix_sort_pairs)
   if (wide)
     hipLaunchKernelGGL((group_hist_kernel<BITS, 1024>), dim3(b.sort_blocks), dim3(1024), 0, s, (const uint32_t*)b.gkey[0], b.G,
@@ -1385,26 +1390,28 @@ static void launch_grouped(hipStream_t s, int P, int64_t R, int gx, int gy, cons
   hipLaunchKernelGGL(group_colscan_kernel, dim3(b.groups), dim3(COLSCAN_WAVES * 64), 0, s, gx, gy, b.sgx,
                      (const uint32_t*)b.group_first, (const uint16_t*)b.chunk_cnt, b.chunk_pre, b.tile_total);
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(2), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                     im.queue_heads, im.work_est, (const uint32_t*)b.tile_total, b.tile_start);
+                     im.queue_heads, im.work_est, (const uint32_t*)b.tile_total, b.tile_start, im.ck_table,
+                     (uint32_t)ck_tiles((size_t)gx * gy));
   launch_chunks<true>(s, b, a);
 }
 
-// The words between Image::ck_table and the end of Image::tile_maxc (table, slot counter, walk depths: contiguous sections).
+// The words between Image::ck_work and the end of Image::tile_maxc (work split, walk depths: contiguous sections).
 static int64_t checkpoint_state_words(const Image& im) {
-  return (int64_t)((reinterpret_cast<const char*>(im.ck_pool) - reinterpret_cast<const char*>(im.ck_table)) / 4);
+  return (int64_t)((reinterpret_cast<const char*>(im.ck_pool) - reinterpret_cast<const char*>(im.ck_work)) / 4);
 }
 
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   if (R <= 0 || b.legacy) {  // (the grouped path clears the checkpoint state in its emit launch)
-    hipError_t e = hipMemsetAsync(im.ck_table, 0, sizeof(uint32_t) * (size_t)checkpoint_state_words(im), s);
+    hipError_t e = hipMemsetAsync(im.ck_work, 0, sizeof(uint32_t) * (size_t)checkpoint_state_words(im), s);
     if (e != hipSuccess) return e;
   }
   if (R <= 0) {
     hipError_t e = hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                       im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                       im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr, im.ck_table,
+                       (uint32_t)ck_tiles((size_t)gx * gy));
     return hipGetLastError();
   }
   if (!b.legacy) {
@@ -1426,7 +1433,8 @@ hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const G
     hipLaunchKernelGGL(tile_ranges_kernel<uint32_t>, gr, dim3(256), 0, s, R, (const uint32_t*)tk[b.final_buf], im.ranges);
   }
   hipLaunchKernelGGL(tile_worklist_kernel, dim3(1), dim3(1024), 0, s, gx * gy, im.ranges, im.work_order, im.work_meta,
-                     im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                     im.queue_heads, im.work_est, (const uint32_t*)nullptr, (uint32_t*)nullptr, im.ck_table,
+                     (uint32_t)ck_tiles((size_t)gx * gy));
   return hipGetLastError();
 }
 

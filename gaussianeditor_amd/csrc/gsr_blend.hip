@@ -348,28 +348,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
-// Pool slot (1-based) of checkpoint k of a tile, handed out on first demand: the waves of a tile (its quadrants, or the
-// sub-items of a cut quadrant) write their own pixels into ONE slot, so the first to arrive takes a slot from the pool and
-// publishes it with a compare-and-swap; a wave that loses the race uses the winner's (its own slot stays unused).  Values
-// above CK_POOL: the pool is exhausted, no checkpoint -- the backward then walks the tile in one piece.
-__device__ __forceinline__ uint32_t checkpoint_slot(const BlendArgs& a, uint32_t tile, uint32_t k) {
-  uint32_t v = 0;
-  if (lane_id() == 0) {
-    uint32_t* e = a.ck_table + (size_t)tile * CK_MAX + k;
-    v = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v == 0u) {
-      // (checkpoint 1 takes TWO consecutive slots: the first holds the tile's FINAL state, written at the end of the item
-      //  by every wave that wrote a checkpoint -- no second table entry, no second resolve)
-      const uint32_t mine = __hip_atomic_fetch_add(a.ck_counter, k == 1u ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-      uint32_t expected = 0u;
-      const bool won = __hip_atomic_compare_exchange_strong(e, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-      v = won ? mine : expected;
-    }
-  }
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
-
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
@@ -403,13 +381,13 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   const f32x2 pfx2 = {pfx, pfx}, pfy2 = {pfy, pfy};
   f32x2 C01 = {0.f, 0.f}, C2D = {0.f, 0.f};  // (C0, C1), (C2, D)
   // Checkpoints for the backward's list segments (Image::ck_*): in front of list position k * stride the state of every
-  // pixel that is still live -- transmittance and accumulated colour -- goes into the tile's slot k.  Only waves that walk
-  // that deep with live pixels ever do this (87 of the benchmark view's 1 633 tiles).
+  // pixel that is still live -- transmittance and accumulated colour -- goes into the tile's slot k (one 16-byte store per
+  // lane and one atomic per wave: the slots are assigned by tile_worklist_kernel, nothing is allocated here).
   // (CKPT: a template switch, chosen per view by the host -- views with short lists run the kernel without any of this)
   constexpr bool ckpt = CKPT && !AUX;
   const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));  // pixel inside its tile
-  uint32_t ck_next = ckpt ? (uint32_t)a.ck_chunks : 0xffffffffu, ck_k = 1u;
-  uint32_t ck_first = 0u;  // the slot pair of checkpoint 1 (0: none written)
+  const uint32_t ck_base = ckpt ? a.ck_table[tile] : CK_NONE;  // rank of the tile among the checkpointed ones
+  uint32_t ck_next = (ckpt && ck_base != CK_NONE) ? (uint32_t)a.ck_chunks : 0xffffffffu, ck_k = 1u;
   auto stage = [&](uint32_t slot, float hA, float nB, float hC, float op, float x, float y, float z, float r, float g,
                    float b, float pos) {
     float* q = sp + (slot >> 1) * FWD_PAIR + (slot & 1u);
@@ -429,14 +407,9 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       if (live_m == 0) break;
       if (ckpt && walk.chunk == ck_next) {  // (uniform; never for walks shorter than the stride)
         if (ck_k < (uint32_t)CK_MAX) {
-          const uint32_t slot = checkpoint_slot(a, (uint32_t)pw.tile, ck_k);
-          const uint32_t rec = ck_k == 1u ? slot + 1u : slot;  // (1-based pool slot of this checkpoint's records)
-          if (rec <= (uint32_t)CK_POOL) {
-            if (!done) a.ck_pool[(size_t)(rec - 1u) * (TILE * TILE) + pidx] = make_float4(T, C01.x, C01.y, C2D.x);
-            if (ck_k == 1u) ck_first = slot;
-            // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
-            if (lane == 0) atomicAdd(&a.ck_work[(size_t)pw.tile * CK_MAX + ck_k], evaluated);
-          }
+          if (!done) a.ck_pool[((size_t)ck_base * CK_MAX + ck_k) * (TILE * TILE) + pidx] = make_float4(T, C01.x, C01.y, C2D.x);
+          // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
+          if (lane == 0) atomicAdd(&a.ck_work[(size_t)tile * CK_MAX + ck_k], evaluated);
         }
         ck_next += (uint32_t)a.ck_chunks;
         ck_k++;
@@ -606,7 +579,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
     // (slot 0): with it a list segment's backward knows what lies behind its last position
     const uint32_t deep = wave_max_u32(pw.inside ? last_contributor : 0u);
     if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
-    if (ck_first != 0u && pw.inside) a.ck_pool[(size_t)(ck_first - 1u) * (TILE * TILE) + pidx] = make_float4(T, C0, C1, C2);
+    if (ck_k > 1u && pw.inside) a.ck_pool[(size_t)ck_base * CK_MAX * (TILE * TILE) + pidx] = make_float4(T, C0, C1, C2);
   }
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
@@ -756,11 +729,9 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
     // backward.cu:515) at that point is the colour of everything behind, over that transmittance:
     //   accum_rec = (C_final - C(seg_hi)) / T(seg_hi),  with nothing pending (last_alpha = 0).
     const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
-    // (table entry k: 1-based pool slot of checkpoint k; entry 1 is a PAIR: the final state first, checkpoint 1 behind it)
-    const uint32_t s_fin = a.ck_table[(size_t)tile * CK_MAX + 1u];
-    const uint32_t s_ck = seg == 0u ? s_fin + 1u : a.ck_table[(size_t)tile * CK_MAX + seg + 1u];
-    const float4 ck = a.ck_pool[(size_t)(s_ck - 1u) * (TILE * TILE) + pidx];
-    const float4 fin = a.ck_pool[(size_t)(s_fin - 1u) * (TILE * TILE) + pidx];
+    const size_t slot0 = (size_t)a.ck_table[tile] * CK_MAX;  // (slot 0: the final state; slot k: in front of position k * stride)
+    const float4 ck = a.ck_pool[(slot0 + seg + 1u) * (TILE * TILE) + pidx];
+    const float4 fin = a.ck_pool[slot0 * (TILE * TILE) + pidx];
     T = ck.x;
     B_acc = ((fin.y - ck.y) * dpx[0] + (fin.z - ck.z) * dpx[1] + (fin.w - ck.w) * dpx[2]) / ck.x;
   }
@@ -1208,24 +1179,21 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   __syncthreads();
   const uint32_t threshold = s_threshold, seg_threshold = s_seg_threshold;
   // List segments: a tile the backward walks deeper than one checkpoint stride AND whose work is a sizeable share of a
-  // workgroup's becomes one item per stride, provided the forward left every checkpoint the segments start from (and the
-  // tile's final state); they run in different workgroups at the same time.  -> number of segments (1 = not cut).
+  // workgroup's becomes one item per stride, provided it owns checkpoint slots (the forward then left the state every
+  // segment starts from); they run in different workgroups at the same time.  -> number of segments (1 = not cut).
   auto segments_of = [&](int t, uint32_t w, uint32_t dp) -> uint32_t {
-    if (w < seg_threshold || dp <= stride) return 1u;
+    if (w < seg_threshold || dp <= stride || ck_table[t] == CK_NONE) return 1u;
     const uint32_t ns = min((dp + stride - 1u) / stride, (uint32_t)CK_MAX);
-    const uint32_t* row = ck_table + (size_t)t * CK_MAX;
     const uint32_t* wrow = ck_work + (size_t)t * CK_MAX;
-    bool ok = true;
     uint32_t prev = 0u, largest = 0u;
-    for (uint32_t k = 1; k < ns; ++k) {  // (entry 1 is a slot PAIR: final state + checkpoint 1)
-      const uint32_t v = row[k], at = min(wrow[k], w);
-      ok = ok && v != 0u && v + (k == 1u ? 1u : 0u) <= (uint32_t)CK_POOL;
+    for (uint32_t k = 1; k < ns; ++k) {
+      const uint32_t at = min(wrow[k], w);
       largest = max(largest, at > prev ? at - prev : 0u);
       prev = at;
     }
     largest = max(largest, w - prev);
     // (a cut only pays if it really divides the work: a tile whose front segment holds nearly all of it stays whole)
-    return (ok && (uint64_t)largest * 5u <= (uint64_t)w * 4u) ? ns : 1u;
+    return (uint64_t)largest * 5u <= (uint64_t)w * 4u ? ns : 1u;
   };
   uint32_t nseg[EST_REG];
 #pragma unroll
@@ -1369,7 +1337,7 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
     else if (split == 2) hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 2, FASTV, CKV>), g, b, 0, s, a);  \
     else hipLaunchKernelGGL((blend_forward_kernel<false, AUXV, 4, FASTV, CKV>), g, b, 0, s, a);                  \
   } while (0)
-  // checkpoints for the backward's list segments: only where the caller (gsr_capi.hip: segments_pay) handed the tables over
+  // checkpoints for the backward's list segments: where the caller handed the tables over (gsr_capi.hip: checkpoint_chunks)
   const bool ck = a.ck_table != nullptr && a.ck_chunks > 0 && a.colors3 == nullptr && !a.profile;
   if (a.profile)
     hipLaunchKernelGGL((blend_forward_kernel<true, false, 1, false, false>), g, b, 0, s, a);

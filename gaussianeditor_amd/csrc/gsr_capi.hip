@@ -136,16 +136,24 @@ inline int bin_legacy(int W, int H) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return (forced || group_count(W, H) > GROUP_MAX || gx > RECT32_EDGE || gy > RECT32_EDGE) ? 1 : 0;
 }
-// Checkpoint stride of the forward blend in 64-entry chunks (GSR_CK_CHUNKS: tests use 1 or 2 to segment small scenes;
-// 0 turns checkpoints -- and with them the backward's list segments -- off).  Read once; never changes a result beyond the
-// backward's summation order.
-inline int checkpoint_chunks() {
-  static const int v = [] {
+// Checkpoint stride of the forward blend in 64-entry chunks, per view: 512 list positions where lists are LONG (deep-tile
+// scenes, 6 M Gaussians: the backward walks up to 7 000 positions of a tile's list; blend backward 438 -> 339 us and
+// 528 -> 314 us), none where they are short.  On the benchmark view (mean list 593 entries per tile) the heaviest backward
+// items are dense tiles walked 350-450 positions deep, the hundred longest within 13 % of each other and of a workgroup's
+// mean load: cutting them (stride 128 / 192 / 256, any work threshold) adds the per-item start-up of a few hundred more
+// items and buys no balance -- blend backward 219 -> 226-232 us in four same-box A/Bs (profiles/r04_d_segments.md) -- and at
+// strides below 256 the segments' start state shows in the per-row parity bar.  A function of what gsr_blend_forward
+// and gsr_blend_backward of a view both receive (R, W, H), so the two agree.  GSR_CK_CHUNKS overrides it (tests use 1 or 2
+// to segment small scenes; 0 = never).  Never changes a result beyond the backward's summation order.
+inline int checkpoint_chunks(int64_t R, int W, int H) {
+  static const int env = [] {
     const char* e = getenv("GSR_CK_CHUNKS");
-    const int c = e != nullptr ? atoi(e) : CK_CHUNKS_DEFAULT;
-    return c < 0 ? 0 : (c > 1024 ? 1024 : c);
+    const int c = e != nullptr ? atoi(e) : -1;
+    return c > 1024 ? 1024 : c;
   }();
-  return v;
+  if (env >= 0) return env;
+  const int64_t T = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+  return R < 2048 * T ? 0 : CK_CHUNKS_DEFAULT;
 }
 // What the blend / export entry points need of the binning scratch sits in front of everything sized by the number of
 // group instances, so they carve with G = 0.
@@ -154,20 +162,6 @@ inline Binning carve_binning_view(const void* binning, int64_t R, int W, int H) 
 }
 // Scratch buffers are accessed with 16-byte vector loads at 256-byte aligned section offsets.
 inline bool misaligned(const void* p) { return ((uintptr_t)p & 255u) != 0; }
-
-// Do forward checkpoints / backward list segments pay for this view?  They shorten the backward's longest items where
-// lists are walked DEEP (deep-tile scenes: blend backward 449 -> 343 us); on views whose heavy tiles are dense rather than
-// deep they only cost (the benchmark view: +11 us in the backward, checkpoints written by 87 tiles).  The decision must be
-// the same in gsr_blend_forward and gsr_blend_backward of a view, so it is a function of what both receive: the mean list
-// length per tile, R / T (benchmark view 593, deep-tile scene 5 993).  GSR_CK_MIN_LIST overrides the threshold (tests: 0).
-inline bool segments_pay(int64_t R, int W, int H) {
-  static const int64_t min_list = [] {
-    const char* e = getenv("GSR_CK_MIN_LIST");
-    return e != nullptr ? (int64_t)atoll(e) : (int64_t)2048;
-  }();
-  const int64_t T = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
-  return checkpoint_chunks() > 0 && R >= min_list * T;
-}
 
 inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, const Image& im, const float* bg,
                                  int queue_kind, int64_t R) {
@@ -191,13 +185,12 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.final_T = im.final_T;
   a.n_contrib = im.n_contrib;
   a.queue = im.queue_heads + (size_t)queue_kind * QUEUE_LINES * QUEUE_STRIDE;
-  if (segments_pay(R, W, H)) {
+  a.ck_chunks = checkpoint_chunks(R, W, H);
+  if (a.ck_chunks > 0) {
     a.ck_table = im.ck_table;
     a.ck_work = im.ck_work;
-    a.ck_counter = im.ck_counter;
     a.tile_maxc = im.tile_maxc;
     a.ck_pool = im.ck_pool;
-    a.ck_chunks = checkpoint_chunks();
   }
   return a;
 }

@@ -111,26 +111,26 @@ struct Image {
   uint32_t* work_order; // (T)  tile ids: non-empty tiles, longest list first (bucketed), then the empty tiles
   uint32_t* work_meta;  // [0] = number of non-empty tiles
   uint32_t* work_est;   // (T,4) entries the forward blend evaluated per (tile, quadrant): the backward's work estimate
-  uint32_t* bwd_order;  // (2T + CK_POOL) items of the backward blend (a tile, half of a heavy tile, or a list segment of a deep
+  uint32_t* bwd_order;  // (2T + CK_MAX * CK_TILES(T)) items of the backward blend (a tile, half of a heavy tile, or a list segment of a deep
                         //      one): most forward work first, tiles without any work dropped
   uint32_t* bwd_meta;   // [0] = number of tiles in bwd_order
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
-  // Checkpoints of the forward blend (round 4): the backward can then walk a deep tile's list as independent SEGMENTS in
+  // Checkpoints of the forward blend (round 4): the backward can then walk a tile's list as independent SEGMENTS in
   // separate work items.  The state of a pixel in front of list position k * stride (transmittance, accumulated colour)
-  // is one float4; a checkpoint of a tile is 256 of them (a pool slot).  Slots are handed out on demand by the forward
-  // (only tiles whose pixels are still live that deep ever take one).
-  uint32_t* ck_table;   // (T x CK_MAX) entry k >= 1: 1 + pool slot of the checkpoint in front of position k * stride (entry 1: a PAIR
-                        //      of slots, the tile's FINAL state first); 0 = none; > CK_POOL = pool exhausted; entry 0 unused
+  // is one float4; a checkpoint of a tile is 256 of them.  The CK_TILES(T) tiles with the longest lists own CK_MAX
+  // consecutive 4 KB slots each (slot 0: the tile's FINAL state), assigned by tile_worklist_kernel -- no allocation, no
+  // atomics in the forward's loop.
+  uint32_t* ck_table;   // (T)  the tile's rank among the checkpointed tiles (its slots: rank * CK_MAX + k), or CK_NONE
   uint32_t* ck_work;    // (T x CK_MAX) entry k: entries the forward had evaluated in the tile when it reached checkpoint k (summed
-                        //      over its quadrants): how a deep tile's backward work splits over its list segments
-  uint32_t* ck_counter; // [0] = pool slots handed out
-  uint32_t* tile_maxc;  // (T)  largest last-contributor position + 1 over the tile's pixels (what the backward walks)
-  float4* ck_pool;      // (CK_POOL x 256)
+                        //      over its quadrants): how the tile's backward work splits over its list segments.  Zero per view.
+  uint32_t* tile_maxc;  // (T)  largest last-contributor position + 1 over the tile's pixels (what the backward walks).  Zero per view.
+  float4* ck_pool;      // (CK_TILES(T) x CK_MAX x 256)
   size_t bytes;
 };
-constexpr int CK_MAX = 16;        // checkpoints per tile (beyond that depth the last segment is simply longer)
-constexpr int CK_POOL = 4096;     // pool slots (4 KB each: 16 MB)
-constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions)
+constexpr int CK_MAX = 8;            // slots per tile: the final state + 7 checkpoints (beyond that depth the last segment is longer)
+constexpr uint32_t CK_NONE = 0xffffffffu;
+constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions) where checkpoints are on
+__host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (64 MB of slots at most)
 __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   char* p = (char*)base;
   const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
@@ -143,14 +143,13 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.work_order = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * T);
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 4 * T);
-  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + 4096 /* CK_POOL */));
+  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + 8 /* CK_MAX */ * (T < 2048 ? T : 2048)));
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
-  im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * 16 /* CK_MAX */ * T);
-  im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * 16 /* CK_MAX */ * T);
-  im.ck_counter = (uint32_t*)(p + off); off += 256;
+  im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * T);
+  im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * 8 /* CK_MAX */ * T);
   im.tile_maxc = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
-  im.ck_pool = (float4*)(p + off);      off += align_up(sizeof(float4) * 256 * 4096 /* CK_POOL */);
+  im.ck_pool = (float4*)(p + off);      off += align_up(sizeof(float4) * 256 * 8 /* CK_MAX */ * (T < 2048 ? T : 2048));
   im.bytes = off;
   return im;
 }

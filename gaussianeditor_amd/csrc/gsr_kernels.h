@@ -98,7 +98,6 @@ struct BlendArgs {
   // forward checkpoints / backward list segments (Image::ck_*); ck_table == null: none (auxiliary render, tracing)
   uint32_t* ck_table;
   uint32_t* ck_work;
-  uint32_t* ck_counter;
   uint32_t* tile_maxc;
   float4* ck_pool;
   int ck_chunks;   // checkpoint stride in 64-entry chunks

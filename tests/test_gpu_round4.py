@@ -181,12 +181,12 @@ def test_bench_fixed_batch_of_views_on_one_gpu_and_on_two_ranks_sharing_it():
 
 def test_backward_list_segments_match_the_oracle_when_forced_on_small_scenes():
     """The backward walks a deep tile's list as independent segments that start from the forward's checkpoints (round 4).  On
-    the deep-tile workload of the three-way parity test it is on by default (783 tiles deeper than one stride; views with
-    short lists -- the headline view -- run without: gsr_capi.hip segments_pay); here a checkpoint every 64 list positions,
-    no work threshold and no list-length threshold cut nearly every tile of the SMALL parity scenes into segments: forward / backward / apply_weights parity against the oracle in a fresh process with those knobs."""
+    the deep-tile and the 6 M workloads of the three-way parity test it is on by default (stride 512; views with short lists
+    -- the headline view -- run without: gsr_capi.hip checkpoint_chunks); here a checkpoint every 64 list positions and no work
+    threshold cut nearly every tile of the SMALL parity scenes into segments: forward / backward / apply_weights parity against the oracle in a fresh process with those knobs."""
     import subprocess
 
-    env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_BWD_SEG="1", GSR_CK_MIN_LIST="0")
+    env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_BWD_SEG="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
                         "backward_vs_oracle or backward_precomp or forward_all_stages or edge_geometries or backward_twice"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
@@ -198,7 +198,7 @@ def test_backward_list_segments_match_the_oracle_when_forced_on_small_scenes():
     # Measured with every tile cut (GSR_BWD_SEG=1): stride 64 / 128 leave 12-20 rows of dL_dopacity outside that bar where
     # 5-11 are allowed (every tensor-max bar holds); stride 256 and the default 512 pass all six cases incl. 1 M, 6 M and the
     # deep-tile scene.
-    env = dict(os.environ, GSR_CK_CHUNKS="4", GSR_BWD_SEG="1", GSR_CK_MIN_LIST="0")
+    env = dict(os.environ, GSR_CK_CHUNKS="4", GSR_BWD_SEG="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_round2.py"), "-k",
                         "three_way_parity"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
