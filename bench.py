@@ -38,6 +38,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max engine clock 2400 MHz (the issue ceiling is priced at it: DVFS runs these kernels
+#                        at ~2.1-2.3 GHz, so the fraction understates the share of the cycles actually clocked)
 STAGES = ("preprocess", "bin", "blend_forward", "blend_backward", "preprocess_backward")
 
 
@@ -215,11 +217,9 @@ def roofline_block(stage_ms, ab, cb, dominant, counters, source, dev, pix_inst):
             out["traffic"] = tb
             out["frac_counter"] = tb / t / 1e9 / HBM_PEAK_GBS
         if vi is not None:
-            prop = torch.cuda.get_device_properties(dev)
-            simds = prop.multi_processor_count * 4
-            clk = prop.clock_rate * 1e3  # Hz
+            simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
             # a SIMD issues at most one VALU instruction of a wave per 4 cycles (64 lanes over a 16-wide datapath)
-            out["valu_issue_frac"] = vi / (simds * t * clk / 4.0)
+            out["valu_issue_frac"] = vi / (simds * t * MAX_CLOCK_HZ / 4.0)
             out["valu_wave_insts"] = vi
     if dominant in ("blend_forward", "blend_backward"):
         out["limiter"] = ("instruction issue / per-item latency, not HBM: see valu_issue_frac and pixel_instances_per_s "

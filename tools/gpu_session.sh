@@ -14,14 +14,7 @@ O=gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $O/${TAG}_pytest.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.txt 2>&1
 bash tools/gpu_counters.sh ${TAG} > $O/${TAG}_counters.log 2>&1
-timeout 900 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
-timeout 300 python bench.py --steps 100 --s0 0.05 --no-cpu-baseline > $O/${TAG}_bench_deep_s005.json 2>> $O/${TAG}_bench.err
-timeout 300 python bench.py --steps 50 --gaussians 6000000 --no-cpu-baseline > $O/${TAG}_bench_6m.json 2>> $O/${TAG}_bench.err
-timeout 300 python bench.py --views 8 --steps 50 --warmup 10 --no-cpu-baseline > $O/${TAG}_bench_views8.json 2>> $O/${TAG}_bench.err
-timeout 300 python bench.py --views 8 --steps 50 --warmup 10 --no-cpu-baseline --no-view-pipeline > $O/${TAG}_bench_views8_serial.json 2>> $O/${TAG}_bench.err
-GSR_TILE_BOUNDS=alpha timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_alpha_bounds.json 2>> $O/${TAG}_bench.err
-GSR_FAST_EXP=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_fast_exp.json 2>> $O/${TAG}_bench.err
-timeout 300 python bench.py --steps 100 --force-exchange --no-cpu-baseline > $O/${TAG}_bench_forced_exchange.json 2>> $O/${TAG}_bench.err
+bash tools/gpu_bench_lines.sh ${TAG} > $O/${TAG}_bench_lines.txt 2>&1
 prof() { # name, rocprof args ... -- bench args
   name=$1; shift
   mkdir -p $R/$O/$name
