@@ -70,6 +70,8 @@ SIGNATURES = {
     "gsr_view_messages_accumulate_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads), _P]),
     "gsr_knn_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
     "gsr_knn_mean_dist2": (c_int, [_P, c_int, _P, _P, _P]),
+    "gsr_near_workspace_size": (c_int, [c_int, POINTER(c_size_t)]),
+    "gsr_near_points": (c_int, [_P, c_int, _P, c_int, _P, c_float, _P, _P, _P]),
     "gsr_compact_workspace_size": (c_int, [c_int64, POINTER(c_size_t)]),
     "gsr_compact_plan": (c_int, [_P, c_int64, _P, _P, POINTER(c_int64)]),
     "gsr_compact_apply": (c_int, [_P, c_int64, _P, _P, c_int, POINTER(CompactTensor)]),

@@ -685,6 +685,22 @@ int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace
   return GSR_OK;
 }
 
+int gsr_near_workspace_size(int n_ref, size_t* bytes) { return gsr_knn_workspace_size(n_ref, bytes); }
+
+int gsr_near_points(void* stream, int n_ref, const float* ref_points, int n_query, const float* query_points,
+                    float dist_thresh, void* workspace, uint8_t* near, float* nn_dist) {
+  if (n_query == 0) return GSR_OK;
+  if (n_ref < 0 || n_query < 0 || !query_points || !near || !(dist_thresh >= 0.f)) return GSR_ERR_BAD_ARGUMENT;
+  if (n_ref == 0) {  // nothing to be near to
+    GSR_HIP(hipMemsetAsync(near, 0, (size_t)n_query, (hipStream_t)stream));
+    if (nn_dist) GSR_HIP(hipMemsetD32Async((hipDeviceptr_t)nn_dist, 0x7f800000, (size_t)n_query, (hipStream_t)stream));
+    return GSR_OK;
+  }
+  if (!ref_points || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_near_points((hipStream_t)stream, n_ref, ref_points, n_query, query_points, dist_thresh, workspace, near, nn_dist));
+  return GSR_OK;
+}
+
 int gsr_adam_step(void* stream, int num_tensors, const gsr_adam_tensor* tensors, int64_t step, double beta1, double beta2,
                   double eps, const uint8_t* row_mask, const float* row_weight) {
   return gsr_adam_step_rows(stream, num_tensors, tensors, step, beta1, beta2, eps, row_mask, row_weight, nullptr);

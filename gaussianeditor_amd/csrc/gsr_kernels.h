@@ -140,6 +140,8 @@ hipError_t launch_export_keys(hipStream_t s, int64_t R, int W, int H, const Binn
 hipError_t launch_binning(hipStream_t s, int P, int64_t R, int W, int H, const Geom& g, const Binning& b, const Image& im);
 size_t knn_workspace_bytes(int P);
 hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out);
+hipError_t launch_near_points(hipStream_t s, int n_ref, const float* ref, int n_query, const float* query, float thresh,
+                              void* workspace, uint8_t* near, float* nn_dist);
 size_t compact_workspace_bytes(int64_t P);
 hipError_t launch_compact_plan(hipStream_t s, int64_t P, const uint8_t* keep, void* workspace);
 const uint64_t* compact_total_ptr(void* workspace, int64_t P);

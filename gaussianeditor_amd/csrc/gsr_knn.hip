@@ -223,8 +223,8 @@ void radix_sort_pairs_u32(hipStream_t s, uint32_t* const keys[2], uint32_t* cons
 
 size_t knn_workspace_bytes(int P) { return carve_knn(nullptr, P).bytes; }
 
-hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out) {
-  const KnnWork w = carve_knn(workspace, P);
+// bounds -> Morton codes -> sort -> gather -> boxes over `points`; leaves w.sorted / w.val[0] / w.boxes
+static void build_knn_index(hipStream_t s, int P, const float* points, const KnnWork& w) {
   const int nb = (P + 255) / 256;
   hipLaunchKernelGGL(knn_bounds_kernel, dim3(nb), dim3(256), 0, s, P, points, w.bounds);
   hipLaunchKernelGGL(knn_bounds_final_kernel, dim3(1), dim3(1024), 0, s, nb, w.bounds);
@@ -233,7 +233,62 @@ hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace
   radix_sort_pairs_u32(s, w.key, w.val, P, 4, digits, w.hist, w.bin_total, true);
   hipLaunchKernelGGL(knn_gather_kernel, dim3(nb), dim3(256), 0, s, P, points, w.val[0], w.sorted);
   hipLaunchKernelGGL(knn_box_kernel, dim3((P + KNN_BOX - 1) / KNN_BOX), dim3(256), 0, s, P, w.sorted, w.boxes);
-  hipLaunchKernelGGL(knn_search_kernel, dim3(nb), dim3(256), 0, s, P, w.sorted, w.val[0], w.boxes, out);
+}
+
+hipError_t launch_knn(hipStream_t s, int P, const float* points, void* workspace, float* out) {
+  const KnnWork w = carve_knn(workspace, P);
+  build_knn_index(s, P, points, w);
+  hipLaunchKernelGGL(knn_search_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, w.sorted, w.val[0], w.boxes, out);
+  return hipGetLastError();
+}
+
+// ---- the Delete path's neighbour query: which query points have a reference point within `thresh` ----
+// Reference: GaussianModel.get_near_gaussians_by_mask (gaussiansplatting/scene/gaussian_model.py:865-898) asks
+// K_nearest_neighbors(object_xyz, 1, query=in_box_remaining_xyz, return_dist=True) (gaussiansplatting/knn.py: a
+// scipy.spatial.KDTree built on the float32 points widened to float64; the 1-NN Euclidean distance comes back as
+// float64 and is cast to the points' dtype) and keeps `nn_dist <= dist_thresh`.
+// Here: the Morton boxes of the reference set prune in float with a safety margin; every surviving candidate's distance
+// is formed in double from the widened coordinates, sqrt in double, rounded to float once -- the same value the KDTree
+// path compares.  With `nn_dist` null a query stops at its first hit.
+__global__ void __launch_bounds__(256) near_search_kernel(int n_ref, const float4* __restrict__ sorted, const float* __restrict__ boxes,
+                                                         int n_query, const float* __restrict__ query, float thresh,
+                                                         uint8_t* __restrict__ near, float* __restrict__ nn_dist) {
+  const int q = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (q >= n_query) return;
+  const float4 point = make_float4(query[3 * (size_t)q], query[3 * (size_t)q + 1], query[3 * (size_t)q + 2], 0.f);
+  const float prune = thresh * thresh * 1.0001f + FLT_MIN;  // float candidates that the double test could still accept
+  const double px = (double)point.x, py = (double)point.y, pz = (double)point.z;
+  double best = HUGE_VAL;  // squared, double
+  const bool first_hit = nn_dist == nullptr;
+  bool hit = false;
+  const int nboxes = (n_ref + KNN_BOX - 1) / KNN_BOX;
+  for (int b = 0; b < nboxes && !(first_hit && hit); b++) {
+    if (!(dist_box_point(boxes + 6 * (size_t)b, point) <= prune)) continue;
+    const int e = min(n_ref, (b + 1) * KNN_BOX);
+    for (int i = b * KNN_BOX; i < e; i++) {
+      const float4 r = sorted[i];
+      const float fx = point.x - r.x, fy = point.y - r.y, fz = point.z - r.z;
+      if (!(fx * fx + fy * fy + fz * fz <= prune)) continue;
+      const double dx = px - (double)r.x, dy = py - (double)r.y, dz = pz - (double)r.z;
+      const double d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 < best) {
+        best = d2;
+        hit = (float)sqrt(d2) <= thresh;
+        if (first_hit && hit) break;
+      }
+    }
+  }
+  const float d = (float)sqrt(best);  // +inf when nothing lay inside the pruning radius
+  near[q] = (d <= thresh) ? 1 : 0;
+  if (nn_dist) nn_dist[q] = d;
+}
+
+hipError_t launch_near_points(hipStream_t s, int n_ref, const float* ref, int n_query, const float* query, float thresh,
+                              void* workspace, uint8_t* near, float* nn_dist) {
+  const KnnWork w = carve_knn(workspace, n_ref);
+  build_knn_index(s, n_ref, ref, w);
+  hipLaunchKernelGGL(near_search_kernel, dim3((n_query + 255) / 256), dim3(256), 0, s, n_ref, w.sorted, w.boxes, n_query, query,
+                     thresh, near, nn_dist);
   return hipGetLastError();
 }
 

@@ -254,6 +254,19 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
 int gsr_knn_workspace_size(int P, size_t* bytes);
 int gsr_knn_mean_dist2(void* stream, int P, const float* points, void* workspace, float* mean_dist2);
 
+/* The Delete path's neighbour query: near[q] = 1 iff some reference point lies within dist_thresh of query point q.
+ * Replaces the CPU KD-tree call inside GaussianModel.get_near_gaussians_by_mask
+ * (gaussiansplatting/scene/gaussian_model.py:865-898: K_nearest_neighbors(object_xyz, 1, query=..., return_dist=True)
+ * of gaussiansplatting/knn.py, a scipy.spatial.KDTree, followed by `nn_dist <= dist_thresh`).  The compared value is
+ * the reference's: the Euclidean distance of the float64-widened coordinates, rounded to float32 once.
+ * ref_points (n_ref,3) f32, query_points (n_query,3) f32, near (n_query) u8, nn_dist (n_query) f32 | NULL: the 1-NN
+ * distance where it is <= dist_thresh * (1 + 1e-4), +inf where no reference point lies that close (the mask never needs
+ * more; NULL lets a query stop at its first hit).  workspace: gsr_near_workspace_size(n_ref) bytes of device scratch.
+ * n_query == 0 is a no-op; n_ref == 0 clears `near` (and fills nn_dist with +inf). */
+int gsr_near_workspace_size(int n_ref, size_t* bytes);
+int gsr_near_points(void* stream, int n_ref, const float* ref_points, int n_query, const float* query_points,
+                    float dist_thresh, void* workspace, uint8_t* near, float* nn_dist);
+
 /* ---- fused, row-masked Adam step over all parameter groups in one launch ----
  * Replaces, per training step, torch.optim.Adam.step() over the six groups of GaussianModel.training_setup
  * (gaussiansplatting/scene/gaussian_model.py:336-380; lr per group, betas (0.9, 0.999), eps 1e-15, no weight decay, no

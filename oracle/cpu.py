@@ -295,3 +295,56 @@ def append_rows(arrays, extensions, n=None):
             e = np.zeros((n,) + a.shape[1:], dtype=a.dtype)
         out.append(np.ascontiguousarray(np.concatenate((a, np.asarray(e, dtype=a.dtype)), axis=0)))
     return out
+
+
+def near_points(ref, query, dist_thresh):
+    """The neighbour query of GaussianModel.get_near_gaussians_by_mask restated by brute force
+    (gaussiansplatting/scene/gaussian_model.py:887-891 over gaussiansplatting/knn.py): the float32 points widened to
+    float64 (numpy -> KDTree), the Euclidean 1-NN distance in float64, rounded to float32 (`.to(mean)`), compared
+    `<= float32(dist_thresh)` (a float32 tensor against a Python scalar compares in float32).
+    (n_ref,3), (n_query,3) -> (near (n_query,) bool, nn_dist (n_query,) float32; +inf with no reference point)."""
+    r = np.asarray(ref, np.float32).reshape(-1, 3).astype(np.float64)
+    q = np.asarray(query, np.float32).reshape(-1, 3).astype(np.float64)
+    dist = np.full(q.shape[0], np.inf, np.float64)
+    if r.shape[0]:
+        step = max(1, (1 << 22) // max(r.shape[0], 1))
+        for i in range(0, q.shape[0], step):
+            d = q[i:i + step, None, :] - r[None, :, :]
+            dist[i:i + step] = np.sqrt((d * d).sum(axis=2).min(axis=1))
+    d32 = dist.astype(np.float32)
+    return d32 <= np.float32(dist_thresh), d32
+
+
+def _quantile_f32(x, q):
+    """torch.quantile(x, q) for a 1-D float32 x, interpolation 'linear' (aten/src/ATen/native/Sorting.cpp
+    quantile_compute: rank = q * (n - 1) in float32, lerp between the two neighbours with torch's two-sided lerp).  A box edge
+    one ulp off only matters for a point exactly on it; the fixture and the live-reference test pin this form."""
+    s = np.sort(np.asarray(x, np.float32))
+    rank = np.float32(q) * np.float32(s.shape[0] - 1)
+    lo = np.floor(rank)
+    w = np.float32(rank - lo)
+    a, b = s[int(lo)], s[min(int(lo) + 1, s.shape[0] - 1)]  # ceil_(ranks) == lo + 1 unless rank is whole; then w == 0
+    diff = np.float32(b - a)
+    # at::native lerp, vectorised form (aten/src/ATen/native/cpu/LerpKernel.cpp lerp_vec): one fused multiply-add
+    # fmadd(coeff, end - start, base) with (coeff, base) = (w, start) for w < 0.5, else (w - 1, end).  The product of two
+    # float32 values is exact in float64, so float32(float64 fma) is the fused result.
+    coeff, base = (w, a) if w < np.float32(0.5) else (np.float32(w - np.float32(1)), b)
+    return np.float32(np.float64(coeff) * np.float64(diff) + np.float64(base))
+
+
+def get_near_gaussians_by_mask(xyz, mask, dist_thresh=0.1):
+    """GaussianModel.get_near_gaussians_by_mask (gaussian_model.py:865-898) restated in numpy float32."""
+    xyz = np.asarray(xyz, np.float32)
+    mask = np.asarray(mask).astype(bool).reshape(-1)
+    obj, rem = xyz[mask], xyz[~mask]
+    lo = np.array([_quantile_f32(obj[:, c], 0.03) for c in range(3)], np.float32)
+    hi = np.array([_quantile_f32(obj[:, c], 0.97) for c in range(3)], np.float32)
+    scale = (hi - lo).astype(np.float32)
+    mid = ((hi + lo) / np.float32(2)).astype(np.float32)
+    scale = (scale * np.float32(1.3)).astype(np.float32)
+    lo2, hi2 = (mid - scale / np.float32(2)).astype(np.float32), (mid + scale / np.float32(2)).astype(np.float32)
+    in_bbox = ((rem >= lo2) & (rem <= hi2)).all(axis=1)
+    near, _ = near_points(obj, rem[in_bbox], dist_thresh)
+    out = np.zeros(rem.shape[0], bool)
+    out[np.nonzero(in_bbox)[0][near]] = True
+    return out
