@@ -339,6 +339,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prewarm", type=int, default=300,
+                    help="untimed train steps in FRONT of the --warmup steps (same count on every rank): a GPU that comes out of idle "
+                         "needs tens of milliseconds of load to reach its clocks, the contract's warmup may be a handful of steps")
     ap.add_argument("--views", type=int, default=0,
                     help="views per step of the WHOLE job (default 0 = one per GPU, weak scaling).  A multiple of --gpus: every "
                          "rank renders views/gpus views per step and the batch is fixed as N grows (strong scaling of "
@@ -377,6 +380,12 @@ def main():
         self_launch(args.gpus)  # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    # The contract: rank 0 prints ONE JSON line.  RCCL writes a version banner to the process's stdout through C stdio (it
+    # appears when the process exits, i.e. BEHIND anything Python printed), so the descriptor the line goes to is set aside
+    # and everything else any library writes to stdout -- on every rank -- is sent to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -501,6 +510,9 @@ def main():
 
     exchange = bucket.sh_exchange
     # (a failing exchange fails the benchmark: it must never silently measure another workload)
+    for _ in range(max(args.prewarm, 0)):  # (untimed, in front of the contract's warmup: clock ramp)
+        train_step()
+    sync_all()
     for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
         train_step()
     sync_all()
@@ -666,7 +678,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * train_s / args.steps,
             "step_ms_gpu": {"median": percentile(step_ms, 0.5), "p10": percentile(step_ms, 0.1), "p90": percentile(step_ms, 0.9),
+                            "first": step_ms[0] if step_ms else None, "max": max(step_ms) if step_ms else None,
                             "note": "HIP events around every timed step on the launch stream of rank 0"},
+            "prewarm_steps": max(args.prewarm, 0),
             "higher_is_better": True,
             "scaling": "strong" if batch_mode else "weak",
             "vs_baseline": None,
@@ -714,7 +728,7 @@ def main():
             })
             if extra is not None:
                 out["extra_configs"] = extra
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 

@@ -78,8 +78,9 @@ def _bench(args, env_extra=None, launcher=None, timeout=900):
     cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    # the contract: ONE JSON line on stdout and nothing else (RCCL's version banner, torch warnings, ... go to stderr)
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]
     return json.loads(lines[0])
 
 
@@ -154,6 +155,15 @@ def test_default_bench_line_carries_extra_configs_and_both_roofline_fractions():
     assert 0 < ex["C2_synth6M_1080p_forward"]["roofline"]["frac"] <= 1
     assert 0.2 < ex["C3_edit_loop_512_1M"]["ms_per_step"] < 10 and 0.05 < ex["C5_apply_weights_12views_512_1M"]["ms_per_view"] < 5
     assert ex["seconds"] < 120
+
+
+def test_bench_stdout_is_one_json_line_even_when_rccl_is_initialised():
+    """RCCL prints a version banner to the process's stdout at exit (C stdio): with a process group up (--force-exchange: the
+    one-rank RCCL exchange) the line must still be the only thing on stdout; the pre-warm steps are reported."""
+    line = _bench(["--gaussians", "50000", "--width", "640", "--height", "368", "--steps", "3", "--warmup", "1", "--prewarm", "7",
+                   "--no-cpu-baseline", "--force-exchange"])
+    assert line["multi_gpu"]["backend"] == "nccl" and line["prewarm_steps"] == 7 and line["steps"] == 3
+    assert line["step_ms_gpu"]["first"] > 0 and line["step_ms_gpu"]["max"] >= line["step_ms_gpu"]["median"]
 
 
 def test_bench_fixed_batch_of_views_on_one_gpu_and_on_two_ranks_sharing_it():
