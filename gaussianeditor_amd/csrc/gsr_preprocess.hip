@@ -7,6 +7,10 @@
 // integer outputs (radii, tiles_touched) are bit-identical to the CPU oracle.
 #include "gsr_kernels.h"
 
+#ifndef GSR_K1_PREFETCH
+#define GSR_K1_PREFETCH 1  // (A/B builds: 0 = the loads where the reference has them)
+#endif
+
 namespace gsr {
 
 // glm::mat3 semantics (column-major m[col][row]; product evaluated left to right),
@@ -135,13 +139,12 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t id
 // computeCov3D, forward.cu:118-152: Sigma = (S R)^T (S R), upper triangle.  Used by K1 and again by K8+K9 -- the reference
 // keeps the six floats in its geometry buffer between the passes (rasterizer_impl.cu:225, 388); recomputing them from
 // the 28 bytes of scale and rotation the backward reads anyway saves a 24-byte store and a 24-byte load per Gaussian.
-__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales, float scale_modifier,
-                                                     const float* __restrict__ rotations, int idx, float (&c3)[6]) {
+__device__ __forceinline__ void cov3d_from_values(float s0, float s1, float s2, float scale_modifier, const float4& q,
+                                                  float (&c3)[6]) {
   M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
-  S.m[0][0] = scale_modifier * scales[3 * idx + 0];
-  S.m[1][1] = scale_modifier * scales[3 * idx + 1];
-  S.m[2][2] = scale_modifier * scales[3 * idx + 2];
-  const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+  S.m[0][0] = scale_modifier * s0;
+  S.m[1][1] = scale_modifier * s1;
+  S.m[2][2] = scale_modifier * s2;
   const float r = q.x, x = q.y, y = q.z, z = q.w;
   const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
@@ -150,6 +153,11 @@ __device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ s
   const M3 Sigma = mul(tr(Mm), Mm);
   c3[0] = Sigma.m[0][0]; c3[1] = Sigma.m[0][1]; c3[2] = Sigma.m[0][2];
   c3[3] = Sigma.m[1][1]; c3[4] = Sigma.m[1][2]; c3[5] = Sigma.m[2][2];
+}
+__device__ __forceinline__ void cov3d_from_scale_rot(const float* __restrict__ scales, float scale_modifier,
+                                                     const float* __restrict__ rotations, int idx, float (&c3)[6]) {
+  cov3d_from_values(scales[3 * idx + 0], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier,
+                    reinterpret_cast<const float4*>(rotations)[idx], c3);
 }
 
 // d(RGB)/d(dir) of computeColorFromSH, backward.cu:88-136 (the part of its backward that needs the SH coefficients):
@@ -199,7 +207,15 @@ __device__ __forceinline__ void sh_color_dir_derivatives(int D, float x, float y
 //  1 KB loads into an LDS tile, every lane then reading its row -- on the same box: preprocess stage 139 -> 161 us at 1 M
 //  Gaussians, 602 -> 703 us at 6 M (the 53 KB of tiles leave three blocks per CU, and the rows cross LDS on top of the
 //  memory round trip): commit 4aadae3 holds it, profiles/r04_b_k1_and_chain.md the table.)
+// MAIN: the training configuration -- covariance from scales / rotations, colours from SH records of 16 coefficients at degree
+// 3 -- as an instantiation of its own: with the other input modes compiled out there is no second definition of any register
+// at a join, and the waits hipcc inserts sit in front of the first USE of the early SH request instead of right behind it.
+template <bool MAIN>
 __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) preprocess_kernel(const PreArgs a) {
+  const float* const cov3D_precomp = MAIN ? nullptr : a.cov3D_precomp;
+  const float* const colors_precomp = MAIN ? nullptr : a.colors_precomp;
+  const bool skip_color = MAIN ? false : (a.skip_color != 0);
+  const int D = MAIN ? 3 : a.D, M = MAIN ? 16 : a.M;
   __shared__ uint32_t smem[GAUSS_BLOCK / 64 + 1], ssum[GAUSS_BLOCK / 64];
   __shared__ uint32_t skmax[2];
   if (threadIdx.x < 2) skmax[threadIdx.x] = 0u;
@@ -207,7 +223,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
   uint32_t my_tiles = 0, my_groups = 0;  // tiles touched; 8x8-tile groups touched (gsr_binning.hip: group instances)
   uint32_t kmax = 0u, kinv = 0u;  // max of the depth key / of its complement over the visible Gaussians of the wave
   Cam cam;
-  load_cam(cam, a.viewmatrix, a.projmatrix, a.skip_color || a.colors_precomp ? nullptr : a.campos);
+  load_cam(cam, a.viewmatrix, a.projmatrix, skip_color || colors_precomp ? nullptr : a.campos);
   const float* view = cam.view;
   const float* proj = cam.proj;
   // ---- geometry (forward.cu:182-237): everything up to the colour.  `live` = the Gaussian survives every cull.
@@ -216,7 +232,26 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
   float my_depth = 0.f, my_radius = 0.f, conx = 0.f, cony = 0.f, conz = 0.f, pix = 0.f, piy = 0.f;
   V3 p = {0.f, 0.f, 0.f};
   uint2 my_rect = make_uint2(0u, 0u);  // tile rectangle (origin, width | height << 16); width * height == tiles_touched
+  // Loads: K1 is a streaming kernel at 4 waves per SIMD, so every DEPENDENT memory round trip of a wave shows.  Position, scale,
+  // rotation and opacity are fetched together, unconditionally (28 wasted bytes for a Gaussian behind the camera); the SH record
+  // -- 192 of the ~300 bytes -- is requested as soon as the projected centre says the Gaussian is probably on screen, in front
+  // of the ~800 instructions of covariance arithmetic instead of behind them (a Gaussian that turns out live without the early
+  // request fetches it where it always did; one that is culled after it wasted the fetch: the 1.5x screen margin keeps both rare).
+  V3 sh[16];
+  bool sh_loaded = false;
+  const bool want_sh = GSR_K1_PREFETCH && !skip_color && colors_precomp == nullptr;
+  float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f, my_opacity = 0.f;
+  float4 quat = make_float4(0.f, 0.f, 0.f, 0.f);
   if (idx < a.P) {
+    if (GSR_K1_PREFETCH) {
+      if (cov3D_precomp == nullptr) {
+        sc0 = a.scales[3 * idx + 0];
+        sc1 = a.scales[3 * idx + 1];
+        sc2 = a.scales[3 * idx + 2];
+        quat = reinterpret_cast<const float4*>(a.rotations)[idx];
+      }
+      my_opacity = a.opacities[idx];
+    }
     do {
       p = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
       // in_frustum, auxiliary.h:139-164: only the near test survives
@@ -229,14 +264,22 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
       const float hw = proj[3] * p.x + proj[7] * p.y + proj[11] * p.z + proj[15];
       const float p_w = 1.0f / (hw + 0.0000001f);
       const float projx = hx * p_w, projy = hy * p_w;
+      if (want_sh) {
+        // (no branch on `likely` around the loads: behind a divergent region hipcc waits for everything in flight.  The other
+        //  lanes re-read the block's first record -- one row for all of them, from the cache)
+        const bool likely = fabsf(projx) < 1.5f && fabsf(projy) < 1.5f;
+        load_sh(a.shs, likely ? (size_t)idx : (size_t)blockIdx.x * GAUSS_BLOCK, M, D, sh);
+        sh_loaded = likely;
+      }
 
       // cov3D: forward.cu:118-152, or the precomputed one
       float c3[6];
-      if (a.cov3D_precomp != nullptr) {
+      if (cov3D_precomp != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
+        for (int i = 0; i < 6; ++i) c3[i] = cov3D_precomp[6 * (size_t)idx + i];
       } else {
-        cov3d_from_scale_rot(a.scales, a.scale_modifier, a.rotations, idx, c3);
+        if (GSR_K1_PREFETCH) cov3d_from_values(sc0, sc1, sc2, a.scale_modifier, quat, c3);
+        else cov3d_from_scale_rot(a.scales, a.scale_modifier, a.rotations, idx, c3);
       }
       // (not stored: the backward recomputes it from the same inputs, bit for bit, instead of reading 24 B back)
 
@@ -284,7 +327,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
         // (gsr_blend.hip: can_touch_quad), intersected with the reference's square.  An instance dropped here passes
         // `alpha < 1/255 -> continue` (forward.cu:340-344) at every pixel of its tile, so images, radii and gradients
         // do not change; num_rendered, the lists and n_contrib do.  radii keeps the reference's value.
-        const float o = a.opacities[idx];
+        const float o = GSR_K1_PREFETCH ? my_opacity : a.opacities[idx];
         float hx = (float)radius_i, hy = (float)radius_i;
         if (o < 1.0f / 255.0f) {
           ntiles = 0;  // never reaches the threshold (a NaN opacity fails this test and keeps the reference rectangle)
@@ -325,27 +368,26 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
   // ---- colour: forward.cu:20-71, or a copy of colors_precomp into the gather record
   if (live) {
       float4 col = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!a.skip_color) {
-        if (a.colors_precomp != nullptr) {
-          col.x = a.colors_precomp[3 * (size_t)idx];
-          col.y = a.colors_precomp[3 * (size_t)idx + 1];
-          col.z = a.colors_precomp[3 * (size_t)idx + 2];
+      if (!skip_color) {
+        if (colors_precomp != nullptr) {
+          col.x = colors_precomp[3 * (size_t)idx];
+          col.y = colors_precomp[3 * (size_t)idx + 1];
+          col.z = colors_precomp[3 * (size_t)idx + 2];
         } else {
           V3 dir = {p.x - cam.campos[0], p.y - cam.campos[1], p.z - cam.campos[2]};
           const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
           dir = {dir.x / len, dir.y / len, dir.z / len};
-          V3 sh[16];
-          load_sh(a.shs, (size_t)idx, a.M, a.D, sh);
+          if (!sh_loaded) load_sh(a.shs, (size_t)idx, M, D, sh);
           V3 result = SH_C0 * sh[0];
-          if (a.D > 0) {
+          if (D > 0) {
             const float x = dir.x, y = dir.y, z = dir.z;
             result = result - (SH_C1 * y) * sh[1] + (SH_C1 * z) * sh[2] - (SH_C1 * x) * sh[3];
-            if (a.D > 1) {
+            if (D > 1) {
               const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
               result = result + (SH_C2[0] * xy) * sh[4] + (SH_C2[1] * yz) * sh[5] +
                        (SH_C2[2] * (2.0f * zz - xx - yy)) * sh[6] + (SH_C2[3] * xz) * sh[7] +
                        (SH_C2[4] * (xx - yy)) * sh[8];
-              if (a.D > 2) {
+              if (D > 2) {
                 result = result + (SH_C3[0] * y * (3.0f * xx - yy)) * sh[9] + (SH_C3[1] * xy * z) * sh[10] +
                          (SH_C3[2] * y * (4.0f * zz - xx - yy)) * sh[11] +
                          (SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[12] +
@@ -354,9 +396,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
               }
             }
           }
-          if (!a.forward_only && a.D > 0) {  // what the backward needs of the SH record (see Geom::dcol)
+          if (!a.forward_only && D > 0) {  // what the backward needs of the SH record (see Geom::dcol)
             V3 ddx, ddy, ddz;
-            sh_color_dir_derivatives(a.D, dir.x, dir.y, dir.z, sh, ddx, ddy, ddz);
+            sh_color_dir_derivatives(D, dir.x, dir.y, dir.z, sh, ddx, ddy, ddz);
             *reinterpret_cast<V3*>(a.g.dcol[0] + 3 * (size_t)idx) = ddx;  // (12-byte records: one dwordx3 store each)
             *reinterpret_cast<V3*>(a.g.dcol[1] + 3 * (size_t)idx) = ddy;
             *reinterpret_cast<V3*>(a.g.dcol[2] + 3 * (size_t)idx) = ddz;
@@ -370,7 +412,7 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_e
         }
       }
       // forward.cu:250-255
-      a.g.rec0[idx] = make_float4(conx, cony, conz, a.opacities[idx]);
+      a.g.rec0[idx] = make_float4(conx, cony, conz, GSR_K1_PREFETCH ? my_opacity : a.opacities[idx]);
       a.g.rec1[idx] = make_float4(pix, piy, my_depth, my_radius);
       a.g.rec2[idx] = col;
   }
@@ -1067,7 +1109,9 @@ __global__ void __launch_bounds__(GAUSS_BLOCK) view_messages_accumulate_kernel(i
 // ----------------------------------------------------------------------------------
 hipError_t launch_preprocess(hipStream_t s, const PreArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
-  hipLaunchKernelGGL(preprocess_kernel, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  const bool main_mode = a.cov3D_precomp == nullptr && a.colors_precomp == nullptr && !a.skip_color && a.M == 16 && a.D == 3;
+  if (main_mode) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
+  else hipLaunchKernelGGL(preprocess_kernel<false>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
   return hipGetLastError();
 }
 // Test-only introspection: unpack the gather records into the reference's separate arrays.
