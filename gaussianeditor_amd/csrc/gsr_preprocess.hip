@@ -576,15 +576,41 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     load_cam(cam, a.viewmatrix, a.projmatrix, a.shs ? a.campos : nullptr);
     const float* view = cam.view;
     const float* proj = cam.proj;
+    // Every input of a visible Gaussian is requested HERE, together: in source order (each load in front of its use) a wave
+    // went through five dependent memory round trips -- position / scale / rotation / conic gradient, the screen-space
+    // gradient, the colour hand-off, scale / rotation again -- with the kernel's arithmetic in between.
     const V3 mean = {a.means3D[3 * idx], a.means3D[3 * idx + 1], a.means3D[3 * idx + 2]};
+    float sc0 = 0.f, sc1 = 0.f, sc2 = 0.f;
+    float4 quat = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.scales != nullptr) {
+      sc0 = a.scales[3 * idx];
+      sc1 = a.scales[3 * idx + 1];
+      sc2 = a.scales[3 * idx + 2];
+      quat = reinterpret_cast<const float4*>(a.rotations)[idx];
+    }
+    const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
+    const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+    V3 dRGBdx = {0.f, 0.f, 0.f}, dRGBdy = {0.f, 0.f, 0.f}, dRGBdz = {0.f, 0.f, 0.f}, dL_dRGB = {0.f, 0.f, 0.f};
+    uint8_t cl = 0;
+    if (a.shs != nullptr) {
+      // d(RGB)/d(dir): K1 evaluated it from the SH record it held (sh_color_dir_derivatives) -- the record itself is not read
+      // again (192 B per Gaussian at M = 16 against these 36); degree 0: the colour does not depend on the direction, K1
+      // wrote nothing
+      if (a.D > 0) {
+        dRGBdx = *reinterpret_cast<const V3*>(a.dcol[0] + 3 * (size_t)idx);
+        dRGBdy = *reinterpret_cast<const V3*>(a.dcol[1] + 3 * (size_t)idx);
+        dRGBdz = *reinterpret_cast<const V3*>(a.dcol[2] + 3 * (size_t)idx);
+      }
+      cl = a.clamped[idx];
+      dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
+    }
     float c3[6];
     if (a.cov3D_precomp != nullptr) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) c3[i] = a.cov3D_precomp[6 * (size_t)idx + i];
     } else {
-      cov3d_from_scale_rot(a.scales, a.scale_modifier, a.rotations, idx, c3);  // what K1 computed, bit for bit
+      cov3d_from_values(sc0, sc1, sc2, a.scale_modifier, quat, c3);  // what K1 computed, bit for bit
     }
-    const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
     const V3 dL_dcon = {gc.x, gc.y, gc.w};
     nonzero_in = gc.x != 0.f || gc.y != 0.f || gc.w != 0.f;
 
@@ -657,7 +683,6 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     const float m_w = 1.0f / (m_hw + 0.0000001f);
     const float mul1 = (proj[0] * m.x + proj[4] * m.y + proj[8] * m.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * m.x + proj[5] * m.y + proj[9] * m.z + proj[13]) * m_w * m_w;
-    const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
     nonzero_in = nonzero_in || g2x != 0.f || g2y != 0.f;
     V3 dL_dmean;
     dL_dmean.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
@@ -670,17 +695,6 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       const V3 dir_orig = {m.x - cam.campos[0], m.y - cam.campos[1], m.z - cam.campos[2]};
       const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
       const V3 dir = {dir_orig.x / len, dir_orig.y / len, dir_orig.z / len};
-      // d(RGB)/d(dir): K1 evaluated it from the SH record it held (sh_color_dir_derivatives) -- the record itself is not read
-      // again (192 B per Gaussian at M = 16 against these 48)
-      // (degree 0: the colour does not depend on the direction, K1 wrote nothing)
-      V3 dRGBdx = {0.f, 0.f, 0.f}, dRGBdy = {0.f, 0.f, 0.f}, dRGBdz = {0.f, 0.f, 0.f};
-      if (a.D > 0) {
-        dRGBdx = *reinterpret_cast<const V3*>(a.dcol[0] + 3 * (size_t)idx);
-        dRGBdy = *reinterpret_cast<const V3*>(a.dcol[1] + 3 * (size_t)idx);
-        dRGBdz = *reinterpret_cast<const V3*>(a.dcol[2] + 3 * (size_t)idx);
-      }
-      const uint8_t cl = a.clamped[idx];
-      V3 dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
       nonzero_in = nonzero_in || dL_dRGB.x != 0.f || dL_dRGB.y != 0.f || dL_dRGB.z != 0.f;
       dL_dRGB.x *= (cl & 1) ? 0.f : 1.f;
       dL_dRGB.y *= (cl & 2) ? 0.f : 1.f;
@@ -724,14 +738,13 @@ preprocess_backward_kernel(const PreBwdArgs a) {
 
     if (a.scales != nullptr) {
       // computeCov3D (backward), backward.cu:278-341
-      const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+      const float4 q = quat;
       const float r = q.x, x = q.y, y = q.z, z = q.w;
       const M3 R = mk(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
                       2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
                       2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
       M3 S = mk(1, 0, 0, 0, 1, 0, 0, 0, 1);
-      const V3 s = {a.scale_modifier * a.scales[3 * idx], a.scale_modifier * a.scales[3 * idx + 1],
-                    a.scale_modifier * a.scales[3 * idx + 2]};
+      const V3 s = {a.scale_modifier * sc0, a.scale_modifier * sc1, a.scale_modifier * sc2};
       S.m[0][0] = s.x; S.m[1][1] = s.y; S.m[2][2] = s.z;
       const M3 Mm = mul(S, R);
       const M3 dL_dSigma = mk(dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3], 0.5f * dcov[4],
