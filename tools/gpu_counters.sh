@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=gpurun_out
 MD=$R/$O/${TAG}_counters.md
-echo "# ${TAG}: HBM traffic and VALU instructions per stage (rocprofv3 PMC passes over bench.py --train-only --steps 4 --warmup 1)" > $MD
+echo "# ${TAG}: HBM traffic and VALU instructions per stage (rocprofv3 PMC passes over bench.py --train-only --steps 4 --warmup 1 --prewarm 0)" > $MD
 echo >> $MD
 pass() { # dir, counters..., -- bench args
   d=$1; shift
@@ -19,9 +19,9 @@ pass() { # dir, counters..., -- bench args
 }
 run() { # key, bench args...
   key=$1; shift
-  F=$(pass $R/$O/${TAG}_f FETCH_SIZE -d $R/$O/${TAG}_f -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 "$@")
-  W=$(pass $R/$O/${TAG}_w WRITE_SIZE -d $R/$O/${TAG}_w -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 "$@")
-  S=$(pass $R/$O/${TAG}_s SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $R/$O/${TAG}_s -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 "$@")
+  F=$(pass $R/$O/${TAG}_f FETCH_SIZE -d $R/$O/${TAG}_f -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 --prewarm 0 "$@")
+  W=$(pass $R/$O/${TAG}_w WRITE_SIZE -d $R/$O/${TAG}_w -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 --prewarm 0 "$@")
+  S=$(pass $R/$O/${TAG}_s SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES -d $R/$O/${TAG}_s -o p -- python $R/bench.py --train-only --steps 4 --warmup 1 --prewarm 0 "$@")
   python tools/collect_counters.py --key "$key" --fetch "$F" --write "$W" --sq "$S" --md $MD \
     --note "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU passes (separate runs) over bench.py --train-only, tools/gpu_counters.sh $TAG; FETCH x2 on the two streaming kernels" > /dev/null
   rm -rf $R/$O/${TAG}_f $R/$O/${TAG}_w $R/$O/${TAG}_s
