@@ -513,6 +513,9 @@ def main():
     for _ in range(max(args.prewarm, 0)):  # (untimed, in front of the contract's warmup: clock ramp)
         train_step()
     sync_all()
+    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+        train_step()
+    sync_all()
     if dist.is_initialized():
         # RCCL's banner sits in the C library's stdout buffer until the process exits; push it out NOW (to stderr, see above),
         # so that it also precedes the JSON line for a reader that merges the two streams
@@ -522,9 +525,6 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:  # (no libc handle: the banner then leaves at exit, still on stderr)
             pass
-    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
-        train_step()
-    sync_all()
     # Timed region: exactly `steps` steps between barrier + synchronize on both sides (the contract's number).  An event
     # per step on the launch stream additionally gives the distribution of the GPU-side step time (median / p10 / p90,
     # SURVEY.md section 8(d)) without adding any synchronisation.
