@@ -339,6 +339,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--keep-gc", action="store_true",
+                    help="leave Python's cyclic garbage collector on during the timed steps (default: collected once and switched "
+                         "off around them, as training loops do: a generation-2 pass stalls the launch thread for milliseconds)")
     ap.add_argument("--prewarm", type=int, default=300,
                     help="untimed train steps in FRONT of the --warmup steps (same count on every rank): a GPU that comes out of idle "
                          "needs tens of milliseconds of load to reach its clocks, the contract's warmup may be a handful of steps")
@@ -530,6 +533,10 @@ def main():
     # SURVEY.md section 8(d)) without adding any synchronisation.
     cur = torch.cuda.current_stream(dev)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    import gc
+
+    if not args.keep_gc:
+        gc.disable()  # (no collect() here: tens of milliseconds of host time in front of the timed region let the GPU fall idle)
     t0 = time.perf_counter()
     step_ev[0].record(cur)
     for i in range(args.steps):
@@ -537,6 +544,7 @@ def main():
         step_ev[i + 1].record(cur)
     sync_all()
     train_s = max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
     step_ms = [step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)]
     local_ms = [step_ev[i].elapsed_time(m["local_done"]) for i, m in enumerate(marks_log) if m and "local_done" in m]
     exch_ms = [m["local_done"].elapsed_time(m["step_done"]) for m in marks_log if m and "step_done" in m]
