@@ -34,6 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the host driver of these boxes only supports dmabuf IPC: without this RCCL's peer access between ranks fails with
+# `hipIpcGetMemHandle: invalid argument` (exported in the image already; kept for a launcher that starts from a clean environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
