@@ -1,5 +1,5 @@
 #!/bin/bash
-# group_chunk_kernel: all loads of a chunk in front of its early exit (one memory round trip + the tile_start lookup instead of two)
+# group_chunk_kernel: two entries of each stream per round in the list-append loop
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
 {
