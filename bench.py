@@ -501,8 +501,9 @@ def main():
     rows_mode = "auto" if rows_env is None else (rows_env == "1")
     marks_log = []
 
-    def train_step(record=False):
-        marks = {} if record else None
+    def train_step(record=False, marks=None):
+        if record and marks is None:
+            marks = {}
         if batch_mode:
             # the fixed batch: this rank's block of views, one message per view, one all-gather (multiview_batch_step)
             _, radii, _, _ = multiview_batch_step(rs_list, params, [G] * len(rs_list), bucket, marks=marks)
@@ -537,6 +538,9 @@ def main():
     # SURVEY.md section 8(d)) without adding any synchronisation.
     cur = torch.cuda.current_stream(dev)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # (the steps' own marks -- local_done / step_done, multiview._mark -- are created here as well: an event created inside the
+    #  timed region can stall the launch thread for milliseconds when the runtime has to grow its pool)
+    step_marks = [{k: torch.cuda.Event(enable_timing=True) for k in ("local_done", "step_done")} for _ in range(args.steps)]
     import gc
 
     if not args.keep_gc:
@@ -544,7 +548,7 @@ def main():
     t0 = time.perf_counter()
     step_ev[0].record(cur)
     for i in range(args.steps):
-        train_step(record=True)
+        train_step(record=True, marks=step_marks[i])
         step_ev[i + 1].record(cur)
     sync_all()
     train_s = max_over_ranks(time.perf_counter() - t0)

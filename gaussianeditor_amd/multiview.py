@@ -446,9 +446,11 @@ def _mark(marks, name, dev):
     """`marks` (a dict, optional argument of the step functions): an event on the launch stream at the named point, so that a
     caller (bench.py) can tell the local render time from the exchange time without adding any synchronisation."""
     if marks is not None and dev.type == "cuda":
-        ev = torch.cuda.Event(enable_timing=True)
+        ev = marks.get(name)
+        if not isinstance(ev, torch.cuda.Event):  # (a caller that times many steps hands the events in: creating one can
+            ev = torch.cuda.Event(enable_timing=True)  # cost the launch thread milliseconds when the runtime grows its pool)
+            marks[name] = ev
         ev.record(torch.cuda.current_stream(dev))
-        marks[name] = ev
 
 
 def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, torch.Tensor], dL_dcolor: torch.Tensor,
