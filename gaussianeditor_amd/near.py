@@ -15,8 +15,13 @@ import torch
 from . import _native
 
 
-def near_points(ref_xyz: torch.Tensor, query_xyz: torch.Tensor, dist_thresh: float, return_dist: bool = False):
+def near_points(ref_xyz: torch.Tensor, query_xyz: torch.Tensor, dist_thresh: float, return_dist: bool = False,
+                check_finite: bool = True):
     """near[q] = some row of ref_xyz lies within dist_thresh of query_xyz[q]; (n_ref,3), (n_query,3) float32 on the GPU.
+
+    check_finite (default): a NaN / infinite coordinate raises ValueError, as scipy's KDTree does on the reference's route
+    ("data must be finite", "'x' must be finite"); it costs one small reduction and a readback.  Without it such points are
+    simply never near anything.
 
     return_dist: also the 1-NN distances, exact where <= dist_thresh and +inf where nothing lies within the search radius
     (the reference's KDTree returns the true distance everywhere; its caller only thresholds it)."""
@@ -29,6 +34,12 @@ def near_points(ref_xyz: torch.Tensor, query_xyz: torch.Tensor, dist_thresh: flo
         raise RuntimeError("near_points: ref_xyz and query_xyz must be on the same device")
     if not dist_thresh >= 0:
         raise ValueError("near_points: dist_thresh must be >= 0")
+    if check_finite:
+        ok = torch.stack([torch.isfinite(ref_xyz).all(), torch.isfinite(query_xyz).all()]).tolist()
+        if not ok[0]:
+            raise ValueError("near_points: ref_xyz must be finite, check for nan or inf values")
+        if not ok[1]:
+            raise ValueError("near_points: query_xyz must be finite, check for nan or inf values")
     dev = query_xyz.device
     n_ref, n_query = int(ref_xyz.size(0)), int(query_xyz.size(0))
     near = torch.zeros((n_query,), dtype=torch.uint8, device=dev)

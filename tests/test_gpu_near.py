@@ -82,6 +82,14 @@ def test_near_points_empty_sets_and_validation():
         near_points(o, torch.ones(5, 4, device=DEV), 0.1)
     with pytest.raises(ValueError):
         near_points(o, o, -1.0)
+    # non-finite coordinates: the reference's KDTree raises ValueError on either side; without the check they are never near
+    bad = o.clone()
+    bad[2, 1] = float("nan")
+    with pytest.raises(ValueError, match="ref_xyz must be finite"):
+        near_points(bad, o, 0.1)
+    with pytest.raises(ValueError, match="query_xyz must be finite"):
+        near_points(o, bad, 0.1)
+    assert near_points(o, bad, 0.1, check_finite=False).tolist() == [True, True, False, True, True]
 
 
 def test_get_near_gaussians_by_mask_matches_reference_fixture(oracle):
