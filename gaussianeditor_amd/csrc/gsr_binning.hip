@@ -29,6 +29,8 @@
 // look-back, so no inter-workgroup hand-off inside a launch (per-XCD L2s are not coherent; a kernel
 // boundary is the cheapest correct fence).  Stability comes from ranking with wave64 ballots in key
 // order, never from atomics.
+#include <stdlib.h>
+
 #include "gsr_kernels.h"
 
 namespace gsr {
@@ -907,8 +909,9 @@ __global__ void __launch_bounds__(1024) tile_worklist_kernel(int T, uint2* __res
     // every few hundred list positions, the backward walks such a tile's list as independent segments
     ck_table[t] = (len != 0u && pos < n_ck_tiles) ? pos : CK_NONE;
   }
-  // per-quadrant work counters of the forward blend (the items of a quadrant combine their counts with atomicMax)
-  for (int i = threadIdx.x; i < 4 * T; i += 1024) est[i] = 0u;
+  // per-quadrant work counters and walk depths of the forward blend (Image::work_est, work_maxc: contiguous; quadrants
+  // outside the image are never written, the items of a cut quadrant combine their values with atomicMax)
+  for (int i = threadIdx.x; i < 8 * T; i += 1024) est[i] = 0u;
   // work-queue cursors and retire counters of the three blend kernels start at zero; each blend launch leaves its
   // own zeroed again (gsr_blend.hip: retire_queue), so this is the only place that clears them
   for (int i = threadIdx.x; i < QUEUE_KINDS * QUEUE_LINES; i += 1024) {

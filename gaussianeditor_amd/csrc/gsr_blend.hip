@@ -25,6 +25,8 @@
 //     the reference issues one per pixel.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "gsr_kernels.h"
 
 namespace gsr {
@@ -163,9 +165,42 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
   if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
 
+// Read-only tables of an earlier kernel, read through the SCALAR cache at a wave-uniform index (s_load: its counter,
+// lgkmcnt, is independent of the vector memory counter, so picking such a value up never waits for stores or gathers).
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t scalar_load(const uint32_t* p, uint32_t i) {
+  return ((__attribute__((address_space(4))) const uint32_t*)(uintptr_t)p)[i];
+}
+__device__ __forceinline__ uint2 scalar_load(const uint2* p, uint32_t i) {
+  const u32x2 v = ((__attribute__((address_space(4))) const u32x2*)(uintptr_t)p)[i];
+  return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 scalar_load(const uint4* p, uint32_t i) {
+  const u32x4 v = ((__attribute__((address_space(4))) const u32x4*)(uintptr_t)p)[i];
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// max over the 64 lanes of a wave, in every lane: 6 v_max_u32_dpp (row_shr 1, 2, 4, 8, row_bcast 15 / 31) + one v_readlane
+__device__ __forceinline__ uint32_t wave_max_u32_dpp(uint32_t v) {
+  auto step = [](uint32_t w, auto ctrl, auto rows) __attribute__((always_inline)) {
+    return max(w, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, decltype(ctrl)::value, decltype(rows)::value, 0xf, false));
+  };
+  v = step(v, std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+  v = step(v, std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+  v = step(v, std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+  v = step(v, std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+  v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+  v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 #ifndef GSR_FWD_SELECT_CHAIN
 #define GSR_FWD_SELECT_CHAIN 1  // 0: the masked (exec-region) serial part for every chunk (A/B builds)
+#endif
+#ifndef GSR_BWD_DEFER_FLUSH
+#define GSR_BWD_DEFER_FLUSH 1  // 0: round 4's loop -- flush at the end of its own chunk, two barriers per chunk (A/B builds)
 #endif
 
 // Sums each of four per-lane values over the 64 lanes of the wave, 10 instructions for all four
@@ -351,12 +386,15 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
+// `range`: the tile's list range (ranges[tile]); `bg`: the background, read once per kernel; `next`: the wave's item
+// stream -- the pop for the item after this one is issued BEHIND this item's first loads.
+// `bg`: the background, read once per kernel (see blend_forward_kernel).
 template <bool PROFILE, bool AUX, int SPLIT, bool FAST, bool CKPT>
-__device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, uint32_t& prof_visited,
-                                             uint64_t* prof_cyc) {
+__device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, const float bg0, const float bg1,
+                                             const float bg2, uint32_t& prof_visited, uint64_t* prof_cyc) {
   PixelWave pw;
   ItemBox box;
-  if (!setup_item<SPLIT>(a, tile, quad, pw, box)) return;  // (work_est was cleared by tile_worklist_kernel)
+  if (!setup_item<SPLIT>(a, tile, quad, pw, box)) return;  // (work_est / work_maxc were cleared by tile_worklist_kernel)
   quad &= 3u;
   const int lane = lane_id();
   const uint2 range = a.ranges[pw.tile];
@@ -572,14 +610,24 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
     }
   }
   const float C0 = C01.x, C1 = C01.y, C2 = C2D.x, D = C2D.y;
-  // (the sub-items of a cut quadrant report the largest of their counts: they walk the same list)
-  if (a.work_est != nullptr && lane == 0) atomicMax(&a.work_est[4u * tile + quad], evaluated);
+  // how deep the backward will walk this quadrant's part of the list (a lane outside the image never contributes)
+  const uint32_t deep = (a.work_est != nullptr || ckpt) ? wave_max_u32_dpp(last_contributor) : 0u;
   if (ckpt) {
-    // how deep the backward will walk this tile, and -- for the pixels some checkpoint was written for -- the FINAL state
-    // (slot 0): with it a list segment's backward knows what lies behind its last position
-    const uint32_t deep = wave_max_u32(pw.inside ? last_contributor : 0u);
+    // ... for the whole tile, and -- for the pixels some checkpoint was written for -- the FINAL state (slot 0): with it a
+    // list segment's backward knows what lies behind its last position
     if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
     if (ck_k > 1u && pw.inside) a.ck_pool[(size_t)ck_base * CK_MAX * (TILE * TILE) + pidx] = make_float4(T, C0, C1, C2);
+  }
+  // the backward's work estimate and walk depth for the quadrant.  One item per quadrant: plain stores; the sub-items of a
+  // cut quadrant report the largest of their values (they walk the same list).
+  if (a.work_est != nullptr && lane == 0) {
+    if (SPLIT == 1) {
+      a.work_est[4u * tile + quad] = evaluated;
+      a.work_maxc[4u * tile + quad] = deep;
+    } else {
+      atomicMax(&a.work_est[4u * tile + quad], evaluated);
+      atomicMax(&a.work_maxc[4u * tile + quad], deep);
+    }
   }
   if (pw.inside) {
     const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
@@ -587,9 +635,9 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       a.final_T[pix] = T;
       a.n_contrib[pix] = last_contributor;
     }
-    a.out_color[pix] = __builtin_fmaf(T, a.bg[0], C0);
-    a.out_color[HW + pix] = __builtin_fmaf(T, a.bg[1], C1);
-    a.out_color[2 * HW + pix] = __builtin_fmaf(T, a.bg[2], C2);
+    a.out_color[pix] = __builtin_fmaf(T, bg0, C0);
+    a.out_color[HW + pix] = __builtin_fmaf(T, bg1, C1);
+    a.out_color[2 * HW + pix] = __builtin_fmaf(T, bg2, C2);
     if (a.out_depth != nullptr) a.out_depth[pix] = D;
   }
 }
@@ -600,12 +648,17 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)
   uint32_t prof_visited = 0, prof_items = 0;
   uint64_t prof_cyc[4] = {0, 0, 0, 0};
   if (PROFILE) t_start = __builtin_amdgcn_s_memtime();
+  // `bg` once per kernel, in scalar registers.  (Read at its uses, hipcc cannot prove that the image stores do not alias it:
+  // it re-loaded each component between two stores and waited for everything in flight each time.)
+  const float bg0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[0])));
+  const float bg1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[1])));
+  const float bg2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[2])));
   // (always_inline: past a size threshold hipcc stops inlining the item function into the work loop's two call sites and
   //  CALLS it -- the 300-byte argument block then travels through scratch memory)
   run_work_queue<SPLIT>(a, true, [&](uint32_t tile, uint32_t quad, bool empty) __attribute__((always_inline)) {
     if (PROFILE) prof_items++;
     if (!empty) {
-      forward_item<PROFILE, AUX, SPLIT, FAST, CKPT>(a, tile, quad, prof_visited, prof_cyc);
+      forward_item<PROFILE, AUX, SPLIT, FAST, CKPT>(a, tile, quad, bg0, bg1, bg2, prof_visited, prof_cyc);
     } else {
       // a tile no Gaussian touches: background only (forward.cu:371-378 with an empty range)
       for (uint32_t q = 0; q < 4; ++q) {
@@ -617,9 +670,9 @@ __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)
             a.final_T[pix] = 1.0f;
             a.n_contrib[pix] = 0u;
           }
-          a.out_color[pix] = __builtin_fmaf(1.0f, a.bg[0], 0.f);
-          a.out_color[HW + pix] = __builtin_fmaf(1.0f, a.bg[1], 0.f);
-          a.out_color[2 * HW + pix] = __builtin_fmaf(1.0f, a.bg[2], 0.f);
+          a.out_color[pix] = __builtin_fmaf(1.0f, bg0, 0.f);
+          a.out_color[HW + pix] = __builtin_fmaf(1.0f, bg1, 0.f);
+          a.out_color[2 * HW + pix] = __builtin_fmaf(1.0f, bg2, 0.f);
           if (a.out_depth != nullptr) a.out_depth[pix] = 0.f;
         }
       }
@@ -673,50 +726,51 @@ constexpr uint32_t BWD_ITEM_TILE = 0x000fffffu;   // (images of up to 2^20 tiles
 // cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
 // 2-3 of a tile's 4 quadrants.
 template <int ABLATE, bool FAST, bool SEG>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
-__device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t tile, float4 (*s0)[WAVE], float4 (*s1)[WAVE],
-                                              float4 (*s2)[WAVE], uint32_t* sid, float4* sco, float (*sacc)[WAVE],
-                                              uint32_t* s_maxc) {
+__device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint4 item, const float bg0, const float bg1,
+                                              const float bg2, float4 (*s0)[WAVE], float4 (*s1)[WAVE], float4 (*s2)[WAVE],
+                                              uint32_t (*sid)[WAVE], float4 (*sco)[WAVE], float (*sacc)[9][WAVE]) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
-  // item code (backward_worklist_kernel): a whole tile, wave w = quadrant w; or half a tile, waves (0,1) and (2,3) =
-  // the upper / lower 8x4 pixels of its two quadrants
+  // The item's descriptor (backward_worklist_kernel): x = code -- a whole tile, wave w = quadrant w; or half a tile, waves
+  // (0,1) and (2,3) = the upper / lower 8x4 pixels of its two quadrants; or one list segment --, y = first position of the
+  // tile's list, z = how deep the item's pixels reach into it (the forward's work_maxc).  Until round 4 the item held the
+  // code only and its start was a chain of dependent round trips: work list -> ranges, final_T, n_contrib -> maximum over
+  // the workgroup (two barriers) -> dL_dpixel, bg -> ids -> records.  Now everything per pixel and the first ids are
+  // requested together, right behind the descriptor.
+  uint32_t tile = item.x;
   const bool half_item = (tile & BWD_ITEM_HALF) != 0u;
   const uint32_t part = (tile & BWD_ITEM_PART) ? 1u : 0u;
   const bool seg_item = SEG && (tile & BWD_ITEM_SEG) != 0u;  // (SEG: a template switch -- the work list of a view without checkpoints holds no such item)
   const uint32_t seg = (tile >> BWD_SEG_SHIFT) & 15u, nseg_m1 = (tile >> BWD_NSEG_SHIFT) & 15u;
   tile &= BWD_ITEM_TILE;
-  PixelWave pw;
-  const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
-  const uint2 range = a.ranges[tile];
-  const float pfx = (float)pw.px, pfy = (float)pw.py;
-  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));  // origin of the wave's 8x8 lane grid
-  if (half_item) pw.inside = pw.inside && ((lane >> 5) == (w & 1));  // (lanes of the other half never become live)
-  const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
-  const bool live = has_pixels && pw.inside;
-
-  const float T_final = live ? a.final_T[pix] : 0.f;
-  float T = T_final;
-  const uint32_t last_contributor = live ? a.n_contrib[pix] : 0u;
-  const uint32_t maxc = wave_max_u32(last_contributor);
-  if (lane == 0) s_maxc[w] = maxc;
-  __syncthreads();
-  const uint32_t tile_max = max(max(s_maxc[0], s_maxc[1]), max(s_maxc[2], s_maxc[3]));
-  __syncthreads();
-  if (tile_max == 0) return 0u;  // uniform over the workgroup
+  const uint32_t list_base = item.y, tile_max = item.z;
+  if (tile_max == 0) return 0u;  // (uniform: nothing of the item's pixels ever contributed)
   // the list positions this item walks: all of [0, tile_max), or one segment of them
   const uint32_t stride = (uint32_t)a.ck_chunks * WAVE;
   const uint32_t seg_lo = seg_item ? seg * stride : 0u;
   const uint32_t seg_hi = (seg_item && seg != nseg_m1) ? min(tile_max, (seg + 1u) * stride) : tile_max;
   if (seg_lo >= seg_hi) return 0u;  // (uniform)
+  PixelWave pw;
+  const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
+  const float pfx = (float)pw.px, pfy = (float)pw.py;
+  const float qx0 = (float)(pw.px - (lane & 7)), qy0 = (float)(pw.py - (lane >> 3));  // origin of the wave's 8x8 lane grid
+  if (half_item) pw.inside = pw.inside && ((lane >> 5) == (w & 1));  // (lanes of the other half never become live)
+  const size_t HW = (size_t)a.H * a.W;
+  const bool live = has_pixels && pw.inside;
+  // per-pixel inputs: UNCONDITIONAL loads (a lane without a pixel reads pixel 0 and drops the values below; a predicated
+  // load makes hipcc wait for the data at the issue point), in front of the walker's first ids
+  const size_t pix = live ? (size_t)pw.py * a.W + pw.px : (size_t)0;
+  const float T_final_ld = a.final_T[pix];
+  const uint32_t n_contrib_ld = a.n_contrib[pix];
+  const float dpx_ld[3] = {a.dL_dpix[pix], a.dL_dpix[HW + pix], a.dL_dpix[2 * HW + pix]};
+  // back to front over the item's positions [seg_lo, seg_hi) of the tile's list, all four waves in the same chunks
+  ChunkWalker<false> walk(a, list_base + seg_lo, seg_hi - seg_lo);
 
-  float dpx[3] = {0.f, 0.f, 0.f};
-  if (live) {
-    dpx[0] = a.dL_dpix[pix];
-    dpx[1] = a.dL_dpix[HW + pix];
-    dpx[2] = a.dL_dpix[2 * HW + pix];
-  }
-  float bg_dot_dpixel = 0.f;
-#pragma unroll
-  for (int i = 0; i < 3; i++) bg_dot_dpixel += a.bg[i] * dpx[i];
+  const float T_final = live ? T_final_ld : 0.f;
+  float T = T_final;
+  const uint32_t last_contributor = live ? n_contrib_ld : 0u;
+  const uint32_t maxc = wave_max_u32_dpp(last_contributor);  // (this wave's pixels; the item's is tile_max)
+  const float dpx[3] = {live ? dpx_ld[0] : 0.f, live ? dpx_ld[1] : 0.f, live ? dpx_ld[2] : 0.f};
+  const float bg_dot_dpixel = (0.f + bg0 * dpx[0]) + bg1 * dpx[1] + bg2 * dpx[2];
   const float neg_Tfinal_bg = -T_final * bg_dot_dpixel;  // the background's share of dL/dalpha is this times 1 / (1 - alpha)
   const float ddelx_dx = 0.5f * a.W, ddely_dy = 0.5f * a.H;
 
@@ -736,14 +790,78 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
     B_acc = ((fin.y - ck.y) * dpx[0] + (fin.z - ck.z) * dpx[1] + (fin.w - ck.w) * dpx[2]) / ck.x;
   }
 
-  // back to front over the item's positions [seg_lo, seg_hi) of the tile's list, all four waves in the same chunks
-  ChunkWalker<false> walk(a, range.x + seg_lo, seg_hi - seg_lo);
+  // Flush of one chunk's accumulators: thread (w, lane) owns chunk slot `lane`; wave 0 forms dL_dmean2D from moments 1, 2
+  // and the conic, wave 1 dL_dconic from moments 3-5, wave 2 dL_dopacity + the first colour channel, wave 3 the other two.
+  // One global atomic per (tile, instance, term); slots no pixel of the tile touched are skipped.  Every (term, slot) is
+  // read by exactly one thread, which also puts it back to zero for the buffer's next chunk.
+  auto flush = [&](uint32_t fb, uint32_t fsize) __attribute__((always_inline)) {
+    const uint32_t p = (uint32_t)lane;
+    constexpr bool emit = ABLATE != 2 && ABLATE != 3;  // (experiments: no global atomics)
+    float(*acc)[WAVE] = sacc[fb];
+    if (p < fsize) {  // (slots >= fsize are never added to)
+      const size_t id = sid[fb][p];
+      if (w == 0) {
+        const float t1 = acc[1][p], t2 = acc[2][p];
+        if (t1 != 0.f || t2 != 0.f) {
+          acc[1][p] = 0.f;
+          acc[2][p] = 0.f;
+          const float4 co = sco[fb][p];  // conic.x, conic.y, conic.z, opacity
+          // backward.cu:545-546: dL_dmean2D = -o (A t1 + B t2, B t1 + C t2) * (0.5 W, 0.5 H)
+          if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id], -(ddelx_dx * co.w) * (co.x * t1 + co.y * t2));
+          if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 1], -(ddely_dy * co.w) * (co.y * t1 + co.z * t2));
+        }
+      } else if (w == 1) {
+        const float t3 = acc[3][p], t4 = acc[4][p], t5 = acc[5][p];
+        if (t3 != 0.f || t4 != 0.f || t5 != 0.f) {
+          acc[3][p] = 0.f;
+          acc[4][p] = 0.f;
+          acc[5][p] = 0.f;
+          const float h = -0.5f * sco[fb][p].w;
+          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id], h * t3);      // backward.cu:549
+          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 1], h * t4);  // backward.cu:550
+          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 3], h * t5);  // backward.cu:551
+        }
+      } else if (w == 2) {
+        const float t0 = acc[0][p], t6 = acc[6][p];
+        if (t0 != 0.f) {
+          acc[0][p] = 0.f;
+          if (emit) unsafeAtomicAdd(&a.dL_dopacity[id], t0);  // backward.cu:554
+        }
+        if (t6 != 0.f) {
+          acc[6][p] = 0.f;
+          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id], t6);  // backward.cu:523
+        }
+      } else {
+        const float t7 = acc[7][p], t8 = acc[8][p];
+        if (t7 != 0.f) {
+          acc[7][p] = 0.f;
+          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 1], t7);
+        }
+        if (t8 != 0.f) {
+          acc[8][p] = 0.f;
+          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 2], t8);
+        }
+      }
+    }
+  };
+
+  // The flush of chunk k is DEFERRED into iteration k + 1 (round 5), behind the walker's prefetch loads: a wave's vector
+  // memory operations retire in order, so the wait for the next chunk's records at the top of an iteration also waited for
+  // the memory-side float atomics the flush had issued a few instructions earlier (ISA: s_waitcnt vmcnt(0) in the loop
+  // header) -- one atomic round trip per chunk on every wave's critical path.  Now the atomics of chunk k have the whole
+  // group loop of chunk k + 1 to complete.  The accumulators, sid and sco are double-buffered by chunk parity, which also
+  // removes one of the two workgroup barriers per chunk: chunk k + 1 writes buffer (k + 1) & 1, whose last flush (chunk
+  // k - 1) ran in iteration k, in front of barrier (B) of that iteration.
+  uint32_t pend_size = 0u;  // slots of the previous chunk still to be flushed (0: none)
   for (; walk.valid(); walk.advance()) {
-    __syncthreads();  // (A) the previous chunk's flush is complete: sacc is zero again, sid is free
     const uint32_t csize = walk.chunk_size();
+    const uint32_t cb = walk.chunk & 1u;
+#if !GSR_BWD_DEFER_FLUSH
+    __syncthreads();  // (A) the previous chunk's flush is complete: sacc is zero again, sid is free
+#endif
     if (w == 0 && (uint32_t)lane < csize) {
-      sid[lane] = walk.cur.id;
-      sco[lane] = walk.cur.r0;
+      sid[cb][lane] = walk.cur.id;
+      sco[cb][lane] = walk.cur.r0;
     }
     const uint32_t pos = seg_lo + walk.lane_pos();
     // pixels that can still use an entry of this chunk: their last contributor lies above the chunk's lowest position;
@@ -772,6 +890,10 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
       s2[w][lane] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
     }
     wave_lds_sync();
+#if GSR_BWD_DEFER_FLUSH
+    if (pend_size != 0u) flush(cb ^ 1u, pend_size);  // (behind barrier (B) of the previous iteration)
+    pend_size = csize;
+#endif
 
     for (uint32_t j = 0; j < cnt4; j += GROUP) {
       float G[GROUP], al[GROUP], dxs[GROUP], dys[GROUP];
@@ -850,79 +972,39 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, uint32_t t
       if ((lane & 15) == 15) {
         const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[k][my_slot], tot[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[cb][k][my_slot], tot[k]);
       }
     }
-    __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc
-    {
-      // flush: thread (w, lane) owns chunk slot `lane`; wave 0 forms dL_dmean2D from moments 1, 2 and the conic, wave 1
-      // dL_dconic from moments 3-5, wave 2 dL_dopacity + the first colour channel, wave 3 the other two.  One global
-      // atomic per (tile, instance, term); slots no pixel of the tile touched are skipped.
-      const uint32_t p = (uint32_t)lane;
-      constexpr bool emit = ABLATE != 2 && ABLATE != 3;  // (experiments: no global atomics)
-      if (p < csize) {  // (slots >= csize are never added to)
-        const size_t id = sid[p];
-        // every (term, slot) is read by exactly one thread, which also puts it back to zero for the next chunk
-        if (w == 0) {
-          const float t1 = sacc[1][p], t2 = sacc[2][p];
-          if (t1 != 0.f || t2 != 0.f) {
-            sacc[1][p] = 0.f;
-            sacc[2][p] = 0.f;
-            const float4 co = sco[p];  // conic.x, conic.y, conic.z, opacity
-            // backward.cu:545-546: dL_dmean2D = -o (A t1 + B t2, B t1 + C t2) * (0.5 W, 0.5 H)
-            if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id], -(ddelx_dx * co.w) * (co.x * t1 + co.y * t2));
-            if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 1], -(ddely_dy * co.w) * (co.y * t1 + co.z * t2));
-          }
-        } else if (w == 1) {
-          const float t3 = sacc[3][p], t4 = sacc[4][p], t5 = sacc[5][p];
-          if (t3 != 0.f || t4 != 0.f || t5 != 0.f) {
-            sacc[3][p] = 0.f;
-            sacc[4][p] = 0.f;
-            sacc[5][p] = 0.f;
-            const float h = -0.5f * sco[p].w;
-            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id], h * t3);      // backward.cu:549
-            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 1], h * t4);  // backward.cu:550
-            if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 3], h * t5);  // backward.cu:551
-          }
-        } else if (w == 2) {
-          const float t0 = sacc[0][p], t6 = sacc[6][p];
-          if (t0 != 0.f) {
-            sacc[0][p] = 0.f;
-            if (emit) unsafeAtomicAdd(&a.dL_dopacity[id], t0);  // backward.cu:554
-          }
-          if (t6 != 0.f) {
-            sacc[6][p] = 0.f;
-            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id], t6);  // backward.cu:523
-          }
-        } else {
-          const float t7 = sacc[7][p], t8 = sacc[8][p];
-          if (t7 != 0.f) {
-            sacc[7][p] = 0.f;
-            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 1], t7);
-          }
-          if (t8 != 0.f) {
-            sacc[8][p] = 0.f;
-            if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 2], t8);
-          }
-        }
-      }
-    }
+    __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc[cb]
+#if !GSR_BWD_DEFER_FLUSH
+    flush(cb, csize);
+#endif
   }
+#if GSR_BWD_DEFER_FLUSH
+  // the last chunk (the next item's first LDS write lies behind barriers).  The walker's last prefetch -- chunks beyond the
+  // end, never used -- is drained first: the flush re-uses its registers, and behind the first atomic every such wait
+  // would be one for the atomic.
+  asm volatile("" ::"v"(walk.nxt.r0.x), "v"(walk.nxt.r1.x), "v"(walk.nxt.r2.x), "v"(walk.id_next), "v"(walk.id_next2));
+  if (pend_size != 0u) flush((walk.chunk - 1u) & 1u, pend_size);
+#endif
   return seg_hi - seg_lo;
 }
 
 template <int ABLATE, bool FAST, bool SEG>
 __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
-  __shared__ uint32_t sid[WAVE];
-  __shared__ float4 sco[WAVE];
-  __shared__ float sacc[9][WAVE];
-  __shared__ uint32_t s_maxc[BWD_WAVES];
+  __shared__ uint32_t sid[2][WAVE];  // (sid, sco, sacc: double-buffered by chunk parity, see backward_tile)
+  __shared__ float4 sco[2][WAVE];
+  __shared__ float sacc[2][9][WAVE];
   __shared__ uint32_t s_item;
-  for (int i = threadIdx.x; i < 9 * WAVE; i += WAVE * BWD_WAVES) (&sacc[0][0])[i] = 0.f;
-  // tile-granular queue: queue x (one per XCD) owns the non-empty tiles x, x+8, ... of work_order
+  for (int i = threadIdx.x; i < 2 * 9 * WAVE; i += WAVE * BWD_WAVES) (&sacc[0][0][0])[i] = 0.f;
+  // `bg` once per kernel, in scalar registers
+  const float bg0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[0])));
+  const float bg1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[1])));
+  const float bg2 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[2])));
+  // item-granular queue: queue x (one per XCD) owns items x, x+8, ... of the backward's work list
   const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;  // HW_REG_XCC_ID
-  const uint32_t nwork = a.work_meta[0];
+  const uint32_t nwork = a.bwd_meta[0];
   const uint32_t n_x = nwork > x ? (nwork - x + 7u) / 8u : 0u;
   uint32_t* head = a.queue + x * QUEUE_STRIDE;
   // debug timing (gsr_debug_blend_backward_profile): per workgroup start / end, tiles, longest and first tile
@@ -930,9 +1012,13 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
   uint64_t t_begin = 0, t_tile = 0, longest = 0, first = 0;
   uint32_t ntiles = 0, west = 0;
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
-  auto run_tile = [&](uint32_t tile) {
+  auto run_tile = [&](uint32_t index) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    const uint32_t tmax = backward_tile<ABLATE, FAST, SEG>(a, tile, s0, s1, s2, sid, sco, sacc, s_maxc);
+    // the descriptor: one scalar load (the work list is an earlier kernel's; the scalar path does not queue behind the
+    // previous item's last atomics)
+    const uint4 item = scalar_load(a.bwd_items, index);
+    const uint32_t tile = item.x;
+    const uint32_t tmax = backward_tile<ABLATE, FAST, SEG>(a, item, bg0, bg1, bg2, s0, s1, s2, sid, sco, sacc);
     if (prof) {
       const uint64_t d = __builtin_amdgcn_s_memtime() - t_tile;
       if (a.profile_items != nullptr && threadIdx.x == 0 && a.work_est != nullptr) {
@@ -959,21 +1045,20 @@ __global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_p
       }
     }
   };
-  // first tile assigned by placement (see first_item_of_block), the rest popped
+  // first item assigned by placement (see first_item_of_block), the rest popped
   uint32_t x0, base;
   const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   {
     const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
-    if (q0 < n0) run_tile(a.work_order[x0 + 8u * q0]);
+    if (q0 < n0) run_tile(x0 + 8u * q0);
   }
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_item = base + __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const uint32_t q = s_item;
-    __syncthreads();
     if (q >= n_x) break;
-    run_tile(a.work_order[x + 8u * q]);
+    run_tile(x + 8u * q);
   }
   if (prof && threadIdx.x == 0) {
     uint64_t* rec = a.profile + (size_t)blockIdx.x * 8;
@@ -1099,7 +1184,8 @@ struct ClearArgs {
 };
 template <bool SEG>
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
-                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
+                                                                const uint32_t* __restrict__ maxc, const uint2* __restrict__ ranges,
+                                                                uint4* __restrict__ items, uint32_t* __restrict__ meta,
                                                                 uint32_t workgroups, int allow_halves,  // allow_halves: 0, or the threshold in 1/8 of a fair share
                                                                 const ClearArgs clear, const uint32_t* __restrict__ tile_maxc,
                                                                 const uint32_t* __restrict__ ck_table,
@@ -1147,12 +1233,20 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   const bool in_regs = T <= 1024 * EST_REG;
   uint4 er[EST_REG];
   uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
+  // what an item's descriptor holds besides its code: the first position of the tile's list and how deep the pixels of
+  // the upper / lower pair of quadrants reach into it (the forward's work_maxc)
+  uint32_t first[EST_REG], reach01[EST_REG], reach23[EST_REG];
   const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && stride != 0u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
     const int t = (int)threadIdx.x + 1024 * j;
-    er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[t < T ? t : T - 1] : make_uint4(0u, 0u, 0u, 0u);
-    deep[j] = (in_regs && segments && T > 0) ? tile_maxc[t < T ? t : T - 1] : 0u;
+    const int tc = t < T ? t : T - 1;
+    er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[tc] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 mc = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(maxc)[tc] : make_uint4(0u, 0u, 0u, 0u);
+    first[j] = (in_regs && T > 0) ? ranges[tc].x : 0u;
+    reach01[j] = max(mc.x, mc.y);
+    reach23[j] = max(mc.z, mc.w);
+    deep[j] = (in_regs && segments && T > 0) ? tile_maxc[tc] : 0u;
     if (t >= T) {
       er[j] = make_uint4(0u, 0u, 0u, 0u);
       deep[j] = 0u;
@@ -1208,12 +1302,12 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
 #pragma unroll
       for (int j = 0; j < EST_REG; ++j) {
         const int t = (int)threadIdx.x + 1024 * j;
-        if (t < T) fn(t, er[j], nseg[j]);
+        if (t < T) fn(t, er[j], nseg[j], j);
       }
     } else {
       for (int t = threadIdx.x; t < T; t += 1024) {
         const uint4 e = reinterpret_cast<const uint4*>(est)[t];
-        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u);
+        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u, -1);
       }
     }
   };
@@ -1225,7 +1319,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     const uint32_t lo = j == 0u ? 0u : min(row[j], w), hi = j + 1u == ns ? w : min(row[j + 1u], w);
     return max(hi > lo ? hi - lo : 0u, 1u);
   };
-  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+  for_each_tile([&](int t, const uint4 e, uint32_t ns, int) {
     const uint32_t w = e.x + e.y + e.z + e.w;
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u);
@@ -1256,17 +1350,29 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+  for_each_tile([&](int t, const uint4 e, uint32_t ns, int j_reg) {
     const uint32_t w = e.x + e.y + e.z + e.w;
+    uint32_t f, r01, r23;
+    if (j_reg >= 0) {
+      f = first[j_reg];
+      r01 = reach01[j_reg];
+      r23 = reach23[j_reg];
+    } else {
+      const uint4 mc = reinterpret_cast<const uint4*>(maxc)[t];
+      f = ranges[t].x;
+      r01 = max(mc.x, mc.y);
+      r23 = max(mc.z, mc.w);
+    }
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j)
-        order[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
-            (uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT);
+        items[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
+            make_uint4((uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT), f, max(r01, r23), 0u);
     } else if (w >= threshold) {
-      order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
-      order[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
+      items[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF, f, r01, 0u);
+      items[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] =
+          make_uint4((uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART, f, r23, 0u);
     } else {
-      order[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = (uint32_t)t;
+      items[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t, f, max(r01, r23), 0u);
     }
   });
 }
@@ -1355,8 +1461,6 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size(true, s) / BWD_WAVES);
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(BWD_WAVES, s);
-  // its own work list, ordered by the work the forward measured (GSR_BWD_WORKLIST=0: reuse the forward's list)
-  static const bool own_list = [] { const char* e = getenv("GSR_BWD_WORKLIST"); return !e || atoi(e) != 0; }();
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   bool seg_items = false;  // the work list holds list-segment items (views whose forward left checkpoints)
@@ -1368,7 +1472,9 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     clear.ptr[2] = a.dL_dopacity; clear.n[2] = P;
     clear.ptr[3] = a.dL_dcolors; clear.n[3] = 3 * P;
   }
-  if (own_list && a.work_est != nullptr) {
+  if (a.work_est == nullptr || a.work_maxc == nullptr || a.bwd_items == nullptr) return hipErrorInvalidValue;
+  {
+    // its own work list (item descriptors), ordered by the work the forward measured
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
     const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : 0u;  // (1 .. 8 per CU: the same 14 us)
     // GSR_BWD_SEG: tiles above this many eighths of a fair share are cut into list segments where the forward left
@@ -1377,20 +1483,13 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     seg_items = a.ck_table != nullptr && a.ck_chunks > 0 && seg_share > 0 && ablate == 0;
     if (seg_items)
       hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear, (const uint32_t*)a.tile_maxc,
-                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, seg_share);
+                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES,
+                         halves, clear, (const uint32_t*)a.tile_maxc, (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work,
+                         (uint32_t)a.ck_chunks * WAVE, seg_share);
     else
       hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
-    a.work_order = a.bwd_order;
-    a.work_meta = a.bwd_meta;
-  } else {
-    a.units = 0;  // the list-length order is too poor a predictor for assigned first tiles (measured: +4 %)
-    for (int k = 0; k < 4 && a.clear_grads; ++k) {
-      hipError_t me = hipMemsetAsync(clear.ptr[k], 0, sizeof(float) * (size_t)clear.n[k], s);
-      if (me != hipSuccess) return me;
-    }
+                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES,
+                         halves, clear, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
   }
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size(true, s) / BWD_WAVES), b(WAVE * BWD_WAVES);

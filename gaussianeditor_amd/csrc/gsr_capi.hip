@@ -174,7 +174,8 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.work_order = im.work_order;
   a.work_meta = im.work_meta;
   a.work_est = im.work_est;
-  a.bwd_order = im.bwd_order;
+  a.work_maxc = im.work_maxc;
+  a.bwd_items = im.bwd_items;
   a.bwd_meta = im.bwd_meta;
   a.ranges = im.ranges;
   a.point_list = b.point_list;
@@ -363,6 +364,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   a.final_T = nullptr;
   a.n_contrib = nullptr;
   a.work_est = nullptr;
+  a.work_maxc = nullptr;
   a.ck_table = nullptr;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));

@@ -8,7 +8,7 @@ SRC=gaussianeditor_amd/csrc
 OUT=build_variants
 BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter"
 FILES="gsr_capi gsr_preprocess gsr_binning gsr_blend gsr_knn gsr_optim gsr_compact"
-ILP="-mllvm -amdgpu-sched-strategy=max-ilp"
+ILP="-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None"
 DEFAULT_VARIANTS=(
   "ilp_blend|gsr_blend:$ILP"
   "ilp_all|gsr_blend:$ILP;gsr_preprocess:$ILP;gsr_binning:$ILP"
