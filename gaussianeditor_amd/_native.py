@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: GSR_LIBRARY_PATH (development only: A/B timing of differently built libraries, tools/ab_variants.py) replaces the
 #: in-tree library; it must export the same ABI and is loaded under the same "no fallback" rule.
 LIB_PATH = os.environ.get("GSR_LIBRARY_PATH") or os.path.join(_HERE, "libgsr_hip.so")
-GSR_ABI_VERSION = 3
+GSR_ABI_VERSION = 4
 
 _P = c_void_p
 

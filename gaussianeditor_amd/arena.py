@@ -82,19 +82,21 @@ class RowArena:
     # --- layout
     def _reserve(self, capacity: int) -> None:
         old = None if self._buf is None else {k: self[k] for k in self.names}
-        self.capacity = int(capacity)
-        self._offsets, off = {}, 0
+        # the new layout is computed aside and installed only once its buffer exists: a caller that catches the
+        # allocation failure below keeps a consistent (smaller) arena
+        capacity = int(capacity)
+        offsets, off = {}, 0
         for k in self.names:
-            self._offsets[k] = off
-            off += _align(self.capacity * self.row_bytes[k])
-        self._half_bytes = off
+            offsets[k] = off
+            off += _align(capacity * self.row_bytes[k])
         try:
-            self._buf = torch.empty(2 * off, dtype=torch.uint8, device=self.device)
+            buf = torch.empty(2 * off, dtype=torch.uint8, device=self.device)
         except torch.OutOfMemoryError as ex:
             held = 0 if old is None else sum(int(t.numel()) * t.element_size() for t in old.values())
-            raise RuntimeError(f"RowArena: cannot allocate {2 * off / 2**30:.2f} GiB for {self.capacity} rows in two halves"
+            raise RuntimeError(f"RowArena: cannot allocate {2 * off / 2**30:.2f} GiB for {capacity} rows in two halves"
                                f" (the {held / 2**30:.2f} GiB of live rows stay allocated until they are copied); construct "
                                "the arena with a larger capacity up front, or with smaller headroom / growth") from ex
+        self.capacity, self._offsets, self._half_bytes, self._buf = capacity, offsets, off, buf
         self.allocations += 1
         self._live = 0
         if old is not None:

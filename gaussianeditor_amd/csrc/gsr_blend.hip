@@ -715,7 +715,8 @@ constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead
 // forward's checkpoint in front of its upper end instead of from their final state (backward_tile).
 constexpr uint32_t BWD_ITEM_SEG = 0x10000000u;
 constexpr int BWD_SEG_SHIFT = 20, BWD_NSEG_SHIFT = 24;  // 4 bits each: segment index, number of segments - 1
-constexpr uint32_t BWD_ITEM_TILE = 0x000fffffu;   // (images of up to 2^20 tiles)
+constexpr uint32_t BWD_ITEM_TILE = 0x000fffffu;   // (images of up to 2^20 tiles: GSR_MAX_TILES, checked by gsr_blend_backward)
+static_assert(BWD_ITEM_TILE + 1u == (uint32_t)GSR_MAX_TILES, "include/gsr.h states the backward's tile limit");
 
 
 // One tile, processed by a 4-wave workgroup (wave w = quadrant w).  The four waves walk the tile's list

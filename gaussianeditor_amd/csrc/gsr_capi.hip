@@ -145,10 +145,15 @@ inline int bin_legacy(int W, int H) {
 // strides below 256 the segments' start state shows in the per-row parity bar.  A function of what gsr_blend_forward
 // and gsr_blend_backward of a view both receive (R, W, H), so the two agree.  GSR_CK_CHUNKS overrides it (tests use 1 or 2
 // to segment small scenes; 0 = never).  Never changes a result beyond the backward's summation order.
+// Strides below 4 chunks (256 positions) put a list segment's start state -- a difference of two binary32 accumulators of
+// the forward -- inside the per-row parity bar (profiles/r04_d_segments.md): the override is clamped to >= 4 unless
+// GSR_CK_DEBUG=1 says the caller knows (the tolerance tests segment small scenes at stride 64).
 inline int checkpoint_chunks(int64_t R, int W, int H) {
   static const int env = [] {
     const char* e = getenv("GSR_CK_CHUNKS");
-    const int c = e != nullptr ? atoi(e) : -1;
+    const char* d = getenv("GSR_CK_DEBUG");
+    int c = e != nullptr ? atoi(e) : -1;
+    if (c > 0 && c < 4 && !(d != nullptr && d[0] == '1')) c = 4;
     return c > 1024 ? 1024 : c;
   }();
   if (env >= 0) return env;
@@ -220,7 +225,10 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
   if (P < 0 || R < 0 || G < 0 || W <= 0 || H <= 0 || sizes == nullptr) return GSR_ERR_BAD_ARGUMENT;
   sizes[0] = carve_geom(nullptr, P).bytes;
   sizes[1] = carve_binning(nullptr, R, G, W, H, bin_legacy(W, H)).bytes;
-  sizes[2] = carve_image(nullptr, W, H).bytes;
+  // (the checkpoint pool -- up to 64 MB, the LAST section of the image scratch -- only for views whose forward writes
+  //  checkpoints: the same predicate of (R, W, H) the blend entry points use.  R = 0, "not known yet": the size WITH the
+  //  pool, so that a buffer sized before gsr_preprocess is never too small)
+  sizes[2] = carve_image(nullptr, W, H, R == 0 || checkpoint_chunks(R, W, H) > 0).bytes;
   return GSR_OK;
 }
 
@@ -408,6 +416,8 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
     return GSR_OK;
   }
   if (P < 0 || R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
+  // (the backward's work items carry the tile id in 20 bits, next to the half / segment fields: gsr_blend.hip BWD_ITEM_TILE)
+  if ((int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE) > (int64_t)GSR_MAX_TILES) return GSR_ERR_BAD_ARGUMENT;
   if (!bg || !geom || !binning || !image || !dL_dpix || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors)
     return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);

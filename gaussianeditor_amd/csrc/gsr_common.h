@@ -137,7 +137,9 @@ constexpr int CK_MAX = 8;            // slots per tile: the final state + 7 chec
 constexpr uint32_t CK_NONE = 0xffffffffu;
 constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions) where checkpoints are on
 __host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (64 MB of slots at most)
-__host__ __device__ inline Image carve_image(void* base, int W, int H) {
+// with_ck_pool: false leaves the checkpoint pool out of `bytes` (it is the last section, so nothing else moves); the
+// pointer is still set and must not be used then (gsr_scratch_sizes / the blend entry points share one predicate)
+__host__ __device__ inline Image carve_image(void* base, int W, int H, bool with_ck_pool = true) {
   char* p = (char*)base;
   const size_t T = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
   const size_t N = (size_t)W * H;
@@ -156,7 +158,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H) {
   im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * T);
   im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * 8 /* CK_MAX */ * T);
   im.tile_maxc = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
-  im.ck_pool = (float4*)(p + off);      off += align_up(sizeof(float4) * 256 * 8 /* CK_MAX */ * (T < 2048 ? T : 2048));
+  im.ck_pool = (float4*)(p + off);      off += with_ck_pool ? align_up(sizeof(float4) * 256 * 8 /* CK_MAX */ * (T < 2048 ? T : 2048)) : 0;
   im.bytes = off;
   return im;
 }

@@ -76,17 +76,18 @@ def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations
                         viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, prefiltered, skip_color, radii, flags):
     L = _native.lib()
     s = _stream(dev)
-    gbytes, _, ibytes = _native.scratch_sizes(P, 0, W, H)
+    gbytes, _, _ = _native.scratch_sizes(P, 0, W, H)
     geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
-    img = torch.empty(ibytes, dtype=torch.uint8, device=dev)
     counts = (ctypes.c_int64 * 2)()  # num_rendered, and the number of tile-group instances the binning works on
     _native.check("gsr_preprocess", L.gsr_preprocess(
         s, P, D, M, _ptr(means3D), _ptr(scales), scale_modifier, _ptr(rotations), _ptr(opacity), _ptr(sh),
         _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H, tan_fovx, tan_fovy,
         int(bool(prefiltered)), int(skip_color), flags, radii.data_ptr(), geom.data_ptr(), counts))
     R, G = int(counts[0]), int(counts[1])
-    _, bbytes, _ = _native.scratch_sizes(P, R, W, H, G)
+    # (the image scratch is sized once R is known: its checkpoint pool, 64 MB at 1080p, exists only for views with long lists)
+    _, bbytes, ibytes = _native.scratch_sizes(P, R, W, H, G)
     binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
+    img = torch.empty(ibytes, dtype=torch.uint8, device=dev)
     _native.check("gsr_bin", L.gsr_bin(s, P, R, G, W, H, geom.data_ptr(), _ptr(binning), img.data_ptr()))
     return R, geom, binning, img
 

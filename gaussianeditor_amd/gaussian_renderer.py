@@ -125,3 +125,30 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     if semantic_color is not None:
         out["semantic"] = outs[3]
     return out
+
+
+def point_cloud_render(viewpoint_camera, xyz, pipe, bg_color: torch.Tensor, scaling_modifier=1.0, override_color=None):
+    """gaussian_renderer/__init__.py:156-250 (the web UI's point-cloud view, webui.py:39): every point as a white,
+    fully opaque, isotropic Gaussian of scale 0.005 with identity rotation; `pipe` and `override_color` are accepted and
+    unused, as in the reference.  Same returned dict as `render` (no `semantic` entry)."""
+    del pipe, override_color
+    means2D = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    try:
+        means2D.retain_grad()
+    except RuntimeError:
+        pass
+    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, 0))
+    n = xyz.shape[0]
+    rotations = torch.zeros((n, 4), dtype=xyz.dtype, device=xyz.device)
+    rotations[:, 0] = 1.0
+    image, radii, depth = rasterizer(
+        means3D=xyz.float(),
+        means2D=means2D.float(),
+        shs=None,
+        colors_precomp=torch.ones((n, 3), dtype=xyz.dtype, device=xyz.device),
+        opacities=torch.ones((n, 1), dtype=torch.float32, device=xyz.device),
+        scales=torch.full((n, 3), 0.005, dtype=torch.float32, device=xyz.device),
+        rotations=rotations.float(),
+        cov3D_precomp=None,
+    )
+    return {"render": image, "viewspace_points": means2D, "visibility_filter": radii > 0, "radii": radii, "depth_3dgs": depth}

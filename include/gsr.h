@@ -47,8 +47,18 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* Everything declared here has default visibility; the library itself is compiled with -fvisibility=hidden, so these
+ * entry points are ALL it exports (tests/test_cpu_abi.py checks both directions). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define GSR_ABI_VERSION 3
+/* 4 (round 5): adds gsr_near_workspace_size / gsr_near_points (round 4 had left the number at 3), the scratch layouts
+ * changed again (sizes come from gsr_scratch_sizes: rebuild nothing, re-query), images of more than GSR_MAX_TILES tiles
+ * are refused by the backward entry points instead of being walked wrongly. */
+#define GSR_ABI_VERSION 4
+/* Largest image the blend BACKWARD accepts, in 16 x 16 tiles (its work items carry the tile id in 20 bits). */
+#define GSR_MAX_TILES (1 << 20)
 
 typedef enum gsr_status {
   GSR_OK = 0,
@@ -69,7 +79,9 @@ int gsr_last_hip_error(void);
  * instances, G group instances (both returned by gsr_preprocess) and a W x H image.  Pass R = G = 0 before they are
  * known (sizes[1] is then 0).
  * sizes[0] = geometry (per Gaussian), sizes[1] = binning (per instance),
- * sizes[2] = image (per pixel / tile).
+ * sizes[2] = image (per pixel / tile).  sizes[2] with the real R may be smaller than with R = 0 (the forward's checkpoint
+ * pool -- 32 KB per tile, 64 MB at most -- is only needed for views with long lists): a caller that allocates the image
+ * scratch after gsr_preprocess saves it, one that sized it with R = 0 beforehand is always large enough.
  * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
 int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]);
 
@@ -91,8 +103,10 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *       state this call leaves: the 48 bytes per Gaussian only the backward reads (the colour's derivative by the view
  *       direction) are neither computed nor written.  A backward on such a state would read uninitialised memory; it is
  *       refused with GSR_ERR_BAD_ARGUMENT where the library can tell: when the flag is passed on to gsr_blend_backward /
- *       gsr_backward, and when `geom` is the buffer the most recent gsr_preprocess on it left forward-only (a host-side
- *       note per geometry buffer, no device read; a state copied to another buffer is not recognised).  The Python
+ *       gsr_backward, and when `geom` is the buffer the most recent gsr_preprocess on it left forward-only.  That second
+ *       check is BEST EFFORT by construction: a host-side table of 1 024 hashed slots keyed by the `geom` pointer, no device
+ *       read -- a note can be evicted by a gsr_preprocess on another buffer that hashes to its slot, and a state copied to
+ *       another buffer is not recognised; do not rely on it to catch the misuse.  The Python
  *       binding sets the flag exactly for renders none of whose inputs requires a gradient;
  *   GSR_FLAG_FAST_EXP    (read by the blend / trace entry points) exp(power) is evaluated with the hardware's
  *                        v_exp_f32 (2^x, 1 ulp) on power * log2(e) instead of the exactly specified polynomial
@@ -433,6 +447,9 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
                                     const void* binning, void* image, float* out_color, float* out_depth,
                                     uint64_t* records, int64_t max_records, int64_t* n_records_host);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -25,7 +25,16 @@ def test_header_symbols_are_exported_and_typed():
     # the Python binding types every declared symbol, and nothing that is not declared
     assert sorted(_native.SIGNATURES) == syms
     L = _native.lib()
-    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 3
+    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 4
+    # ... and the library exports NOTHING else: no C++ internals, kernel handles or toolchain objects (-fvisibility=hidden
+    # + csrc/gsr.map).  Read from the dynamic symbol table with nm.
+    import shutil
+    import subprocess
+
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.strip()})
+    assert exported == syms, sorted(set(exported) ^ set(syms))[:10]
     assert L.gsr_status_string(0) == b"ok" and b"channels" in L.gsr_status_string(-2)
 
 
@@ -40,7 +49,10 @@ def test_scratch_sizes_and_sort_bits():
     g0, b0, i0 = _native.scratch_sizes(1000, 0, 640, 480)
     g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480, 1500)
     # grouped binning: 4 bytes per tile instance (the point list) + 12 per group instance (ping-pong group ids and indices)
-    assert b0 == 0 and b1 > 5000 * 4 + 1500 * 12 and g1 > g0 > 1000 * 48 and i0 == i1 > 640 * 480 * 8
+    # (the image scratch sized before the counts are known, R = 0, includes the forward's checkpoint pool; with the counts of
+    #  a view with short lists it does not: 32 KB per tile less)
+    assert b0 == 0 and b1 > 5000 * 4 + 1500 * 12 and g1 > g0 > 1000 * 48 and i0 > i1 > 640 * 480 * 8
+    assert i0 - i1 == 40 * 30 * 8 * 4096 and _native.scratch_sizes(2000, 2048 * 1200, 640, 480, 1500)[2] == i0
     assert _native.scratch_sizes(2000, 5000, 640, 480, 3000)[1] > b1
     # beyond 131 072 tiles (2048 groups of 8 x 8) the tile-pair sort: ping-pong tile ids (uint32 there) + ping-pong indices
     assert _native.scratch_sizes(2000, 5000, 5808, 5808)[1] > 5000 * 16
@@ -94,6 +106,10 @@ def test_argument_validation_needs_no_gpu():
     assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 16) == -1
     assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, one, one, one, 16) == -1
     assert L.gsr_trace_weights(None, 10, 5, 64, 64, 1, one, one, one, one, one, one, 16) == -1
+    # the blend backward's work items carry the tile id in 20 bits (GSR_MAX_TILES of include/gsr.h): a larger image is
+    # refused, not walked with masked tile ids (16 400^2 pixels = 1 025^2 tiles > 2^20)
+    assert L.gsr_blend_backward(None, 10, 5, 16400, 16400, one, one, one, one, one, one, one, one, one, 0) == -1
+    assert "GSR_MAX_TILES (1 << 20)" in open(os.path.join(ROOT, "include", "gsr.h")).read()
 
 
 def test_options_are_per_render_and_per_thread():

@@ -110,6 +110,28 @@ def test_reference_render_runs_on_the_drop_in(oracle, monkeypatch, reference_mod
     assert np.array_equal(cnt.numpy().reshape(-1), c2) and np.array_equal(w.numpy(), w2)
 
 
+def test_reference_point_cloud_render_equals_the_mirror(oracle, monkeypatch, reference_modules):
+    """`point_cloud_render` (gaussian_renderer/__init__.py:156-250, imported by webui.py:39): the reference's own function on
+    the drop-in against the mirror's, outputs and the gradient of the screen-space points bit for bit."""
+    from gaussianeditor_amd import gaussian_renderer as mirror
+
+    oracle_backend.install(monkeypatch)
+    case = make_case(2000, 80, 48, seed=5, s0=0.05)
+    G = seed_gradient(48, 80, 1) * 48 * 80
+    outs = []
+    for fn in (reference_modules.renderer.point_cloud_render, mirror.point_cloud_render):
+        xyz = case["sc"]["xyz"].clone().requires_grad_(True)
+        out = fn(case["cam"], xyz, None, case["bg"])
+        (out["render"] * G).sum().backward()
+        outs.append((out, xyz))
+    (a, xa), (b, xb) = outs
+    assert set(a) == set(b) == {"render", "viewspace_points", "visibility_filter", "radii", "depth_3dgs"}
+    for k in ("render", "depth_3dgs", "radii", "visibility_filter"):
+        assert torch.equal(a[k], b[k]), k
+    assert int(a["visibility_filter"].sum()) > 100 and float(a["render"].max()) > 0.5
+    assert torch.equal(xa.grad, xb.grad) and torch.equal(a["viewspace_points"].grad, b["viewspace_points"].grad)
+
+
 def _adam_with_state(P, seed):
     gen = torch.Generator().manual_seed(seed)
     shapes = {"xyz": (P, 3), "f_dc": (P, 1, 3), "f_rest": (P, 15, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}

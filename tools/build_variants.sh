@@ -6,7 +6,7 @@ set -euo pipefail
 cd "$(dirname "$0")/.."
 SRC=gaussianeditor_amd/csrc
 OUT=build_variants
-BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize -Wall -Wextra -Wno-unused-parameter"
+BASE="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -munsafe-fp-atomics -fno-gpu-rdc -fno-slp-vectorize -fvisibility=hidden -Wall -Wextra -Wno-unused-parameter"
 FILES="gsr_capi gsr_preprocess gsr_binning gsr_blend gsr_knn gsr_optim gsr_compact"
 ILP="-mllvm -amdgpu-sched-strategy=max-ilp -mllvm -amdgpu-atomic-optimizer-strategy=None"
 DEFAULT_VARIANTS=(
@@ -33,6 +33,6 @@ for v in "${VARIANTS[@]}"; do
     fi
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libgsr_$name.so" $objs
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$SRC/gsr.map -o "$OUT/libgsr_$name.so" $objs
   echo "built $OUT/libgsr_$name.so"
 done
