@@ -55,8 +55,13 @@ def _sh_to_rgb(D: int, shs: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
 
 def render_f64(struct: Dict[str, np.ndarray], means3D, means2D, opacities, scales, rotations, shs, colors_precomp,
                cov3D_precomp, viewmatrix, projmatrix, campos, bg, W: int, H: int, tanfovx: float, tanfovy: float,
-               scale_modifier: float = 1.0, sh_degree: int = 0) -> torch.Tensor:
+               scale_modifier: float = 1.0, sh_degree: int = 0, dL_dimage=None) -> torch.Tensor:
     """Differentiable colour image (3,H,W) in float64.
+
+    `dL_dimage` (3,H,W): the gradient of a loss by the image.  The backward then runs INSIDE this call, tile by tile (a
+    tile's graph -- 256 pixels x list length x a dozen float64 tensors -- is freed before the next tile is built: scenes
+    with hundreds of thousands of instances fit in memory), the inputs' `.grad` are filled and the returned image is
+    detached.
 
     struct: dict from oracle.cpu.forward() supplying `point_list`, `ranges`, `radii`.
     Tensor arguments are float64 torch tensors (requires_grad as desired); pass
@@ -118,6 +123,13 @@ def render_f64(struct: Dict[str, np.ndarray], means3D, means2D, opacities, scale
         rgb = colors_precomp
 
     op = opacities.reshape(-1)
+    per_gaussian = None
+    if dL_dimage is not None:
+        # per-Gaussian quantities become leaves of the per-tile graphs; their gradients are pushed to the inputs at the end
+        per_gaussian = [px, py, conic, rgb, op]
+        px, py, conic, rgb, op = [t.detach().requires_grad_(True) for t in per_gaussian]
+        leaves = [px, py, conic, rgb, op]
+        dL = dL_dimage.to(dt)
     point_list = torch.from_numpy(struct["point_list"].astype(np.int64))
     ranges = struct["ranges"]
     gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -155,5 +167,13 @@ def render_f64(struct: Dict[str, np.ndarray], means3D, means2D, opacities, scale
             Tfinal = torch.where(live, one_m, torch.ones_like(one_m)).prod(dim=1)
             col = (w @ rgb[ids]).transpose(0, 1) + Tfinal[None, :] * bgd[:, None]
         hh, ww = ys.numel(), xs.numel()
+        if per_gaussian is not None:
+            if col.requires_grad:
+                (col.reshape(3, hh, ww) * dL[:, ty0:ty0 + hh, tx0:tx0 + ww]).sum().backward()
+            col = col.detach()
         out[:, ty0:ty0 + hh, tx0:tx0 + ww] = col.reshape(3, hh, ww)
+    if per_gaussian is not None:
+        pairs = [(t, l.grad) for t, l in zip(per_gaussian, leaves) if l.grad is not None and t.requires_grad]
+        if pairs:
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
     return out

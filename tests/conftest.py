@@ -23,3 +23,15 @@ def oracle():
 
     cpu.build()
     return cpu
+
+
+def pytest_terminal_summary(terminalreporter):
+    """How many tests of this run were checked against the reference's own code (oracle/_ref) -- a number that silently
+    drops to zero is what GSR_REQUIRE_REF=1 turns into failures."""
+    try:
+        import helpers
+    except ImportError:
+        return
+    n = len(helpers.REF_BACKED)
+    req = os.environ.get("GSR_REQUIRE_REF") == "1"
+    terminalreporter.write_line(f"reference-backed tests (oracle/_ref): {n} ran" + (" [GSR_REQUIRE_REF=1]" if req else ""))

@@ -96,3 +96,30 @@ def rel_err(a, b):
 
 
 __all__ = ["make_case", "oracle_forward", "oracle_backward", "settings", "hip_state", "rel_err", "seed_gradient"]
+
+
+# ---- the reference's own sources compiled for gfx950 (oracle/_ref): presence is LOUD when asked for ----
+REF_BACKED = []  # node ids of the tests that really ran against oracle/_ref (printed in the terminal summary, conftest.py)
+
+
+def require_ref(variant="nofma", knn=False):
+    """-> the `oracle.ref` module, after checking that the reference build `variant` exists.  The binaries are git-ignored
+    and reach the GPU box with gpurun's push of the work tree: where one is missing the test is SKIPPED -- unless
+    GSR_REQUIRE_REF=1 (tools/gpu_session.sh, tools/gpu_final.sh set it; the round-end driver should too), under which it
+    FAILS: a lost push must not turn the strongest parity evidence into green skips."""
+    import os
+
+    import pytest
+
+    from oracle import ref
+
+    ok = ref.knn_available(variant) if knn else ref.available(variant)
+    if not ok:
+        what = f"oracle/_ref ({'knn ' if knn else ''}{variant}) not built / not shipped (needs /root/reference at build time)"
+        if os.environ.get("GSR_REQUIRE_REF") == "1":
+            pytest.fail("GSR_REQUIRE_REF=1: " + what)
+        pytest.skip(what)
+    node = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    if node not in REF_BACKED:
+        REF_BACKED.append(node)
+    return ref

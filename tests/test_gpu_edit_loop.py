@@ -41,11 +41,9 @@ LAMBDA_L1 = 10.0
 
 
 def _ref_lib():
-    from oracle import ref
+    from helpers import require_ref
 
-    if not ref.available("nofma"):
-        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
-    return ref
+    return require_ref("nofma")
 
 
 class _RefRasterize(torch.autograd.Function):

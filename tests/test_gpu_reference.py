@@ -17,11 +17,9 @@ DEV = "cuda:0"
 
 
 def _ref(variant):
-    from oracle import ref
+    from helpers import require_ref
 
-    if not ref.available(variant):
-        pytest.skip(f"oracle/_ref not built ({variant})")
-    return ref.Reference(variant, DEV)
+    return require_ref(variant).Reference(variant, DEV)
 
 
 def _ref_forward(R, case, **kw):
@@ -180,10 +178,9 @@ def test_knn_vs_reference_simple_knn(P, kind):
     """distCUDA2 against the reference's own simple_knn.cu compiled for gfx950: bit-identical to the contraction-free
     build (both round dx*dx + dy*dy + dz*dz operation by operation), within one rounding of the default (FMA) build."""
     from gaussianeditor_amd.simple_knn._C import distCUDA2
-    from oracle import ref as R
+    from helpers import require_ref
 
-    if not R.knn_available("nofma"):
-        pytest.skip("oracle/_ref/libknn_ref_nofma.so not built (needs /root/reference at build time)")
+    R = require_ref("nofma", knn=True)
     g = torch.Generator().manual_seed(P)
     pts = torch.rand(P, 3, generator=g) * 2 - 1
     if kind == "clustered":

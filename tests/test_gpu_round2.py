@@ -32,11 +32,9 @@ def _np(t):
 
 
 def _ref(variant="nofma"):
-    from oracle import ref
+    from helpers import require_ref
 
-    if not ref.available(variant):
-        pytest.skip(f"oracle/_ref not built ({variant})")
-    return ref.Reference(variant, DEV)
+    return require_ref(variant).Reference(variant, DEV)
 
 
 def _product(case, G, flags=None):
@@ -314,6 +312,12 @@ def test_needle_gaussians_match_oracle(oracle, bounds):
     from oracle import ref as _refmod
 
     gr = None
+    import os as _os
+
+    if _os.environ.get("GSR_REQUIRE_REF") == "1":
+        from helpers import require_ref
+
+        require_ref("nofma")
     if _refmod.available("nofma"):
         sc, cam = case["sc"], case["cam"]
         R_ = _refmod.Reference("nofma", DEV)

@@ -196,7 +196,8 @@ def test_backward_list_segments_match_the_oracle_when_forced_on_small_scenes():
     threshold cut nearly every tile of the SMALL parity scenes into segments: forward / backward / apply_weights parity against the oracle in a fresh process with those knobs."""
     import subprocess
 
-    env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_BWD_SEG="1")
+    # (strides below 4 chunks are clamped outside GSR_CK_DEBUG=1, round 5: they are inside the per-row parity bar)
+    env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_CK_DEBUG="1", GSR_BWD_SEG="1")
     p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
                         "backward_vs_oracle or backward_precomp or forward_all_stages or edge_geometries or backward_twice"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)

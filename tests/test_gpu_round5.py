@@ -1,0 +1,180 @@
+"""-m gpu, round 5: the fuzz sweep's three outliers pinned against the reference's own backward and a float64 restatement;
+degenerate depth distributions through the depth sort; the arena's failed growth; the synth-v2 workload's parity case."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hip_state, make_case, oracle_backward, oracle_forward, require_ref, seed_gradient
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GRADS = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _sweep_case(seed):
+    """The configuration tests/test_gpu_parity.py::test_random_configuration_sweep draws for `seed` (same generator calls)."""
+    rng = np.random.default_rng(1000 + seed)
+    P = int([1, 2, 63, 65, 255, 256][seed] if seed < 6 else rng.integers(300, 6000))
+    W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 3 == 0 else rng.integers(1, 400))
+    H = int(rng.choice([1, 3, 16, 47]) if seed % 4 == 1 else rng.integers(1, 300))
+    D = int(rng.integers(0, 4))
+    case = make_case(P, W, H, seed=100 + seed, s0=float(rng.choice([0.01, 0.05, 0.3])), view=int(rng.integers(0, 4)),
+                     sh_degree=D, scale_xyz=float(rng.choice([0.2, 1.0, 2.5])))
+    return case, float(rng.choice([0.5, 1.0, 1.7])), D
+
+
+# tools/fuzz_parity.py, seeds 12 .. 3 188 (round 4): every integer and forward float bit-exact in all 3 177 configurations;
+# in these three ONE gradient tensor sat 18-29 % over the suite's 1e-5 bar on a single large Gaussian.
+FUZZ_OUTLIERS = (2977, 3019, 3186)
+
+
+@pytest.mark.parametrize("seed", FUZZ_OUTLIERS)
+def test_fuzz_outliers_are_no_further_from_float64_than_the_reference(oracle, seed):
+    """Four-way on the sweep's outliers: reference(no contraction) backward / oracle / product / float64 autograd.
+
+    The product's gradients must be no further from the float64 restatement than the reference's OWN backward
+    (backward.cu:417-556 compiled for gfx950) and the oracle are -- the needle test's pattern: a Gaussian that covers
+    thousands of pixels sums terms whose binary32 total depends on the summation order (the oracle adds pixel after pixel,
+    the kernels reduce waves and tiles, the reference's atomics any order).  Two conventions of the reference's analytic
+    backward that autograd does not share are taken out first: dL_dscales lacks the factor scale_modifier
+    (backward.cu:computeCov3D differentiates `mod * scale` by the product), and a Gaussian whose view-space x/z or y/z is
+    clamped to 1.3 tan(fov) (forward.cu:82-87) is differentiated with the clamped value as a constant -- those rows are
+    compared with the reference and the oracle only."""
+    import test_gpu_parity as tp
+    from oracle.torch_ref import render_f64
+
+    case, sm, D = _sweep_case(seed)
+    sc, cam, W, H = case["sc"], case["cam"], case["W"], case["H"]
+    P = sc["xyz"].shape[0]
+    f, _ = tp._compare_forward(oracle, case, scale_modifier=sm)  # every stage of the forward, bit for bit
+    G = seed_gradient(H, W, seed) * (H * W)
+    go = oracle_backward(oracle, case, f, G, scale_modifier=sm)
+    gp = tp._grads_hip(case, G, scale_modifier=sm)
+    R_ = require_ref("nofma").Reference("nofma", DEV)
+    R_.forward(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], sc["features"], None, None, cam.world_view_transform,
+               cam.full_proj_transform, cam.camera_center, case["bg"], W, H, case["tfx"], case["tfy"], sm, D)
+    gr = {k: _np(v) for k, v in R_.backward(G).items()}
+    # float64 autograd (CPU, tile by tile)
+    d = torch.float64
+    ins = {k: sc[k].to(d).requires_grad_(True) for k in ("xyz", "scaling", "rotation", "opacity", "features")}
+    m2 = torch.zeros(P, 3, dtype=d, requires_grad=True)
+    img = render_f64(f, ins["xyz"], m2, ins["opacity"], ins["scaling"], ins["rotation"], ins["features"], None, None,
+                     cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], W, H, case["tfx"],
+                     case["tfy"], sm, D, dL_dimage=G)
+    assert np.abs(img.float().numpy() - f["color"]).max() < 1e-5
+    g64 = {"dL_dmeans3D": ins["xyz"].grad, "dL_dmeans2D": m2.grad, "dL_dopacity": ins["opacity"].grad,
+           "dL_dscales": ins["scaling"].grad / sm, "dL_drotations": ins["rotation"].grad, "dL_dsh": ins["features"].grad}
+    pv = torch.cat([sc["xyz"].to(d), torch.ones(P, 1, dtype=d)], 1) @ cam.world_view_transform.to(d)
+    inside = ((pv[:, 0] / pv[:, 2]).abs() <= 1.3 * case["tfx"]) & ((pv[:, 1] / pv[:, 2]).abs() <= 1.3 * case["tfy"])
+    inside = inside.numpy()
+    print(f"seed {seed}: P={P} {W}x{H} D={D} scale_modifier={sm} R={f['num_rendered']}; rows inside the clamp cone {int(inside.sum())}")
+    for k in GRADS:
+        a = gp[k].reshape(P, -1).astype(np.float64)
+        o = go[k].reshape(P, -1).astype(np.float64)
+        r = gr[k].reshape(P, -1).astype(np.float64)
+        t = (torch.zeros_like(ins["xyz"]) if g64[k] is None else g64[k]).numpy().reshape(P, -1)
+        so = max(np.abs(o).max(), 1e-30)
+        e_po, e_ro = np.abs(a - o).max() / so, np.abs(r - o).max() / so
+        st = max(np.abs(t[inside]).max(), 1e-30)
+        e_pf, e_rf, e_of = (np.abs(x[inside] - t[inside]).max() / st for x in (a, r, o))
+        print(f"  {k:14s} vs oracle: product {e_po:.2e} reference {e_ro:.2e} | vs float64 (unclamped rows): product {e_pf:.2e} "
+              f"reference {e_rf:.2e} oracle {e_of:.2e}")
+        assert np.isfinite(a).all(), k
+        assert e_po <= max(1e-5, 3.0 * e_ro), k                 # no further from the oracle than the reference's atomics are
+        assert e_pf <= max(1e-5, 3.0 * max(e_rf, e_of)), k      # no further from float64 than the reference and the oracle
+
+
+def _depth_wall_case(P, W, H, kind, seed=3):
+    """Degenerate depth distributions for the depth sort (rasterizer_impl.cu:229-271 sorts 64-bit keys whatever they are),
+    seen by a camera that looks down the world's z axis, so that a point's view-space depth is its z + 4 exactly:
+    `wall`: every Gaussian at EXACTLY the same depth (all depth keys equal: the order is the index order);
+    `two`: such a wall and a handful of Gaussians far behind it (the key range spans octaves, the wall shares one value);
+    `steps`: sixteen walls."""
+    import math
+
+    from gaussianeditor_amd.synth import look_at_camera
+
+    case = make_case(P, W, H, seed=seed, s0=0.02)
+    cam = look_at_camera([0.0, 0.0, -4.0], [0.0, 0.0, 0.0], W, H)
+    case.update(cam=cam, tfx=math.tan(cam.FoVx / 2), tfy=math.tan(cam.FoVy / 2))
+    xyz = case["sc"]["xyz"]
+    g = torch.Generator().manual_seed(seed)
+    if kind == "wall":
+        xyz[:, 2] = 0.25
+    elif kind == "two":
+        xyz[:, 2] = 0.25
+        far = torch.randperm(P, generator=g)[:32]
+        xyz[far, 2] = 30.0 + 50.0 * torch.rand(32, generator=g)
+        xyz[far, :2] *= 4.0
+    else:
+        xyz[:, 2] = -0.5 + 0.0625 * torch.randint(0, 16, (P,), generator=g).float()
+    return case
+
+
+@pytest.mark.parametrize("kind", ["wall", "two", "steps"])
+def test_depth_sort_with_walls_of_equal_depth(oracle, kind):
+    """Sorted keys, point list, ranges, n_contrib and the image bit-identical to the oracle when (nearly) all depth keys are
+    equal -- ties must come out in ascending Gaussian index, as the reference's stable sort leaves them -- and gradients
+    within the bar."""
+    import test_gpu_parity as tp
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+
+    P, W, H = 60000, 640, 360
+    case = _depth_wall_case(P, W, H, kind)
+    sc, cam = case["sc"], case["cam"]
+    f = oracle_forward(oracle, case)
+    e = torch.empty(0, device=DEV)
+    d = lambda t: t.to(DEV)  # noqa: E731
+    R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+        d(case["bg"]), d(sc["xyz"]), e, d(sc["opacity"]), d(sc["scaling"]), d(sc["rotation"]), 1.0, e,
+        d(cam.world_view_transform), d(cam.full_proj_transform), case["tfx"], case["tfy"], H, W, d(sc["features"]), case["D"],
+        d(cam.camera_center), False, False)
+    st = hip_state(P, R, W, H, geom, binning, img)
+    vis = f["radii"] > 0
+    keys = f["depths"][vis].view(np.uint32)
+    print(f"{kind}: visible {int(vis.sum())}, distinct depth keys {len(np.unique(keys))}, R = {R}")
+    assert len(np.unique(keys)) <= (1 if kind == "wall" else 40) and int(vis.sum()) > P // 2
+    assert R == f["num_rendered"] and np.array_equal(st["keys"], f["keys"]) and np.array_equal(st["point_list"], f["point_list"])
+    same = f["keys"][1:] == f["keys"][:-1]
+    assert same.sum() > R // 2 and np.all(f["point_list"][1:][same] > f["point_list"][:-1][same])
+    assert np.array_equal(st["ranges"], f["ranges"]) and np.array_equal(st["n_contrib"], f["n_contrib"])
+    assert np.array_equal(_np(color), f["color"]) and np.array_equal(_np(depth), f["depth"])
+    G = seed_gradient(H, W, 5) * (H * W)
+    g = oracle_backward(oracle, case, f, G)
+    for k, v in tp._grads_hip(case, G).items():
+        assert tp.rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
+
+
+def test_row_arena_survives_a_failed_growth(monkeypatch):
+    """RowArena._reserve installed the new capacity and offsets before the allocation that can fail; a caller that
+    caught the error was left with the new layout over the old, smaller buffer.  Now the arena is unchanged."""
+    from gaussianeditor_amd.arena import RowArena
+
+    g = torch.Generator(device=DEV).manual_seed(1)
+    P = 3000
+    t = dict(xyz=torch.randn(P, 3, device=DEV, generator=g), rot=torch.randn(P, 4, device=DEV, generator=g))
+    arena = RowArena(t, headroom=1.0)
+    before = {k: arena[k].clone() for k in t}
+    cap, ptr = arena.capacity, arena["xyz"].data_ptr()
+    real = torch.empty
+
+    def failing_empty(*a, **kw):
+        if kw.get("dtype") == torch.uint8 and a and isinstance(a[0], int) and a[0] > 2 * 7 * 4 * cap:
+            raise torch.OutOfMemoryError("simulated")
+        return real(*a, **kw)
+
+    monkeypatch.setattr(torch, "empty", failing_empty)
+    with pytest.raises(RuntimeError, match="cannot allocate"):
+        arena.append({"xyz": torch.zeros(5000, 3, device=DEV), "rot": torch.zeros(5000, 4, device=DEV)})
+    monkeypatch.setattr(torch, "empty", real)
+    assert arena.capacity == cap and arena.P == P and arena["xyz"].data_ptr() == ptr
+    for k in t:
+        assert torch.equal(arena[k], before[k])
+    # ... and it still works: a growth that succeeds, then the rows are where they belong
+    n = arena.append({"xyz": torch.ones(5000, 3, device=DEV), "rot": None})
+    assert n == P + 5000 and torch.equal(arena["xyz"][:P], before["xyz"]) and float(arena["xyz"][P:].min()) == 1.0
+    assert float(arena["rot"][P:].abs().max()) == 0.0

@@ -9,6 +9,7 @@
 TAG=${1:-session}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+export GSR_REQUIRE_REF=1  # a missing oracle/_ref build FAILS the reference-backed tests instead of skipping them
 R=$GRAFT_REPO_ROOT
 O=gpurun_out
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -12 > $O/${TAG}_pytest.txt
