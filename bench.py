@@ -108,8 +108,10 @@ def csrc_sha16() -> str:
     return h.hexdigest()[:16]
 
 
-def workload_key(P, W, H, s0) -> str:
+def workload_key(P, W, H, s0, scene="v1") -> str:
     """Key of a workload in profiles/traffic_latest.json (tools/collect_counters.py writes the same)."""
+    if scene == "v2":
+        return f"synth-v2:{int(P)}:{int(W)}x{int(H)}"
     return f"synth-v1:{int(P)}:{int(W)}x{int(H)}:s0={float(s0):g}"
 
 
@@ -334,6 +336,74 @@ def extra_configs(dev, flags, budget_s=60.0):
             "roofline": roofline_block(st, ab, cb, dom, counters, src, dev, pix)}
         del params, sc
         torch.cuda.empty_cache()
+    # ---- synth-v2 at the headline's size: a scene that looks like a trained capture to the rasterizer --
+    # every tile non-empty, ~70 % of the visible Gaussians receive a gradient -- train iteration + forward, stage times, roofline
+    if time.perf_counter() - t_begin < budget_s + 30.0:
+        from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+        from gaussianeditor_amd.multiview import GradBucket, multiview_batch_step, multiview_step
+        from gaussianeditor_amd.synth import synth_scene_v2
+
+        P2, W, H = 1_000_000, 1920, 1080
+        sc = synth_scene_v2(P2, seed=0)
+        ring = ring_cameras(8, W, H)
+        params = {k: sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+
+        def rs_of(v):
+            c = ring[v % 8]
+            return GaussianRasterizationSettings(H, W, math.tan(c.FoVx / 2), math.tan(c.FoVy / 2), sc["bg"].to(dev), 1.0,
+                                                 c.world_view_transform.to(dev), c.full_proj_transform.to(dev), 3,
+                                                 c.camera_center.to(dev), False, False)
+
+        rs = rs_of(0)
+        G2 = seed_gradient(H, W, 0).to(dev)
+        bucket = GradBucket(P2, 16, dev, sh_exchange="auto")
+        t_train = timed(lambda: multiview_step(rs, params, G2, bucket, rows="auto"), 100, 30)
+        rast, m2d = GaussianRasterizer(rs), torch.zeros_like(params["xyz"])
+
+        def fwd():
+            with torch.no_grad():
+                rast(params["xyz"], m2d, params["opacity"], shs=params["features"], scales=params["scaling"], rotations=params["rotation"])
+
+        t_fwd = timed(fwd, 100, 10)
+        st, R, V, pix = stage_times(dev, params, rs, G2, 3, flags, 10)
+        N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), 16
+        ab, cb = algorithmic_bytes(P2, V, R, N, T, M), compulsory_bytes(P2, V, R, N, T, M)
+        dom = max(st, key=st.get)
+        counters, src = load_counters(workload_key(P2, W, H, 0.0, "v2"))
+        out["synth_v2_1M_1080p"] = {
+            "what": "synth-v2 (gaussianeditor_amd/synth.py: disks on a dome, a ground, three shells and a wall; bimodal opacity), "
+                    "1 M Gaussians, 1920x1080, ring view 0: one train iteration (forward + backward through the L1 API) and one "
+                    "forward, wall clock over 100 iterations each; stage times from HIP events around the C-ABI calls",
+            "train_ms_per_step": 1e3 * t_train, "train_iters_per_s": 1.0 / t_train, "forward_ms": 1e3 * t_fwd,
+            "forward_mpixels_per_s": N / t_fwd / 1e6, "stage_ms": st, "num_rendered": R, "visible": V,
+            "roofline": roofline_block(st, ab, cb, dom, counters, src, dev, pix)}
+        del bucket
+        # ---- the fixed 8-view batch of configs[3] on ONE GPU (multiview_batch_step: two-stream view pipelining, the blend kernels
+        # at 2 waves per SIMD by the library's own choice), headline scene; 3 repetitions each way -> median and range
+        sc1 = synth_scene(1_000_000, seed=0, s0=0.01)
+        p1 = {k: sc1[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+        rs8 = [GaussianRasterizationSettings(H, W, math.tan(c.FoVx / 2), math.tan(c.FoVy / 2), sc1["bg"].to(dev), 1.0,
+                                             c.world_view_transform.to(dev), c.full_proj_transform.to(dev), 3,
+                                             c.camera_center.to(dev), False, False) for c in ring]
+        import gaussianeditor_amd.multiview as mv
+
+        res = {}
+        for name, pipe_on in (("pipelined", True), ("serial", False)):
+            mv._VIEW_PIPELINE = pipe_on
+            b8 = GradBucket(1_000_000, 16, dev, sh_exchange="rgb")
+            runs = []
+            for _ in range(3):
+                t8 = timed(lambda: multiview_batch_step(rs8, p1, [G2] * 8, b8), 12, 4)
+                runs.append(8.0 / t8)
+            runs.sort()
+            res[name] = {"view_iters_per_s_median": runs[1], "min": runs[0], "max": runs[2], "ms_per_view": 1e3 / runs[1]}
+            del b8
+        mv._VIEW_PIPELINE = True
+        out["views8_one_gpu"] = dict(res, what="the 8 ring views of BASELINE configs[3] as ONE batch on one GPU (bench.py --views 8): "
+                                               "forward + backward of every view, touched-rows messages, one accumulate; three "
+                                               "repetitions of 12 steps each way")
+        del params, p1
+        torch.cuda.empty_cache()
     out["seconds"] = time.perf_counter() - t_begin
     return out
 
@@ -359,6 +429,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--s0", type=float, default=0.01, help="synth-v1 median scale (0.01 = headline; 0.03-0.05 = deep tiles)")
+    ap.add_argument("--scene", choices=("v1", "v2"), default="v1",
+                    help="v1 = synth-v1, the uniform cube of SURVEY.md section 8(d) (the headline); v2 = synth-v2, surfaces of "
+                         "disk-like Gaussians with bimodal opacity seen from inside (every tile non-empty, most visible "
+                         "Gaussians receive a gradient: gaussianeditor_amd/synth.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the `extra_configs` block (6 M forward, edit loop, tracing)")
     ap.add_argument("--train-only", action="store_true",
@@ -425,13 +499,10 @@ def main():
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
 
     # Several views per rank: multiview_batch_step pipelines successive views on two streams (view v + 1's forward under
-    # view v's backward); the persistent blend kernels then run 2 waves per SIMD instead of 4, which leaves register space
-    # for the other stream's kernels (tools/pipeline_probe.py: 0.61 -> 0.52 ms per view; both knobs are read once, at
-    # the library's / the module's first use, and neither changes a result).
+    # view v's backward) and tells the rasterizer itself to run the persistent blend kernels at 2 waves per SIMD for those
+    # views (GSR_FLAG_SHARED_SIMDS; until round 4 this file set GSR_BLEND_WAVES_PER_SIMD=2 for the process).
     if args.no_view_pipeline:
         os.environ["GSR_VIEW_PIPELINE"] = "0"
-    elif batch_mode and views // world > 1:
-        os.environ.setdefault("GSR_BLEND_WAVES_PER_SIMD", "2")
     import gaussianeditor_amd
     from gaussianeditor_amd import _native
 
@@ -443,7 +514,7 @@ def main():
     flags = options.current_flags()
     from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from gaussianeditor_amd.multiview import GradBucket, multiview_batch_step, multiview_step, views_of_rank
-    from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene
+    from gaussianeditor_amd.synth import ring_cameras, seed_gradient, synth_scene, synth_scene_v2
 
     P, W, H = args.gaussians, args.width, args.height
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
@@ -461,7 +532,7 @@ def main():
         P = int(sc["xyz"].shape[0])
         ply_degree = int(raw["max_sh_degree"])
     else:
-        sc = synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
+        sc = synth_scene_v2(P, seed=0) if args.scene == "v2" else synth_scene(P, seed=0, s0=args.s0, sh_degree=3)
         ply_degree = 3
     M = sc["features"].shape[1]
     ring = ring_cameras(8, W, H)
@@ -686,7 +757,8 @@ def main():
     rows_per_view = bucket.last_counts if route["last"] == "rows" else None
     extra = None
     # (only next to the headline workload: a bench line of another workload -- tests, --ply, deep tiles -- stays short)
-    is_headline = args.ply is None and (P, W, H) == (1_000_000, 1920, 1080) and args.s0 == 0.01 and not batch_mode
+    is_headline = (args.ply is None and args.scene == "v1" and (P, W, H) == (1_000_000, 1920, 1080) and args.s0 == 0.01
+                   and not batch_mode)
     if rank == 0 and world == 1 and is_headline and not (args.no_extra_configs or args.train_only or args.force_exchange):
         del bucket
         torch.cuda.empty_cache()
@@ -711,7 +783,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if args.ply is None else "file (scene) + synthetic cameras / pixel gradient",
-            "config": {"workload": (f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0}), {W}x{H}, ring-v1 8 views, "
+            "config": {"workload": ((f"synth-v1 {P} Gaussians SH3 (M=16, s0={args.s0})" if args.scene == "v1" else
+                                     f"synth-v2 {P} Gaussians SH3 (M=16): disks on surfaces, bimodal opacity, every tile non-empty")
+                                    + f", {W}x{H}, ring-v1 8 views, "
                                     + (f"a fixed batch of {views} views per step dealt to the ranks" if batch_mode else "one view per GPU")
                                     + " (BASELINE.json configs[3] shape; configs[1] bicycle.ply is not available offline)")
                        if args.ply is None else
@@ -721,7 +795,8 @@ def main():
                        "gaussians": P, "width": W, "height": H, "views_per_step": views, "views_per_rank": len(my_views),
                        "parallelism": f"dp{world}-views",
                        "view_pipeline": bool(batch_mode and len(my_views) > 1 and not args.no_view_pipeline),
-                       "blend_waves_per_simd": int(os.environ.get("GSR_BLEND_WAVES_PER_SIMD", "4")),
+                       "blend_waves_per_simd": (int(os.environ["GSR_BLEND_WAVES_PER_SIMD"]) if "GSR_BLEND_WAVES_PER_SIMD" in os.environ
+                                                else (2 if (batch_mode and len(my_views) > 1 and not args.no_view_pipeline) else 4)),
                        "tile_bounds": gaussianeditor_amd.get_tile_bounds(), "fast_exp": gaussianeditor_amd.get_fast_exp(),
                        "synth_s0": args.s0,
                        "grad_exchange": exchange + (" (forced on one rank: development run)" if args.force_exchange else ""),
@@ -737,7 +812,8 @@ def main():
         if not args.train_only:
             renders_per_s = world * args.steps / fwd_s
             dominant = max(stage_ms, key=stage_ms.get)
-            counters, src = load_counters(workload_key(P, W, H, args.s0)) if args.ply is None else (None, "not a synth-v1 workload")
+            counters, src = (load_counters(workload_key(P, W, H, args.s0, args.scene)) if args.ply is None
+                             else (None, "not a synthetic workload"))
             out.update({
                 "forward_ms_gpu": {"median": percentile(fwd_ms, 0.5), "p10": percentile(fwd_ms, 0.1), "p90": percentile(fwd_ms, 0.9)},
                 "forward_renders_per_s": renders_per_s,

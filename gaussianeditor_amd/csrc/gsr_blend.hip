@@ -1397,25 +1397,26 @@ static int cus_of_stream(hipStream_t s) {
 // Number of persistent waves of a launch: (SIMDs on the device) x (waves per SIMD), 4 by default.
 // GSR_BLEND_WAVES_PER_SIMD overrides the default for all blend kernels, GSR_FWD_WAVES_PER_SIMD for the forward / trace
 // kernels only (the backward is built for exactly 4: amdgpu_waves_per_eu) -- tuning knobs, read once.
-static int waves_per_simd(bool backward) {
-  static const int all = [] { const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD"); return e ? atoi(e) : 4; }();
+static int waves_per_simd(bool backward, bool shared_simds) {
+  static const int all = [] { const char* e = getenv("GSR_BLEND_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();
   static const int fwd = [] { const char* e = getenv("GSR_FWD_WAVES_PER_SIMD"); return e ? atoi(e) : 0; }();
-  const int v = (!backward && fwd > 0) ? fwd : all;
+  // (GSR_FLAG_SHARED_SIMDS: a second stream's kernels run alongside -- 2 waves per SIMD; the environment knobs win)
+  const int v = (!backward && fwd > 0) ? fwd : (all > 0 ? all : (shared_simds ? 2 : 4));
   return v < 1 ? 1 : (v > 8 ? 8 : v);
 }
-unsigned blend_grid_size(bool backward, hipStream_t s) {
+unsigned blend_grid_size(bool backward, hipStream_t s, bool shared_simds) {
   // (GSR_FWD_GRID: development knob, any number of persistent forward waves -- tools/microbench, profiles/r02_e)
   static const unsigned fwd_fixed = [] { const char* e = getenv("GSR_FWD_GRID"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 0u; }();
   if (!backward && fwd_fixed != 0u) return fwd_fixed;
-  return (unsigned)cus_of_stream(s) * 4u * (unsigned)waves_per_simd(backward);
+  return (unsigned)cus_of_stream(s) * 4u * (unsigned)waves_per_simd(backward, shared_simds);
 }
 // Placement units of a launch with `waves_per_wg`-wave workgroups (see first_item_of_block): SIMDs or CUs; 0 turns the
 // assigned first items off (GSR_BLEND_FOLD=0, or a CU count the fold does not divide).
-static unsigned blend_units(unsigned waves_per_wg, hipStream_t s) {
+static unsigned blend_units(unsigned waves_per_wg, hipStream_t s, bool shared_simds) {
   static const bool fold = [] { const char* e = getenv("GSR_BLEND_FOLD"); return !e || atoi(e) != 0; }();
   const unsigned cus = (unsigned)cus_of_stream(s);
   const unsigned units = waves_per_wg == 1 ? cus * 4u : cus;
-  const unsigned grid = blend_grid_size(waves_per_wg != 1, s) / waves_per_wg;
+  const unsigned grid = blend_grid_size(waves_per_wg != 1, s, shared_simds) / waves_per_wg;
   if (!fold || units % 8u != 0u || grid % units != 0u) return 0u;
   return units;
 }
@@ -1429,13 +1430,14 @@ static hipError_t prepare_queue(hipStream_t s, BlendArgs& a, unsigned grid) {
   return use_memset ? hipMemsetAsync(a.queue, 0, sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES, s) : hipSuccess;
 }
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s));
+  const bool sh = a.shared_simds != 0;
+  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s, sh));
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(1, s);
+  a.units = (int)blend_units(1, s, sh);
   static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
   a.allow_split = split_ok ? 1 : 0;
   // fewer than two quadrant items per persistent wave (bounded by the tile count of the image): cut the quadrants
-  const unsigned grid = blend_grid_size(false, s), quads = 4u * (unsigned)(a.gx * a.gy);
+  const unsigned grid = blend_grid_size(false, s, sh), quads = 4u * (unsigned)(a.gx * a.gy);
   const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
   const dim3 g(grid), b(WAVE);
 #define GSR_FWD_LAUNCH(AUXV, FASTV, CKV)                                                                        \
@@ -1459,9 +1461,10 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size(true, s) / BWD_WAVES);
+  const bool sh = a.shared_simds != 0;
+  hipError_t e = prepare_queue(s, a, blend_grid_size(true, s, sh) / BWD_WAVES);
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(BWD_WAVES, s);
+  a.units = (int)blend_units(BWD_WAVES, s, sh);
   // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   bool seg_items = false;  // the work list holds list-segment items (views whose forward left checkpoints)
@@ -1484,16 +1487,16 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     seg_items = a.ck_table != nullptr && a.ck_chunks > 0 && seg_share > 0 && ablate == 0;
     if (seg_items)
       hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES,
+                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES,
                          halves, clear, (const uint32_t*)a.tile_maxc, (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work,
                          (uint32_t)a.ck_chunks * WAVE, seg_share);
     else
       hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s) / BWD_WAVES,
+                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES,
                          halves, clear, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
   }
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
-  const dim3 g(blend_grid_size(true, s) / BWD_WAVES), b(WAVE * BWD_WAVES);
+  const dim3 g(blend_grid_size(true, s, sh) / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false, false>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false, false>), g, b, 0, s, a); break;
@@ -1512,10 +1515,11 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   return hipGetLastError();
 }
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a) {
-  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s));
+  const bool sh = a.shared_simds != 0;
+  hipError_t e = prepare_queue(s, a, blend_grid_size(false, s, sh));
   if (e != hipSuccess) return e;
-  a.units = (int)blend_units(1, s);
-  const unsigned grid = blend_grid_size(false, s), quads = 4u * (unsigned)(a.gx * a.gy);
+  a.units = (int)blend_units(1, s, sh);
+  const unsigned grid = blend_grid_size(false, s, sh), quads = 4u * (unsigned)(a.gx * a.gy);
   static const bool split_ok = [] { const char* e = getenv("GSR_FWD_SPLIT"); return !e || atoi(e) != 0; }();
   const int split = !split_ok || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);  // as the forward
   const dim3 g(grid), b(WAVE);

@@ -352,6 +352,7 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   a.out_color = out_color;
   a.out_depth = out_depth;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
+  a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }
@@ -375,6 +376,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
   a.work_maxc = nullptr;
   a.ck_table = nullptr;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
+  a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }
@@ -430,6 +432,7 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   a.dL_dopacity = dL_dopacity;
   a.dL_dcolors = dL_dcolors;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
+  a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   a.P = P;
   a.clear_grads = (flags & GSR_FLAG_CLEAR_GRADS) ? 1 : 0;
   GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
@@ -680,6 +683,7 @@ int gsr_trace_weights(void* stream, int P, int64_t R, int W, int H, int C, const
   a.weights = weights;
   a.cnt = cnt;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
+  a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   GSR_HIP(launch_trace_weights((hipStream_t)stream, a));
   return GSR_OK;
 }

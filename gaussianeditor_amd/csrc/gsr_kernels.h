@@ -93,6 +93,7 @@ struct BlendArgs {
   int P;           // number of Gaussians (rows of the backward's accumulators)
   int clear_grads; // GSR_FLAG_CLEAR_GRADS: the backward clears its four accumulators itself (launch_blend_backward)
   int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)
+  int shared_simds;  // GSR_FLAG_SHARED_SIMDS: 2 persistent waves per SIMD instead of 4 (another stream's kernels run alongside)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
@@ -154,7 +155,7 @@ hipError_t launch_adam_step(hipStream_t s, int nt, const gsr_adam_tensor* tensor
                             double beta2, double eps, const uint8_t* row_mask, const float* row_weight,
                             const uint8_t* grad_valid = nullptr);
 hipError_t launch_blend_forward(hipStream_t s, BlendArgs a);
-unsigned blend_grid_size(bool backward, hipStream_t s);  // persistent waves of a blend launch on the device of stream s
+unsigned blend_grid_size(bool backward, hipStream_t s, bool shared_simds = false);  // persistent waves of a blend launch on the device of stream s
 hipError_t launch_blend_backward(hipStream_t s, BlendArgs a);
 hipError_t launch_trace_weights(hipStream_t s, BlendArgs a);
 

@@ -37,6 +37,9 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.distributed as dist
 
+import contextlib
+
+from . import options as _options
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _C
 
 __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview_step", "multiview_batch_step", "views_of_rank",
@@ -609,41 +612,46 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
     # (tools/pipeline_probe.py, profiles/r04_c_pipelining.md): 0.61 -> 0.52 ms per view with the blend kernels at 2 waves
     # per SIMD, 1.13 -> 0.96 ms on deep tiles.  GSR_VIEW_PIPELINE=0 turns it off.
     pipeline = speculate and on_gpu and k_local > 1 and _VIEW_PIPELINE
+    # ... and the library, not its caller, says so to the rasterizer: the renders of a pipelined batch carry
+    # GSR_FLAG_SHARED_SIMDS (2 persistent blend waves per SIMD; until round 4 bench.py set GSR_BLEND_WAVES_PER_SIMD=2 for the
+    # whole process, so any other caller of this function ran the pipeline at 4)
+    shared = _options.override(_options.current_flags() | _options.FLAG_SHARED_SIMDS) if pipeline else contextlib.nullcontext()
     try:
         if pipeline:
-            main = torch.cuda.current_stream(dev)
-            if bucket._view_streams is None:
-                bucket._view_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-            S = bucket._view_streams
-            for st_ in S:
-                st_.wait_stream(main)
-            args = (params["xyz"], params["opacity"], params["features"], params["scaling"], params["rotation"])
-            with torch.cuda.stream(S[0]):
-                fstate = _view_forward(settings_list[0], *args)
-            packed_prev, all_radii = None, []
-            for v in range(k_local):
-                with torch.cuda.stream(S[v % 2]):
-                    if packed_prev is not None:
-                        S[v % 2].wait_event(packed_prev)  # the bucket is free: view v - 1's message holds its rows
-                    _view_backward(settings_list[v], fstate, dL_dcolor_list[v], bucket)
-                    colors.append(fstate[0].detach())
-                    depths.append(fstate[2].detach())
-                    all_radii.append(fstate[1])
-                    if state["planned"] is not None:
-                        S[v % 2].wait_event(state["planned"])
-                    _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, cap, send[v])
-                    packed_prev = torch.cuda.Event()
-                    packed_prev.record(S[v % 2])
-                if v + 1 < k_local:
-                    with torch.cuda.stream(S[(v + 1) % 2]):
-                        fstate = _view_forward(settings_list[v + 1], *args)  # underneath view v's backward
-            for st_ in S:
-                main.wait_stream(st_)
-            radii_max = all_radii[0].clone()
-            for r in all_radii[1:]:
-                torch.maximum(radii_max, r, out=radii_max)
-            for t in colors + depths + all_radii:
-                t.record_stream(main)
+            with shared:
+                main = torch.cuda.current_stream(dev)
+                if bucket._view_streams is None:
+                    bucket._view_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+                S = bucket._view_streams
+                for st_ in S:
+                    st_.wait_stream(main)
+                args = (params["xyz"], params["opacity"], params["features"], params["scaling"], params["rotation"])
+                with torch.cuda.stream(S[0]):
+                    fstate = _view_forward(settings_list[0], *args)
+                packed_prev, all_radii = None, []
+                for v in range(k_local):
+                    with torch.cuda.stream(S[v % 2]):
+                        if packed_prev is not None:
+                            S[v % 2].wait_event(packed_prev)  # the bucket is free: view v - 1's message holds its rows
+                        _view_backward(settings_list[v], fstate, dL_dcolor_list[v], bucket)
+                        colors.append(fstate[0].detach())
+                        depths.append(fstate[2].detach())
+                        all_radii.append(fstate[1])
+                        if state["planned"] is not None:
+                            S[v % 2].wait_event(state["planned"])
+                        _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, cap, send[v])
+                        packed_prev = torch.cuda.Event()
+                        packed_prev.record(S[v % 2])
+                    if v + 1 < k_local:
+                        with torch.cuda.stream(S[(v + 1) % 2]):
+                            fstate = _view_forward(settings_list[v + 1], *args)  # underneath view v's backward
+                for st_ in S:
+                    main.wait_stream(st_)
+                radii_max = all_radii[0].clone()
+                for r in all_radii[1:]:
+                    torch.maximum(radii_max, r, out=radii_max)
+                for t in colors + depths + all_radii:
+                    t.record_stream(main)
         for v in range(0 if not pipeline else k_local, k_local):
             color, radii, depth, _ = render_view_grads(settings_list[v], params["xyz"], params["opacity"], params["features"],
                                                        params["scaling"], params["rotation"], dL_dcolor_list[v], bucket)

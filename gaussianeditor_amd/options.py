@@ -16,6 +16,7 @@ FLAG_FAST_EXP = 2
 FLAG_ALL = 3             # the behaviour switches a caller may set
 FLAG_CLEAR_GRADS = 4     # (internal to the binding: the backward clears its accumulators itself; include/gsr.h)
 FLAG_FORWARD_ONLY = 8    # (internal to the binding: a render none of whose inputs requires a gradient)
+FLAG_SHARED_SIMDS = 16   # (set by multiview_batch_step for a rank's pipelined views: 2 persistent blend waves per SIMD)
 
 _default = 0
 _local = threading.local()
@@ -41,8 +42,9 @@ def set_default_flags(flags: int) -> None:
 
 @contextlib.contextmanager
 def override(flags: int):
-    """Run the renders started inside the block, by this thread, with `flags`."""
-    if flags & ~FLAG_ALL:
+    """Run the renders started inside the block, by this thread, with `flags` (behaviour switches, and the scheduling hint
+    FLAG_SHARED_SIMDS)."""
+    if flags & ~(FLAG_ALL | FLAG_SHARED_SIMDS):
         raise ValueError(f"unknown flag bits in {flags:#x}")
     prev = getattr(_local, "flags", None)
     _local.flags = int(flags)

@@ -114,12 +114,18 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *                        bar, but a pixel whose alpha or transmittance sits within a rounding of a threshold
  *                        (1/255, 1e-4) may take the other branch than the CPU oracle, so n_contrib / final_T are no
  *                        longer bit-identical to it (they are not bit-identical to the reference's libm build either).
+ *   GSR_FLAG_SHARED_SIMDS (ABI 4; read by the blend / trace entry points) the caller overlaps this view's kernels with
+ *                        another view's on a second stream: the persistent blend kernels are launched with 2 waves per
+ *                        SIMD instead of 4, which leaves wave slots and registers for the other stream's kernels (a rank
+ *                        that renders several views of a batch: -15 % per view, profiles/r04_c_pipelining.md).  Never
+ *                        changes a result.  The environment knob GSR_BLEND_WAVES_PER_SIMD, where set, takes precedence.
  * Unknown bits are rejected with GSR_ERR_BAD_ARGUMENT. */
 #define GSR_FLAG_TILE_BOUNDS_ALPHA 1u
 #define GSR_FLAG_FAST_EXP 2u
 #define GSR_FLAG_CLEAR_GRADS 4u
 #define GSR_FLAG_FORWARD_ONLY 8u
-#define GSR_FLAG_ALL 15u
+#define GSR_FLAG_SHARED_SIMDS 16u
+#define GSR_FLAG_ALL 31u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);

@@ -592,3 +592,42 @@ def test_batch_of_eight_views_on_1_2_4_ranks_is_bit_identical_to_the_single_proc
     assert np.array_equal(out[1]["flat"], tot)
     assert np.array_equal(out[1]["sh"], sh.reshape(out[1]["sh"].shape))
     assert np.array_equal(out[1]["radii"], rad)
+
+
+def test_eight_rank_weak_step_matches_the_single_process_sums(oracle, tmp_path):
+    """The weak-scaling path of BASELINE configs[3] at its real rank count (the driver's 8-GPU run is the first time hardware
+    sees world_size 8): `multiview_step` with one view per rank on EIGHT gloo ranks -- the whole step as bench.py runs it,
+    route chosen from the gathered counts -- leaves every replica with the same bits, equal to a single process that renders
+    the eight views one after the other and sums."""
+    world, P8, s0 = 8, 1203, 0.01  # (P % 4 != 0: segment padding; small splats: the touched-rows route)
+    mp.spawn(_worker_rgb, args=(world, _free_port(), str(tmp_path), "auto", s0, P8), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"rgb_rank{r}.npz") for r in range(world)]
+    for r in rs[1:]:
+        for k in ("flat", "sh", "radii"):
+            assert np.array_equal(rs[0][k], r[k]), k
+    tot, sh, rad = None, None, None
+    for v in range(world):
+        case = make_case(P8, W, H, seed=5, s0=s0, view=v, nviews=world)
+        f = oracle_forward(oracle, case)
+        g = oracle_backward(oracle, case, f, seed_gradient(H, W, 100 + v) * H * W)
+        flat = np.concatenate([g[k].reshape(-1) for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dmeans2D", "dL_dopacity")])
+        tot = flat if tot is None else tot + flat
+        sh = g["dL_dsh"] if sh is None else sh + g["dL_dsh"]
+        rad = f["radii"] if rad is None else np.maximum(rad, f["radii"])
+    assert all(bool(r["rows_route"][0]) == bool(rs[0]["rows_route"][0]) for r in rs)
+    assert rel_err(rs[0]["flat"], tot) < 1e-6 and np.array_equal(rs[0]["radii"], rad)
+    if bool(rs[0]["rows_route"][0]):  # rows added view after view to zeros: the single process's sums, bit for bit
+        assert np.array_equal(rs[0]["flat"], tot)
+    assert np.array_equal(rs[0]["sh"], sh.reshape(rs[0]["sh"].shape))
+
+
+def test_densify_synchronized_on_eight_ranks(tmp_path):
+    """`densify_synchronized` at world_size 8: eight differently seeded replicas split identically, their own random streams
+    continue undisturbed, and a diverged replica is refused on every rank."""
+    world = 8
+    mp.spawn(_worker_densify, args=(world, _free_port(), str(tmp_path), True), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"dz_1_{r}.npz") for r in range(world)]
+    assert all(r["same"][0] and r["rng_kept"][0] for r in rs)
+    assert all(np.array_equal(rs[0]["xyz"], r["xyz"]) for r in rs[1:]) and rs[0]["xyz"].shape[0] > 200
+    assert len({float(r["before"][0]) for r in rs}) == world  # eight different generators went in
+    assert all(np.load(tmp_path / f"dzr_{r}.npz")["raised"][0] for r in range(world))

@@ -147,8 +147,15 @@ def test_three_way_parity_forward_and_backward(oracle, P, W, H, s0, seed, D):
     Follows backward.cu:399-557 (render) and :144-396 (preprocess)."""
     big = P >= 1_000_000
     case = make_case(P, W, H, seed=seed, s0=s0, view=0, nviews=8 if big else 4, bg=(0.0, 0.0, 0.0) if big else (0.1, 0.2, 0.3))
-    sc, cam = case["sc"], case["cam"]
     G = seed_gradient(H, W, seed) * (1.0 if big else H * W)
+    three_way(oracle, case, G, D)
+
+
+def three_way(oracle, case, G, D):
+    """The body of the three-way test for any case dictionary (tests/helpers.py: make_case) -- also run on the synth-v2
+    scenes by tests/test_gpu_round5.py."""
+    sc, cam = case["sc"], case["cam"]
+    P, W, H = sc["xyz"].shape[0], case["W"], case["H"]
     N = W * H
     # --- the reference itself
     R_ = _ref("nofma")

@@ -178,3 +178,63 @@ def test_row_arena_survives_a_failed_growth(monkeypatch):
     n = arena.append({"xyz": torch.ones(5000, 3, device=DEV), "rot": None})
     assert n == P + 5000 and torch.equal(arena["xyz"][:P], before["xyz"]) and float(arena["xyz"][P:].min()) == 1.0
     assert float(arena["rot"][P:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("P", [200_000, 1_000_000])
+def test_three_way_parity_on_synth_v2(oracle, P):
+    """synth-v2 (gaussianeditor_amd/synth.py: disks on surfaces, bimodal opacity, the camera inside the scene -- every one of
+    the 8 160 tiles non-empty, most visible Gaussians receive a gradient; bench.py --scene v2) through the three-way test of
+    round 2: reference(no contraction) / oracle / product, integers bit-exact, images and all six gradients within 1e-5."""
+    import math
+
+    from gaussianeditor_amd.synth import ring_cameras, synth_scene_v2
+    from test_gpu_round2 import three_way
+
+    W, H = 1920, 1080
+    sc = synth_scene_v2(P, seed=0)
+    cam = ring_cameras(8, W, H)[0]
+    case = dict(sc=sc, cam=cam, W=W, H=H, tfx=math.tan(cam.FoVx / 2), tfy=math.tan(cam.FoVy / 2), bg=torch.zeros(3), D=3)
+    f = oracle_forward(oracle, case)
+    rl = f["ranges"].reshape(-1, 2)
+    vis = f["radii"] > 0
+    print(f"synth-v2 P={P}: visible {int(vis.sum())}, R = {f['num_rendered']}, empty tiles {int((rl[:, 1] == rl[:, 0]).sum())}")
+    assert (rl[:, 1] > rl[:, 0]).all() and vis.mean() > 0.6  # what the workload is for
+    three_way(oracle, case, seed_gradient(H, W, 0), 3)
+
+
+@pytest.mark.parametrize("extra,views", [([], 8), (["--views", "16"], 16)])
+def test_bench_eight_ranks_share_one_gpu(extra, views):
+    """`bench.py --gpus 8` exactly as the driver's scaling run launches it (torch.distributed.run, one process per rank), on a
+    box with ONE GPU: GSR_BENCH_SHARED_GPU=1 puts all eight ranks on GPU 0 over gloo, so the first real 8-GPU run cannot die
+    on a rank-count assumption -- views sharded over eight ranks (weak: one each; strong: the fixed batch of 16, two per rank,
+    pipelined), eight-way touched-rows exchange, max-over-ranks timing, ONE line from rank 0 with the `multi_gpu` block of
+    eight entries.  (The numbers of such a run mean nothing.)"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GSR_BENCH_SHARED_GPU"] = "1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "8", "--gaussians",
+                        "40000", "--width", "640", "--height", "368", "--steps", "3", "--warmup", "1", "--prewarm", "2",
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=1200, cwd=root, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["steps"] == 3 and line["value"] > 0
+    assert line["scaling"] == ("strong" if extra else "weak")
+    cfg, mg = line["config"], line["multi_gpu"]
+    assert cfg["views_per_step"] == views and cfg["views_per_rank"] == views // 8 and cfg["parallelism"] == "dp8-views"
+    assert mg["world_size"] == 8 and mg["shared_gpu_test_run"] and len(mg["per_rank"]["step_ms_gpu"]) == 8
+    assert cfg["grad_exchange_route"] in ("rows", "dense")
+    if cfg["grad_exchange_route"] == "rows":
+        assert len(cfg["grad_exchange_rows_per_view"]) == views and all(0 < c <= 40000 for c in cfg["grad_exchange_rows_per_view"])
+        assert all(b > 0 for b in mg["per_rank"]["bytes_sent_per_step"])

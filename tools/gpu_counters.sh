@@ -1,6 +1,6 @@
 #!/bin/bash
-# PMC passes for the bench line's `roofline.traffic` / `frac_counter` / `valu_issue_frac` on the three bench workloads
-# (headline, deep tiles, 6 M Gaussians): rocprofv3 --kernel-trace --pmc <group> over `bench.py --train-only`, one group per
+# PMC passes for the bench line's `roofline.traffic` / `frac_counter` / `valu_issue_frac` on the four bench workloads
+# (headline, deep tiles, 6 M Gaussians, synth-v2): rocprofv3 --kernel-trace --pmc <group> over `bench.py --train-only`, one group per
 # pass (FETCH_SIZE and WRITE_SIZE never together, never with another trace domain), then tools/collect_counters.py.
 #   gpurun --timeout 1500 -- 'bash tools/gpu_counters.sh r04_x'
 TAG=${1:-counters}
@@ -29,5 +29,6 @@ run() { # key, bench args...
 run "synth-v1:1000000:1920x1080:s0=0.01"
 run "synth-v1:1000000:1920x1080:s0=0.05" --s0 0.05
 run "synth-v1:6000000:1920x1080:s0=0.01" --gaussians 6000000
+run "synth-v2:1000000:1920x1080" --scene v2
 cp profiles/traffic_latest.json $O/${TAG}_traffic_latest.json
 cat $MD | head -60
