@@ -991,8 +991,12 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
   return seg_hi - seg_lo;
 }
 
+#ifndef GSR_BWD_WAVES_PER_EU
+#define GSR_BWD_WAVES_PER_EU 4  // (A/B builds: 5 with GSR_BLEND_WAVES_PER_SIMD=5)
+#endif
 template <int ABLATE, bool FAST, bool SEG>
-__global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) blend_backward_kernel(const BlendArgs a) {
+__global__ void __launch_bounds__(WAVE* BWD_WAVES) __attribute__((amdgpu_waves_per_eu(GSR_BWD_WAVES_PER_EU, GSR_BWD_WAVES_PER_EU)))
+blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[2][WAVE];  // (sid, sco, sacc: double-buffered by chunk parity, see backward_tile)
   __shared__ float4 sco[2][WAVE];

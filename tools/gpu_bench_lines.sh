@@ -12,6 +12,8 @@ timeout 300 python bench.py --views 8 --steps 50 --warmup 10 --no-cpu-baseline -
 GSR_TILE_BOUNDS=alpha timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_alpha_bounds.json 2>> $O/${TAG}_bench.err
 GSR_FAST_EXP=1 timeout 300 python bench.py --steps 100 --no-cpu-baseline --no-extra-configs > $O/${TAG}_bench_fast_exp.json 2>> $O/${TAG}_bench.err
 timeout 300 python bench.py --steps 100 --force-exchange --no-cpu-baseline > $O/${TAG}_bench_forced_exchange.json 2>> $O/${TAG}_bench.err
+timeout 300 python bench.py --scene v2 --steps 100 --no-cpu-baseline > $O/${TAG}_bench_v2.json 2>> $O/${TAG}_bench.err
+timeout 300 python bench.py --scene v2 --gaussians 6000000 --steps 30 --no-cpu-baseline > $O/${TAG}_bench_v2_6m.json 2>> $O/${TAG}_bench.err
 grep -v amdgpu.ids $O/${TAG}_bench.err | tail -5
 python - <<PY
 import json, glob
