@@ -1236,33 +1236,30 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   // them in registers, larger ones re-read) and the counters are scanned by one block scan.
   constexpr int EST_REG = 8;
   const bool in_regs = T <= 1024 * EST_REG;
-  uint4 er[EST_REG];
+  uint2 er[EST_REG];  // the forward's counts of the upper / lower pair of quadrants.  (Register budget: 64 VGPRs, so that TWO
+                      // 1024-thread blocks fit a CU -- the clearing blocks of this launch are bandwidth work, two per CU.  With
+                      // the four counts, the four walk depths and the list start of every tile held across the passes the
+                      // kernel needed 98 and the clearing blocks ran one after the other: work list + clear 14 -> 16 us.  The
+                      // descriptors' other two words are therefore fetched in the LAST pass, four tiles at a time.)
   uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
-  // what an item's descriptor holds besides its code: the first position of the tile's list and how deep the pixels of
-  // the upper / lower pair of quadrants reach into it (the forward's work_maxc)
-  uint32_t first[EST_REG], reach01[EST_REG], reach23[EST_REG];
   const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && stride != 0u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
     const int t = (int)threadIdx.x + 1024 * j;
-    const int tc = t < T ? t : T - 1;
-    er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[tc] : make_uint4(0u, 0u, 0u, 0u);
-    const uint4 mc = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(maxc)[tc] : make_uint4(0u, 0u, 0u, 0u);
-    first[j] = (in_regs && T > 0) ? ranges[tc].x : 0u;
-    reach01[j] = max(mc.x, mc.y);
-    reach23[j] = max(mc.z, mc.w);
+    const int tc = t < T ? t : max(T - 1, 0);
+    const uint4 e4 = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[tc] : make_uint4(0u, 0u, 0u, 0u);
+    er[j] = make_uint2(e4.x + e4.y, e4.z + e4.w);
     deep[j] = (in_regs && segments && T > 0) ? tile_maxc[tc] : 0u;
     if (t >= T) {
-      er[j] = make_uint4(0u, 0u, 0u, 0u);
+      er[j] = make_uint2(0u, 0u);
       deep[j] = 0u;
     }
   }
-  auto est_of = [&](int t, int j) -> uint4 { return in_regs ? er[j] : reinterpret_cast<const uint4*>(est)[t]; };
   // total work -> the weight above which a tile is cut
   uint32_t mine = 0;
   if (in_regs) {
 #pragma unroll
-    for (int j = 0; j < EST_REG; ++j) mine += er[j].x + er[j].y + er[j].z + er[j].w;
+    for (int j = 0; j < EST_REG; ++j) mine += er[j].x + er[j].y;
   } else {
     for (int t = threadIdx.x; t < T; t += 1024) {
       const uint4 e = reinterpret_cast<const uint4*>(est)[t];
@@ -1297,7 +1294,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   uint32_t nseg[EST_REG];
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j)
-    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y + er[j].z + er[j].w, deep[j]) : 1u;
+    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y, deep[j]) : 1u;
   auto bucket_of = [](uint32_t w) -> uint32_t {
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
@@ -1307,16 +1304,16 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
 #pragma unroll
       for (int j = 0; j < EST_REG; ++j) {
         const int t = (int)threadIdx.x + 1024 * j;
-        if (t < T) fn(t, er[j], nseg[j], j);
+        if (t < T) fn(t, er[j], nseg[j]);
       }
     } else {
       for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint4 e = reinterpret_cast<const uint4*>(est)[t];
-        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u, -1);
+        const uint4 e4 = reinterpret_cast<const uint4*>(est)[t];
+        const uint2 e = make_uint2(e4.x + e4.y, e4.z + e4.w);
+        fn(t, e, segments ? segments_of(t, e.x + e.y, tile_maxc[t]) : 1u);
       }
     }
   };
-  (void)est_of;
   // work of segment j of a cut tile: what the forward evaluated between checkpoints j and j + 1 (the front segment holds
   // most of it: the deep positions of a list are walked for a few stragglers)
   auto seg_work = [&](int t, uint32_t w, uint32_t ns, uint32_t j) -> uint32_t {
@@ -1324,13 +1321,13 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     const uint32_t lo = j == 0u ? 0u : min(row[j], w), hi = j + 1u == ns ? w : min(row[j + 1u], w);
     return max(hi > lo ? hi - lo : 0u, 1u);
   };
-  for_each_tile([&](int t, const uint4 e, uint32_t ns, int) {
-    const uint32_t w = e.x + e.y + e.z + e.w;
+  for_each_tile([&](int t, const uint2 e, uint32_t ns) {
+    const uint32_t w = e.x + e.y;
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u);
     } else if (w >= threshold) {
-      atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
-      atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u);
+      atomicAdd(&cnt[bucket_of(e.x) * BWD_SUB + sub], 1u);
+      atomicAdd(&cnt[bucket_of(e.y) * BWD_SUB + sub], 1u);
     } else {
       atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u);
     }
@@ -1355,31 +1352,45 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  for_each_tile([&](int t, const uint4 e, uint32_t ns, int j_reg) {
-    const uint32_t w = e.x + e.y + e.z + e.w;
-    uint32_t f, r01, r23;
-    if (j_reg >= 0) {
-      f = first[j_reg];
-      r01 = reach01[j_reg];
-      r23 = reach23[j_reg];
-    } else {
-      const uint4 mc = reinterpret_cast<const uint4*>(maxc)[t];
-      f = ranges[t].x;
-      r01 = max(mc.x, mc.y);
-      r23 = max(mc.z, mc.w);
-    }
+  // last pass: the descriptors.  x = item code, y = first position of the tile's list (ranges[t].x), z = how deep the item's
+  // pixels reach into it (the forward's work_maxc: the upper / lower pair of quadrants for a half item, else all four)
+  auto put = [&](int t, const uint2 e, uint32_t ns, uint32_t f, const uint4 mc) {
+    const uint32_t w = e.x + e.y, r01 = max(mc.x, mc.y), r23 = max(mc.z, mc.w);
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j)
         items[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
             make_uint4((uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT), f, max(r01, r23), 0u);
     } else if (w >= threshold) {
-      items[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF, f, r01, 0u);
-      items[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] =
-          make_uint4((uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART, f, r23, 0u);
+      items[atomicAdd(&cnt[bucket_of(e.x) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF, f, r01, 0u);
+      items[atomicAdd(&cnt[bucket_of(e.y) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART, f, r23, 0u);
     } else {
       items[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t, f, max(r01, r23), 0u);
     }
-  });
+  };
+  if (in_regs) {
+#pragma unroll
+    for (int j0 = 0; j0 < EST_REG; j0 += 4) {
+      uint32_t f[4];
+      uint4 mc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // (unconditional, clamped: the four tiles' loads travel together)
+        const int t = (int)threadIdx.x + 1024 * (j0 + u), tc = t < T ? t : max(T - 1, 0);
+        f[u] = ranges[tc].x;
+        mc[u] = reinterpret_cast<const uint4*>(maxc)[tc];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = (int)threadIdx.x + 1024 * (j0 + u);
+        if (t < T) put(t, er[j0 + u], nseg[j0 + u], f[u], mc[u]);
+      }
+    }
+  } else {
+    for (int t = threadIdx.x; t < T; t += 1024) {
+      const uint4 e4 = reinterpret_cast<const uint4*>(est)[t];
+      const uint2 e = make_uint2(e4.x + e4.y, e4.z + e4.w);
+      put(t, e, segments ? segments_of(t, e.x + e.y, tile_maxc[t]) : 1u, ranges[t].x, reinterpret_cast<const uint4*>(maxc)[t]);
+    }
+  }
 }
 
 // Compute units of the device a launch goes to: the device of the STREAM (a C-ABI caller may hand over a stream of another
