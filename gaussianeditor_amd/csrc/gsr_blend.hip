@@ -731,12 +731,12 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
                                               const float bg2, float4 (*s0)[WAVE], float4 (*s1)[WAVE], float4 (*s2)[WAVE],
                                               uint32_t (*sid)[WAVE], float4 (*sco)[WAVE], float (*sacc)[9][WAVE]) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
-  // The item's descriptor (backward_worklist_kernel): x = code -- a whole tile, wave w = quadrant w; or half a tile, waves
-  // (0,1) and (2,3) = the upper / lower 8x4 pixels of its two quadrants; or one list segment --, y = first position of the
-  // tile's list, z = how deep the item's pixels reach into it (the forward's work_maxc).  Until round 4 the item held the
-  // code only and its start was a chain of dependent round trips: work list -> ranges, final_T, n_contrib -> maximum over
-  // the workgroup (two barriers) -> dL_dpixel, bg -> ids -> records.  Now everything per pixel and the first ids are
-  // requested together, right behind the descriptor.
+  // The item's descriptor (assembled by the caller from three scalar loads): x = code -- a whole tile, wave w = quadrant w; or
+  // half a tile, waves (0,1) and (2,3) = the upper / lower 8x4 pixels of its two quadrants; or one list segment --, y = first
+  // position of the tile's list, z = how deep the item's pixels reach into it (the forward's work_maxc).  Until round 4 an
+  // item's start was a chain of dependent round trips: work list -> ranges, final_T, n_contrib -> maximum over the
+  // workgroup (two barriers) -> dL_dpixel, bg -> ids -> records.  Now everything per pixel and the first ids are requested
+  // together, right behind the descriptor.
   uint32_t tile = item.x;
   const bool half_item = (tile & BWD_ITEM_HALF) != 0u;
   const uint32_t part = (tile & BWD_ITEM_PART) ? 1u : 0u;
@@ -1019,9 +1019,18 @@ blend_backward_kernel(const BlendArgs a) {
   if (prof) t_begin = __builtin_amdgcn_s_memtime();
   auto run_tile = [&](uint32_t index) {
     if (prof) t_tile = __builtin_amdgcn_s_memtime();
-    // the descriptor: one scalar load (the work list is an earlier kernel's; the scalar path does not queue behind the
-    // previous item's last atomics)
-    const uint4 item = scalar_load(a.bwd_items, index);
+    // The item's descriptor -- code, first position of the tile's list, how deep the item's pixels reach into it -- from three
+    // SCALAR loads (tables of earlier kernels: the work list, the ranges, the walk depths the forward left per quadrant; the
+    // scalar path does not queue behind the previous item's last atomics): code first, the other two together.  (Round 5's
+    // first form had backward_worklist_kernel write whole descriptors: that one-block kernel is a chain of dependent round
+    // trips between the forward and the backward -- 14 -> 16-18 us for what costs this kernel, whose waves wait behind three
+    // others, nothing measurable.)
+    const uint32_t code = scalar_load(a.bwd_order, index);
+    const uint32_t ctile = code & BWD_ITEM_TILE;
+    const uint2 crange = scalar_load(a.ranges, ctile);
+    const uint4 cmax = scalar_load(reinterpret_cast<const uint4*>(a.work_maxc), ctile);
+    const uint32_t r01 = max(cmax.x, cmax.y), r23 = max(cmax.z, cmax.w);
+    const uint4 item = make_uint4(code, crange.x, (code & BWD_ITEM_HALF) ? ((code & BWD_ITEM_PART) ? r23 : r01) : max(r01, r23), 0u);
     const uint32_t tile = item.x;
     const uint32_t tmax = backward_tile<ABLATE, FAST, SEG>(a, item, bg0, bg1, bg2, s0, s1, s2, sid, sco, sacc);
     if (prof) {
@@ -1189,8 +1198,7 @@ struct ClearArgs {
 };
 template <bool SEG>
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
-                                                                const uint32_t* __restrict__ maxc, const uint2* __restrict__ ranges,
-                                                                uint4* __restrict__ items, uint32_t* __restrict__ meta,
+                                                                uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
                                                                 uint32_t workgroups, int allow_halves,  // allow_halves: 0, or the threshold in 1/8 of a fair share
                                                                 const ClearArgs clear, const uint32_t* __restrict__ tile_maxc,
                                                                 const uint32_t* __restrict__ ck_table,
@@ -1236,30 +1244,25 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   // them in registers, larger ones re-read) and the counters are scanned by one block scan.
   constexpr int EST_REG = 8;
   const bool in_regs = T <= 1024 * EST_REG;
-  uint2 er[EST_REG];  // the forward's counts of the upper / lower pair of quadrants.  (Register budget: 64 VGPRs, so that TWO
-                      // 1024-thread blocks fit a CU -- the clearing blocks of this launch are bandwidth work, two per CU.  With
-                      // the four counts, the four walk depths and the list start of every tile held across the passes the
-                      // kernel needed 98 and the clearing blocks ran one after the other: work list + clear 14 -> 16 us.  The
-                      // descriptors' other two words are therefore fetched in the LAST pass, four tiles at a time.)
+  uint4 er[EST_REG];
   uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
   const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && stride != 0u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
     const int t = (int)threadIdx.x + 1024 * j;
-    const int tc = t < T ? t : max(T - 1, 0);
-    const uint4 e4 = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[tc] : make_uint4(0u, 0u, 0u, 0u);
-    er[j] = make_uint2(e4.x + e4.y, e4.z + e4.w);
-    deep[j] = (in_regs && segments && T > 0) ? tile_maxc[tc] : 0u;
+    er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[t < T ? t : T - 1] : make_uint4(0u, 0u, 0u, 0u);
+    deep[j] = (in_regs && segments && T > 0) ? tile_maxc[t < T ? t : T - 1] : 0u;
     if (t >= T) {
-      er[j] = make_uint2(0u, 0u);
+      er[j] = make_uint4(0u, 0u, 0u, 0u);
       deep[j] = 0u;
     }
   }
+  auto est_of = [&](int t, int j) -> uint4 { return in_regs ? er[j] : reinterpret_cast<const uint4*>(est)[t]; };
   // total work -> the weight above which a tile is cut
   uint32_t mine = 0;
   if (in_regs) {
 #pragma unroll
-    for (int j = 0; j < EST_REG; ++j) mine += er[j].x + er[j].y;
+    for (int j = 0; j < EST_REG; ++j) mine += er[j].x + er[j].y + er[j].z + er[j].w;
   } else {
     for (int t = threadIdx.x; t < T; t += 1024) {
       const uint4 e = reinterpret_cast<const uint4*>(est)[t];
@@ -1294,7 +1297,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   uint32_t nseg[EST_REG];
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j)
-    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y, deep[j]) : 1u;
+    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y + er[j].z + er[j].w, deep[j]) : 1u;
   auto bucket_of = [](uint32_t w) -> uint32_t {
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
@@ -1308,12 +1311,12 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
       }
     } else {
       for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint4 e4 = reinterpret_cast<const uint4*>(est)[t];
-        const uint2 e = make_uint2(e4.x + e4.y, e4.z + e4.w);
-        fn(t, e, segments ? segments_of(t, e.x + e.y, tile_maxc[t]) : 1u);
+        const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u);
       }
     }
   };
+  (void)est_of;
   // work of segment j of a cut tile: what the forward evaluated between checkpoints j and j + 1 (the front segment holds
   // most of it: the deep positions of a list are walked for a few stragglers)
   auto seg_work = [&](int t, uint32_t w, uint32_t ns, uint32_t j) -> uint32_t {
@@ -1321,13 +1324,13 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     const uint32_t lo = j == 0u ? 0u : min(row[j], w), hi = j + 1u == ns ? w : min(row[j + 1u], w);
     return max(hi > lo ? hi - lo : 0u, 1u);
   };
-  for_each_tile([&](int t, const uint2 e, uint32_t ns) {
-    const uint32_t w = e.x + e.y;
+  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+    const uint32_t w = e.x + e.y + e.z + e.w;
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u);
     } else if (w >= threshold) {
-      atomicAdd(&cnt[bucket_of(e.x) * BWD_SUB + sub], 1u);
-      atomicAdd(&cnt[bucket_of(e.y) * BWD_SUB + sub], 1u);
+      atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
+      atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u);
     } else {
       atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u);
     }
@@ -1352,45 +1355,19 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  // last pass: the descriptors.  x = item code, y = first position of the tile's list (ranges[t].x), z = how deep the item's
-  // pixels reach into it (the forward's work_maxc: the upper / lower pair of quadrants for a half item, else all four)
-  auto put = [&](int t, const uint2 e, uint32_t ns, uint32_t f, const uint4 mc) {
-    const uint32_t w = e.x + e.y, r01 = max(mc.x, mc.y), r23 = max(mc.z, mc.w);
+  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+    const uint32_t w = e.x + e.y + e.z + e.w;
     if (ns > 1u) {
       for (uint32_t j = 0; j < ns; ++j)
-        items[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
-            make_uint4((uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT), f, max(r01, r23), 0u);
+        order[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
+            (uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT);
     } else if (w >= threshold) {
-      items[atomicAdd(&cnt[bucket_of(e.x) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF, f, r01, 0u);
-      items[atomicAdd(&cnt[bucket_of(e.y) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART, f, r23, 0u);
+      order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
+      order[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
     } else {
-      items[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = make_uint4((uint32_t)t, f, max(r01, r23), 0u);
+      order[atomicAdd(&cnt[bucket_of(w) * BWD_SUB + sub], 1u)] = (uint32_t)t;
     }
-  };
-  if (in_regs) {
-#pragma unroll
-    for (int j0 = 0; j0 < EST_REG; j0 += 4) {
-      uint32_t f[4];
-      uint4 mc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {  // (unconditional, clamped: the four tiles' loads travel together)
-        const int t = (int)threadIdx.x + 1024 * (j0 + u), tc = t < T ? t : max(T - 1, 0);
-        f[u] = ranges[tc].x;
-        mc[u] = reinterpret_cast<const uint4*>(maxc)[tc];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = (int)threadIdx.x + 1024 * (j0 + u);
-        if (t < T) put(t, er[j0 + u], nseg[j0 + u], f[u], mc[u]);
-      }
-    }
-  } else {
-    for (int t = threadIdx.x; t < T; t += 1024) {
-      const uint4 e4 = reinterpret_cast<const uint4*>(est)[t];
-      const uint2 e = make_uint2(e4.x + e4.y, e4.z + e4.w);
-      put(t, e, segments ? segments_of(t, e.x + e.y, tile_maxc[t]) : 1u, ranges[t].x, reinterpret_cast<const uint4*>(maxc)[t]);
-    }
-  }
+  });
 }
 
 // Compute units of the device a launch goes to: the device of the STREAM (a C-ABI caller may hand over a stream of another
@@ -1491,9 +1468,9 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     clear.ptr[2] = a.dL_dopacity; clear.n[2] = P;
     clear.ptr[3] = a.dL_dcolors; clear.n[3] = 3 * P;
   }
-  if (a.work_est == nullptr || a.work_maxc == nullptr || a.bwd_items == nullptr) return hipErrorInvalidValue;
+  if (a.work_est == nullptr || a.work_maxc == nullptr || a.bwd_order == nullptr) return hipErrorInvalidValue;
   {
-    // its own work list (item descriptors), ordered by the work the forward measured
+    // its own work list, ordered by the work the forward measured
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
     const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : 0u;  // (1 .. 8 per CU: the same 14 us)
     // GSR_BWD_SEG: tiles above this many eighths of a fair share are cut into list segments where the forward left
@@ -1502,13 +1479,12 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     seg_items = a.ck_table != nullptr && a.ck_chunks > 0 && seg_share > 0 && ablate == 0;
     if (seg_items)
       hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES,
-                         halves, clear, (const uint32_t*)a.tile_maxc, (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work,
-                         (uint32_t)a.ck_chunks * WAVE, seg_share);
+                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)a.tile_maxc,
+                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, seg_share);
     else
       hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
-                         (const uint32_t*)a.work_maxc, a.ranges, a.bwd_items, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES,
-                         halves, clear, (const uint32_t*)nullptr, (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+                         a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
   }
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size(true, s, sh) / BWD_WAVES), b(WAVE * BWD_WAVES);

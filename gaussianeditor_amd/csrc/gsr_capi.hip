@@ -180,7 +180,7 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.work_meta = im.work_meta;
   a.work_est = im.work_est;
   a.work_maxc = im.work_maxc;
-  a.bwd_items = im.bwd_items;
+  a.bwd_order = im.bwd_order;
   a.bwd_meta = im.bwd_meta;
   a.ranges = im.ranges;
   a.point_list = b.point_list;

@@ -112,14 +112,11 @@ struct Image {
   uint32_t* work_meta;  // [0] = number of non-empty tiles
   uint32_t* work_est;   // (T,4) entries the forward blend evaluated per (tile, quadrant): the backward's work estimate
   uint32_t* work_maxc;  // (T,4) right behind work_est (one clear): the largest last-contributor position + 1 over the quadrant's
-                        //      pixels, left by the forward blend -- how deep the backward walks the tile's list, known to its work
-                        //      list without a look at n_contrib
-  uint4* bwd_items;     // (2T + CK_MAX * CK_TILES(T)) items of the backward blend (a tile, half of a heavy tile, or a list segment
-                        //      of a deep one), most forward work first, tiles without any work dropped; an item is a DESCRIPTOR:
-                        //      x = item code (tile | flags), y = first position of the tile's list (ranges[tile].x), z = positions
-                        //      the item's pixels reach (max of work_maxc over its quadrants) -- one load behind the pop instead of
-                        //      work list -> ranges -> n_contrib -> workgroup maximum
-  uint32_t* bwd_meta;   // [0] = number of items in bwd_items
+                        //      pixels, left by the forward blend -- how deep the backward walks the tile's list, known to an item
+                        //      from one scalar load instead of n_contrib -> maximum over the workgroup (two barriers)
+  uint32_t* bwd_order;  // (2T + CK_MAX * CK_TILES(T)) items of the backward blend (a tile, half of a heavy tile, or a list segment of a deep
+                        //      one): most forward work first, tiles without any work dropped
+  uint32_t* bwd_meta;   // [0] = number of items in bwd_order
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
   // Checkpoints of the forward blend (round 4): the backward can then walk a tile's list as independent SEGMENTS in
   // separate work items.  The state of a pixel in front of list position k * stride (transmittance, accumulated colour)
@@ -152,7 +149,7 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H, bool with
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += sizeof(uint32_t) * 4 * T;  // (work_maxc follows without a gap)
   im.work_maxc = (uint32_t*)(p + off);  off = align_up(off + sizeof(uint32_t) * 4 * T);
-  im.bwd_items = (uint4*)(p + off);     off += align_up(sizeof(uint4) * (2 * T + 8 /* CK_MAX */ * (T < 2048 ? T : 2048)));
+  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + 8 /* CK_MAX */ * (T < 2048 ? T : 2048)));
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
   im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * T);

@@ -63,7 +63,7 @@ struct BlendArgs {
   const uint32_t* work_meta;   // [0] = number of non-empty tiles
   uint32_t* work_est;          // forward: out, (T,4) evaluated entries per quadrant; null = not recorded
   uint32_t* work_maxc;         // forward: out, (T,4) deepest contributing list position + 1 per quadrant (with work_est)
-  uint4* bwd_items;            // backward launch: its own work list, one descriptor per item (gsr_blend.hip: backward_worklist_kernel)
+  uint32_t* bwd_order;         // backward launch: scratch for its own work list (gsr_blend.hip: backward_worklist_kernel)
   uint32_t* bwd_meta;
   uint32_t* queue;             // 8 per-XCD cursors + retire counters of this kind, QUEUE_STRIDE words apart; zero on
                                // entry, and left zero again by the launch's last workgroup
