@@ -203,27 +203,56 @@ class GradBucket:
         return {k: v for k, v in self.views.items() if self.sh_exchange == "direct" or k != "sh"}
 
 
+#: GSR_VIEW_AUTOGRAD=1: one view's forward / backward go through the L1 autograd.Function and torch.autograd.grad, as up to
+#: round 4, instead of calling the L0 entry points directly (same native calls, same numbers; for A/B measurements)
+_VIEW_AUTOGRAD = _os.environ.get("GSR_VIEW_AUTOGRAD", "0") == "1"
+
+
 def _view_forward(settings, means3D, opacities, shs, scales, rotations):
-    """Forward of one view through the drop-in L1 API -> (color, radii, depth, leaves): what `_view_backward` needs."""
-    leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
-    m3, sh, op, sc, rot = leaves
-    # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
-    # not zero-filled here (the reference's render() does: gaussian_renderer/__init__.py:60-69)
-    m2 = torch.empty_like(m3).requires_grad_(True)
-    color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
-    return color, radii, depth, leaves + [m2]
+    """Forward of one view -> (color, radii, depth, saved): `saved` is what `_view_backward` needs.
+
+    The L0 entry points are called DIRECTLY (_C.rasterize_gaussians / _C.rasterize_gaussians_backward with the argument order
+    of the reference's rasterize_points.h:17-60, exactly what the L1 autograd.Function passes them): going through
+    autograd.Function.apply and torch.autograd.grad ran every view's backward on the engine's device thread and cost the
+    launch thread 280 us per view at 10^6 Gaussians -- the two-stream batch was bound by that, not by the GPU
+    (profiles/r05_c_view_pipelining.md).  GSR_VIEW_AUTOGRAD=1 restores the L1 route."""
+    if _VIEW_AUTOGRAD:
+        leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
+        m3, sh, op, sc, rot = leaves
+        # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
+        # not zero-filled here (the reference's render() does: gaussian_renderer/__init__.py:60-69)
+        m2 = torch.empty_like(m3).requires_grad_(True)
+        color, radii, depth = GaussianRasterizer(settings)(m3, m2, op, shs=sh, scales=sc, rotations=rot)
+        return color, radii, depth, leaves + [m2]
+    rs = settings
+    flags = _options.current_flags()
+    m3, sh, op, sc, rot = (t.detach() for t in (means3D, shs, opacities, scales, rotations))
+    absent = m3.new_empty(0)  # "not provided": colors_precomp, cov3D_precomp (diff_gaussian_rasterization/__init__.py:_absent)
+    R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+        rs.bg, m3, absent, op, sc, rot, rs.scale_modifier, absent, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+        rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, flags=flags)
+    return color, radii, depth, (flags, R, geom, binning, img, m3, sh, sc, rot, absent)
 
 
 def _view_backward(settings, state, dL_dcolor, bucket):
     """Backward of the view `_view_forward` rendered, with `dL_dcolor` as the pixel gradient -> the six rasterizer-input
     gradients (views of `bucket` when one is given)."""
-    color, radii, depth, leaves = state
-    m3, sh, op, sc, rot, m2 = leaves
-    if bucket is not None:
-        bucket.attach(color)
-    # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by the exchange)
-    g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
+    color, radii, depth, saved = state
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
+    if _VIEW_AUTOGRAD:
+        m3, sh, op, sc, rot, m2 = saved
+        if bucket is not None:
+            bucket.attach(color)
+        # ("rgb" exchange mode: the SH gradient comes back as None here and is rebuilt by the exchange)
+        g = torch.autograd.grad([color], [m3, sh, op, sc, rot, m2], grad_outputs=[dL_dcolor], allow_unused=True)
+    else:
+        rs = settings
+        flags, R, geom, binning, img, m3, sh, sc, rot, absent = saved
+        g_m2, _, g_op, g_m3, _, g_sh, g_sc, g_rot = _C.rasterize_gaussians_backward(
+            rs.bg, m3, radii, absent, sc, rot, rs.scale_modifier, absent, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, dL_dcolor, sh, rs.sh_degree, rs.campos, geom, R, binning, img, rs.debug, flags=flags,
+            grad_allocator=None if bucket is None else bucket.allocator)
+        g = (g_m3, g_sh, g_op, g_sc, g_rot, g_m2)
     grads = dict(zip(names, g))
     if bucket is not None:
         # Every gradient must now BE its bucket segment (all segments are 16-byte aligned, so the backward can always
@@ -244,7 +273,7 @@ def _view_backward(settings, state, dL_dcolor, bucket):
 
 def render_view_grads(settings: GaussianRasterizationSettings, means3D, opacities, shs, scales, rotations,
                       dL_dcolor: torch.Tensor, bucket: Optional[GradBucket] = None, after_forward=None):
-    """Forward + backward of ONE view through the drop-in L1 API with `dL_dcolor` as the
+    """Forward + backward of ONE view (the L0 entry points the drop-in L1 API calls) with `dL_dcolor` as the
     pixel gradient.  Returns (color, radii, depth, grads) where grads has the six
     rasterizer-input gradients (views of `bucket` when one is given).  `after_forward(radii)` is called between the
     forward and the backward (multiview_step starts the radii's MAX all-reduce there, so that it overlaps the backward)."""
