@@ -408,7 +408,15 @@ def extra_configs(dev, flags, budget_s=60.0):
         out["views8_one_gpu"] = dict(res, what="the 8 ring views of BASELINE configs[3] as ONE batch on one GPU (bench.py --views 8): "
                                                "forward + backward of every view, touched-rows messages, one accumulate; three "
                                                "repetitions of 12 steps each way")
-        del params, p1
+        # ---- the headline iteration with persistent gradient rows (opt-in, GradBucket(persistent_rows=True)): the backward
+        # rewrites a zero gradient row only if it does not hold zeros already.  NOT the headline: that writes every row.
+        bp = GradBucket(1_000_000, 16, dev, sh_exchange="auto", persistent_rows=True)
+        t_p = timed(lambda: multiview_step(rs8[0], p1, G2, bp, rows="auto"), 100, 30)
+        out["persistent_rows_1M_1080p"] = {
+            "what": "the headline workload (synth-v1, 1 M Gaussians, 1920x1080, ring view 0) with GradBucket(persistent_rows=True): "
+                    "same gradients, zero rows that already hold zeros are not rewritten; wall clock over 100 iterations",
+            "train_ms_per_step": 1e3 * t_p, "train_iters_per_s": 1.0 / t_p}
+        del bp, params, p1
         torch.cuda.empty_cache()
     out["seconds"] = time.perf_counter() - t_begin
     return out

@@ -245,3 +245,43 @@ def test_bench_eight_ranks_share_one_gpu(extra, views):
     if cfg["grad_exchange_route"] == "rows":
         assert len(cfg["grad_exchange_rows_per_view"]) == views and all(0 < c <= 40000 for c in cfg["grad_exchange_rows_per_view"])
         assert all(b > 0 for b in mg["per_rank"]["bytes_sent_per_step"])
+
+
+def test_views_rendered_through_the_l0_entry_points_equal_the_l1_autograd_route(monkeypatch):
+    """`multiview._view_forward` / `_view_backward` call `_C.rasterize_gaussians` / `_C.rasterize_gaussians_backward` directly
+    since round 5 (the autograd engine's thread hand-over cost the launch thread 280 us per view and bound the two-stream batch,
+    profiles/r05_c_view_pipelining.md).  Same native calls with the same arguments: every forward output and the gradients the
+    backward writes without atomics are bit-identical to the L1 route's, the atomically accumulated ones agree to the blend
+    backward's run-to-run spread -- without a bucket and with one ("direct" and "rgb" SH exchange)."""
+    import gaussianeditor_amd.multiview as mv
+    from helpers import settings
+
+    W, H, P = 320, 200, 20000
+    case = make_case(P, W, H, seed=5, s0=0.03)
+    dev = torch.device(DEV)
+    sc = case["sc"]
+    params = [sc[k].to(dev) for k in ("xyz", "opacity", "features", "scaling", "rotation")]
+    G = seed_gradient(H, W, 3).to(dev)
+    rs = settings(case, dev)
+
+    def run(autograd, bucket):
+        monkeypatch.setattr(mv, "_VIEW_AUTOGRAD", autograd)
+        color, radii, depth, grads = mv.render_view_grads(rs, *params, G, bucket)
+        torch.cuda.synchronize(dev)
+        return _np(color), _np(radii), _np(depth), {k: (None if v is None else _np(v).copy()) for k, v in grads.items()}
+
+    for mode in (None, "direct", "rgb"):
+        b0 = None if mode is None else mv.GradBucket(P, 16, dev, sh_exchange=mode)
+        b1 = None if mode is None else mv.GradBucket(P, 16, dev, sh_exchange=mode)
+        c0, r0, d0, g0 = run(False, b0)
+        c1, r1, d1, g1 = run(True, b1)
+        assert np.array_equal(c0, c1) and np.array_equal(r0, r1) and np.array_equal(d0, d1)
+        assert set(g0) == set(g1)
+        for k in g0:
+            if g0[k] is None or g1[k] is None:
+                assert g0[k] is None and g1[k] is None, (mode, k)
+                continue
+            scale = max(float(np.abs(g1[k]).max()), 1e-30)
+            assert float(np.abs(g0[k] - g1[k]).max()) <= 5e-6 * scale, (mode, k)
+        if mode == "rgb":
+            assert float(np.abs(_np(b0.rgb) - _np(b1.rgb)).max()) <= 5e-6 * max(float(np.abs(_np(b1.rgb)).max()), 1e-30)
