@@ -21,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--no-serial", action="store_true", help="only the pipelined form")
 ap.add_argument("--timeline", action="store_true", help="event-stamp the forward and the backward of every view of one extra step per round")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -52,7 +53,7 @@ def dev_allocs():
 # the same two forms alternately, several times over: does the FIRST one measured differ from the later ones?
 for rnd in range(a.rounds):
     for gc_on in (True,):
-        for name, on in (("pipelined", True), ("serial", False)):
+        for name, on in ((("pipelined", True),) if a.no_serial else (("pipelined", True), ("serial", False))):
             mv._VIEW_PIPELINE = on
             b8 = mv.GradBucket(P, 16, dev, sh_exchange="rgb")
             timed(lambda: mv.multiview_batch_step(rs8, p1, [G] * 8, b8), 10, 5)
@@ -74,12 +75,12 @@ for rnd in range(a.rounds):
                 f0, b0 = mv._view_forward, mv._view_backward
 
                 def stamped(kind, fn):
-                    def run(*args):
+                    def run(*args, **kw):
                         st = torch.cuda.current_stream(dev)
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         t_host = time.perf_counter()
                         e0.record(st)
-                        r = fn(*args)
+                        r = fn(*args, **kw)
                         e1.record(st)
                         stamps.append((kind, st.cuda_stream, e0, e1, t_host, time.perf_counter()))
                         return r
