@@ -199,6 +199,12 @@ constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 #ifndef GSR_FWD_SELECT_CHAIN
 #define GSR_FWD_SELECT_CHAIN 1  // 0: the masked (exec-region) serial part for every chunk (A/B builds)
 #endif
+// T / (1 - alpha) of the backward's transmittance chain (backward.cu:503): 0 = T * v_rcp_f32 (1 ulp), 2 = the reciprocal
+// refined by one Newton step (the product since round 5: along a list of thousands of translucent entries the raw
+// reciprocal's error accumulated to 1e-5 of a gradient, tools/fuzz_v2.py seeds 110 / 256), 1 = IEEE division (A/B builds)
+#ifndef GSR_BWD_DIV
+#define GSR_BWD_DIV 2
+#endif
 #ifndef GSR_BWD_DEFER_FLUSH
 #define GSR_BWD_DEFER_FLUSH 1  // 0: round 4's loop -- flush at the end of its own chunk, two barriers per chunk (A/B builds)
 #endif
@@ -418,6 +424,13 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   const f32x2 pfx2 = {pfx, pfx}, pfy2 = {pfy, pfy};
   f32x2 C01 = {0.f, 0.f}, C2D = {0.f, 0.f};  // (C0, C1), (C2, D)
+  // CKPT: the colour accumulated SINCE THE LAST CHECKPOINT, in accumulators of its own (round 5).  The backward needs, at a
+  // segment's upper end, the colour of everything behind it; as C_final - C(checkpoint) that is a difference of two sums
+  // near 1 whose increments were rounded to 6e-8 each, divided by a transmittance that may be 0.01 -- the gradients of a
+  // Gaussian in front of a dense segment came out 1e-5 .. 2e-5 off (tools/fuzz_v2.py, seed 365).  A segment's own sum
+  // carries its own magnitude's rounding only.
+  f32x2 S01 = {0.f, 0.f};
+  float S2 = 0.f;
   // Checkpoints for the backward's list segments (Image::ck_*): in front of list position k * stride the state of every
   // pixel that is still live -- transmittance and accumulated colour -- goes into the tile's slot k (one 16-byte store per
   // lane and one atomic per wave: the slots are assigned by tile_worklist_kernel, nothing is allocated here).
@@ -445,7 +458,12 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       if (live_m == 0) break;
       if (ckpt && walk.chunk == ck_next) {  // (uniform; never for walks shorter than the stride)
         if (ck_k < (uint32_t)CK_MAX) {
-          if (!done) a.ck_pool[((size_t)ck_base * CK_MAX + ck_k) * (TILE * TILE) + pidx] = make_float4(T, C01.x, C01.y, C2D.x);
+          // slot k: T in front of position k * stride, and the colour of segment k - 1.  Written by every pixel of the
+          // quadrant (a saturated one writes zeros: the backward never reads them, but it may read the slots of a pixel that
+          // is live and simply found nothing to blend)
+          if (pw.inside) a.ck_pool[((size_t)ck_base * CK_MAX + ck_k) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
+          S01 = f32x2{0.f, 0.f};
+          S2 = 0.f;
           // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
           if (lane == 0) atomicAdd(&a.ck_work[(size_t)tile * CK_MAX + ck_k], evaluated);
         }
@@ -541,6 +559,10 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
             const f32x2 w2 = {wz, wz};
             C01 = __builtin_elementwise_fma(rg[u], w2, C01);
             C2D = __builtin_elementwise_fma(bz[u], w2, C2D);
+            if (ckpt) {
+              S01 = __builtin_elementwise_fma(rg[u], w2, S01);
+              S2 = __builtin_fmaf(bz[u].x, wz, S2);
+            }
             Ts = A ? test_T : -__builtin_fabsf(Ts);
             last_contributor = (wz > 0.0f) ? __float_as_uint(posf[u]) : last_contributor;
           }
@@ -600,6 +622,10 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
               const f32x2 w2 = {w, w};
               C01 = __builtin_elementwise_fma(rg[u], w2, C01);
               C2D = __builtin_elementwise_fma(bz[u], w2, C2D);
+              if (ckpt) {
+                S01 = __builtin_elementwise_fma(rg[u], w2, S01);
+                S2 = __builtin_fmaf(bz[u].x, w, S2);
+              }
               T = test_T;
               last_contributor = __float_as_uint(posf[u]);
             }
@@ -613,10 +639,13 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   // how deep the backward will walk this quadrant's part of the list (a lane outside the image never contributes)
   const uint32_t deep = (a.work_est != nullptr || ckpt) ? wave_max_u32_dpp(last_contributor) : 0u;
   if (ckpt) {
-    // ... for the whole tile, and -- for the pixels some checkpoint was written for -- the FINAL state (slot 0): with it a
-    // list segment's backward knows what lies behind its last position
+    // ... for the whole tile, and -- for the pixels some checkpoint was written for -- the colour of the segment the walk
+    // ended in, as if its closing checkpoint had been reached: slot ck_k, or slot 0 once the tile's slots are used up (that
+    // "segment" then reaches to the end of the list).  With it the colour of segment k is ALWAYS in slot k + 1 (k + 1 < CK_MAX)
+    // or in slot 0 (k = CK_MAX - 1), whether the wave went on beyond it or not.
     if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
-    if (ck_k > 1u && pw.inside) a.ck_pool[(size_t)ck_base * CK_MAX * (TILE * TILE) + pidx] = make_float4(T, C0, C1, C2);
+    if (ck_k > 1u && pw.inside)
+      a.ck_pool[((size_t)ck_base * CK_MAX + (ck_k < (uint32_t)CK_MAX ? ck_k : 0u)) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
   }
   // the backward's work estimate and walk depth for the quadrant.  One item per quadrant: plain stores; the sub-items of a
   // cut quadrant report the largest of their values (they walk the same list).
@@ -783,12 +812,23 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
     // would have there.  T in front of position seg_hi is the forward's checkpoint; the colour recurrence (accum_rec,
     // backward.cu:515) at that point is the colour of everything behind, over that transmittance:
     //   accum_rec = (C_final - C(seg_hi)) / T(seg_hi),  with nothing pending (last_alpha = 0).
+    // Round 5: the colour behind is the SUM of the later segments' own colours (the forward accumulates every segment from
+    // zero: slot k + 1 holds segment k's, slot 0 that of segment CK_MAX - 1 and everything after it), smallest first -- as
+    // C_final - C(seg_hi) it was a difference of two numbers near 1 divided by a small transmittance.
     const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
-    const size_t slot0 = (size_t)a.ck_table[tile] * CK_MAX;  // (slot 0: the final state; slot k: in front of position k * stride)
-    const float4 ck = a.ck_pool[(slot0 + seg + 1u) * (TILE * TILE) + pidx];
-    const float4 fin = a.ck_pool[slot0 * (TILE * TILE) + pidx];
-    T = ck.x;
-    B_acc = ((fin.y - ck.y) * dpx[0] + (fin.z - ck.z) * dpx[1] + (fin.w - ck.w) * dpx[2]) / ck.x;
+    const size_t slot0 = (size_t)a.ck_table[tile] * CK_MAX;  // (slot k >= 1: T in front of position k * stride + segment k - 1's colour)
+    const uint32_t m = min((last_contributor - 1u) / stride, (uint32_t)CK_MAX - 1u);  // the segment of the pixel's last contributor
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    for (uint32_t k = (uint32_t)CK_MAX - 1u; k > seg; --k) {  // (wave-uniform bounds; a lane takes part from its own m down)
+      if (k <= m) {
+        const float4 sk = a.ck_pool[(slot0 + (k + 1u < (uint32_t)CK_MAX ? k + 1u : 0u)) * (TILE * TILE) + pidx];
+        b0 += sk.y;
+        b1 += sk.z;
+        b2 += sk.w;
+      }
+    }
+    T = a.ck_pool[(slot0 + seg + 1u) * (TILE * TILE) + pidx].x;
+    B_acc = (b0 * dpx[0] + b1 * dpx[1] + b2 * dpx[2]) / T;
   }
 
   // Flush of one chunk's accumulators: thread (w, lane) owns chunk slot `lane`; wave 0 forms dL_dmean2D from moments 1, 2
@@ -934,7 +974,15 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
           // and its moments are zero -- three selects per entry instead of six.
           const bool on = contrib[u];
           const float alpha = on ? al[u] : 0.f;
+#if GSR_BWD_DIV == 1  // (A/B builds) IEEE division
+          const float inv_one_m = 1.0f / (1.f - alpha);
+#elif GSR_BWD_DIV == 2  // rcp + one Newton step
+          const float one_m = 1.f - alpha;
+          const float r0 = __builtin_amdgcn_rcpf(one_m);
+          const float inv_one_m = __builtin_fmaf(r0, __builtin_fmaf(-one_m, r0, 1.0f), r0);
+#else
           const float inv_one_m = __builtin_amdgcn_rcpf(1.f - alpha);
+#endif
           const float cdot = cols[u].x * dpx[0] + cols[u].y * dpx[1] + cols[u].z * dpx[2];
           T = T * inv_one_m;                                      // T / (1 - alpha), backward.cu:503
           B_acc = B_acc + last_alpha * (last_cdot - B_acc);       // accum_rec update, backward.cu:515

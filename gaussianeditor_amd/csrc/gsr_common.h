@@ -119,10 +119,11 @@ struct Image {
   uint32_t* bwd_meta;   // [0] = number of items in bwd_order
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
   // Checkpoints of the forward blend (round 4): the backward can then walk a tile's list as independent SEGMENTS in
-  // separate work items.  The state of a pixel in front of list position k * stride (transmittance, accumulated colour)
-  // is one float4; a checkpoint of a tile is 256 of them.  The CK_TILES(T) tiles with the longest lists own CK_MAX
-  // consecutive 4 KB slots each (slot 0: the tile's FINAL state), assigned by tile_worklist_kernel -- no allocation, no
-  // atomics in the forward's loop.
+  // separate work items.  A checkpoint of a pixel is one float4, a checkpoint of a tile 256 of them: slot k >= 1 holds the
+  // transmittance in front of list position k * stride and (round 5) the colour segment k - 1 -- positions [(k - 1) stride,
+  // k stride) -- contributed, accumulated from zero; slot 0 the colour of segment CK_MAX - 1 and everything behind it.  The
+  // CK_TILES(T) tiles with the longest lists own CK_MAX consecutive 4 KB slots each, assigned by tile_worklist_kernel -- no
+  // allocation, no atomics in the forward's loop.
   uint32_t* ck_table;   // (T)  the tile's rank among the checkpointed tiles (its slots: rank * CK_MAX + k), or CK_NONE
   uint32_t* ck_work;    // (T x CK_MAX) entry k: entries the forward had evaluated in the tile when it reached checkpoint k (summed
                         //      over its quadrants): how the tile's backward work splits over its list segments.  Zero per view.
@@ -130,7 +131,7 @@ struct Image {
   float4* ck_pool;      // (CK_TILES(T) x CK_MAX x 256)
   size_t bytes;
 };
-constexpr int CK_MAX = 8;            // slots per tile: the final state + 7 checkpoints (beyond that depth the last segment is longer)
+constexpr int CK_MAX = 8;            // slots per tile: 7 checkpoints + the tail (beyond that depth the last segment is longer)
 constexpr uint32_t CK_NONE = 0xffffffffu;
 constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions) where checkpoints are on
 __host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (64 MB of slots at most)

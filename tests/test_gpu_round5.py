@@ -34,6 +34,16 @@ FUZZ_OUTLIERS = (2977, 3019, 3186)
 
 @pytest.mark.parametrize("seed", FUZZ_OUTLIERS)
 def test_fuzz_outliers_are_no_further_from_float64_than_the_reference(oracle, seed):
+    """The sweep's outliers, four ways (see `four_way`)."""
+    case, sm, D = _sweep_case(seed)
+    four_way(oracle, case, sm, D, seed)
+
+
+class RestatementMismatch(AssertionError):
+    """four_way: the float64 restatement rendered another image than the binary32 forward (it cannot judge the gradients)."""
+
+
+def four_way(oracle, case, sm, D, seed, image_tol=1e-5):
     """Four-way on the sweep's outliers: reference(no contraction) backward / oracle / product / float64 autograd.
 
     The product's gradients must be no further from the float64 restatement than the reference's OWN backward
@@ -47,7 +57,6 @@ def test_fuzz_outliers_are_no_further_from_float64_than_the_reference(oracle, se
     import test_gpu_parity as tp
     from oracle.torch_ref import render_f64
 
-    case, sm, D = _sweep_case(seed)
     sc, cam, W, H = case["sc"], case["cam"], case["W"], case["H"]
     P = sc["xyz"].shape[0]
     f, _ = tp._compare_forward(oracle, case, scale_modifier=sm)  # every stage of the forward, bit for bit
@@ -65,7 +74,11 @@ def test_fuzz_outliers_are_no_further_from_float64_than_the_reference(oracle, se
     img = render_f64(f, ins["xyz"], m2, ins["opacity"], ins["scaling"], ins["rotation"], ins["features"], None, None,
                      cam.world_view_transform, cam.full_proj_transform, cam.camera_center, case["bg"], W, H, case["tfx"],
                      case["tfy"], sm, D, dL_dimage=G)
-    assert np.abs(img.float().numpy() - f["color"]).max() < 1e-5
+    # (the float64 restatement renders the same image; scenes whose pixels sum thousands of translucent layers -- tools/fuzz_v2.py
+    #  -- differ from the binary32 forward by more than the suite's cases do: the caller then widens the sanity bound)
+    worst_px = float(np.abs(img.float().numpy() - f["color"]).max())
+    if not worst_px < image_tol:  # (a pixel where float64 decides an alpha / transmittance threshold the other way: no judge)
+        raise RestatementMismatch(f"the float64 restatement's image differs from the binary32 forward's by {worst_px:.2e}")
     g64 = {"dL_dmeans3D": ins["xyz"].grad, "dL_dmeans2D": m2.grad, "dL_dopacity": ins["opacity"].grad,
            "dL_dscales": ins["scaling"].grad / sm, "dL_drotations": ins["rotation"].grad, "dL_dsh": ins["features"].grad}
     pv = torch.cat([sc["xyz"].to(d), torch.ones(P, 1, dtype=d)], 1) @ cam.world_view_transform.to(d)
