@@ -95,7 +95,25 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max())) if a.size else 0.0
 
 
-__all__ = ["make_case", "oracle_forward", "oracle_backward", "settings", "hip_state", "rel_err", "seed_gradient"]
+def v2_fuzz_case(seed):
+    """Configuration `seed` of tools/fuzz_v2.py: a synth-v2 scene (thin disks on surfaces, bimodal opacity) of random size seen
+    through a random small image -> (case, scale_modifier, sh_degree)."""
+    from gaussianeditor_amd.synth import synth_scene_v2
+
+    rng = np.random.default_rng(77000 + seed)
+    P = int(rng.integers(300, 9000))
+    W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 5 == 0 else rng.integers(8, 500))
+    H = int(rng.choice([1, 3, 16, 47]) if seed % 7 == 1 else rng.integers(8, 320))
+    D = int(rng.integers(0, 4))
+    sm = float(rng.choice([0.5, 1.0, 1.7]))
+    case = make_case(P, W, H, seed=seed, view=int(rng.integers(0, 8)), nviews=8, sh_degree=D)
+    sc = synth_scene_v2(P, seed=seed, sh_degree=D)
+    sc["xyz"] = (sc["xyz"] * float(rng.choice([0.5, 1.0, 1.0, 2.0]))).contiguous()
+    case["sc"] = sc
+    return case, sm, D
+
+
+__all__ = ["make_case", "oracle_forward", "oracle_backward", "settings", "hip_state", "rel_err", "seed_gradient", "v2_fuzz_case"]
 
 
 # ---- the reference's own sources compiled for gfx950 (oracle/_ref): presence is LOUD when asked for ----

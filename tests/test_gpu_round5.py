@@ -298,3 +298,32 @@ def test_views_rendered_through_the_l0_entry_points_equal_the_l1_autograd_route(
             assert float(np.abs(g0[k] - g1[k]).max()) <= 5e-6 * scale, (mode, k)
         if mode == "rgb":
             assert float(np.abs(_np(b0.rgb) - _np(b1.rgb)).max()) <= 5e-6 * max(float(np.abs(_np(b1.rgb)).max()), 1e-30)
+
+
+@pytest.mark.parametrize("seed", [365, 110])
+def test_deep_translucent_lists_keep_the_gradients_inside_the_bar(oracle, seed):
+    """Two configurations of tools/fuzz_v2.py (synth-v2 scenes through tiny images) that exposed product-specific precision
+    losses in round 5, both along lists of thousands of translucent entries:
+      365 (2 x 16 pixels, ONE tile with a list of 3 231 entries, so forward checkpoints + backward list segments are on): the
+          colour behind a segment was C_final - C(checkpoint), two sums near 1 with 6e-8 roundings, divided by a small
+          transmittance -- gradients of Gaussians in front of a dense segment 1.1e-5 .. 2.3e-5 off where the reference's own
+          backward is 1e-6 from float64.  The forward now accumulates every segment's colour from zero: <= 1.5e-6;
+      110 (1 x 151): T / (1 - alpha) with the raw v_rcp_f32 accumulated 2.6e-5 on dL_dscales; with one Newton step 1.6e-5,
+          which is where the reference's own backward sits on this scene (four-way: tools/fuzz_v2.py --judge --only 110)."""
+    import test_gpu_parity as tp
+    from helpers import v2_fuzz_case
+
+    case, sm, D = v2_fuzz_case(seed)
+    f, _ = tp._compare_forward(oracle, case, scale_modifier=sm)  # every stage of the forward, bit for bit
+    H, W = case["H"], case["W"]
+    G = seed_gradient(H, W, seed) * (H * W)
+    g = oracle_backward(oracle, case, f, G, scale_modifier=sm)
+    h = tp._grads_hip(case, G, scale_modifier=sm)
+    errs = {k: tp.rel_err(v, g[k].reshape(v.shape)) for k, v in h.items()}
+    print(f"seed {seed}: R = {f['num_rendered']}, errors {errs}")
+    if seed == 365:
+        assert f["num_rendered"] > 2048 and f["ranges"].reshape(-1, 2).shape[0] == 1  # (one tile, long list: segments are on)
+        assert max(errs.values()) <= 3e-6
+    else:
+        assert max(errs[k] for k in ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dsh")) <= 1e-5
+        assert max(errs.values()) <= 2e-5  # (2.6e-5 - 2.7e-5 with the raw reciprocal)

@@ -28,8 +28,8 @@ def main():
     ap.add_argument("--only", type=int, nargs="*", default=None, help="only these seeds")
     a = ap.parse_args()
     import test_gpu_parity as tp
-    from gaussianeditor_amd.synth import seed_gradient, synth_scene_v2
-    from helpers import make_case, oracle_backward
+    from gaussianeditor_amd.synth import seed_gradient
+    from helpers import oracle_backward, v2_fuzz_case
     from oracle import cpu
 
     cpu.build()
@@ -37,16 +37,8 @@ def main():
     for seed in (a.only if a.only else range(a.first, a.first + a.count)):
         if time.time() - t0 > a.seconds:
             break
-        rng = np.random.default_rng(77000 + seed)
-        P = int(rng.integers(300, 9000))
-        W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 5 == 0 else rng.integers(8, 500))
-        H = int(rng.choice([1, 3, 16, 47]) if seed % 7 == 1 else rng.integers(8, 320))
-        D = int(rng.integers(0, 4))
-        sm = float(rng.choice([0.5, 1.0, 1.7]))
-        case = make_case(P, W, H, seed=seed, view=int(rng.integers(0, 8)), nviews=8, sh_degree=D)
-        sc = synth_scene_v2(P, seed=seed, sh_degree=D)
-        sc["xyz"] = (sc["xyz"] * float(rng.choice([0.5, 1.0, 1.0, 2.0]))).contiguous()
-        case["sc"] = sc
+        case, sm, D = v2_fuzz_case(seed)
+        P, W, H = case["sc"]["xyz"].shape[0], case["W"], case["H"]
         what = (seed, P, W, H, D, sm)
         try:
             f, _ = tp._compare_forward(cpu, case, scale_modifier=sm)

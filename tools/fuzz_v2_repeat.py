@@ -15,22 +15,14 @@ ap.add_argument("seeds", type=int, nargs="+")
 ap.add_argument("--runs", type=int, default=4)
 a = ap.parse_args()
 import test_gpu_parity as tp  # noqa: E402
-from gaussianeditor_amd.synth import seed_gradient, synth_scene_v2  # noqa: E402
-from helpers import make_case, oracle_backward, oracle_forward  # noqa: E402
+from gaussianeditor_amd.synth import seed_gradient  # noqa: E402
+from helpers import oracle_backward, oracle_forward, v2_fuzz_case  # noqa: E402
 from oracle import cpu  # noqa: E402
 
 cpu.build()
 for seed in a.seeds:
-    rng = np.random.default_rng(77000 + seed)
-    P = int(rng.integers(300, 9000))
-    W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 5 == 0 else rng.integers(8, 500))
-    H = int(rng.choice([1, 3, 16, 47]) if seed % 7 == 1 else rng.integers(8, 320))
-    D = int(rng.integers(0, 4))
-    sm = float(rng.choice([0.5, 1.0, 1.7]))
-    case = make_case(P, W, H, seed=seed, view=int(rng.integers(0, 8)), nviews=8, sh_degree=D)
-    sc = synth_scene_v2(P, seed=seed, sh_degree=D)
-    sc["xyz"] = (sc["xyz"] * float(rng.choice([0.5, 1.0, 1.0, 2.0]))).contiguous()
-    case["sc"] = sc
+    case, sm, D = v2_fuzz_case(seed)
+    P, W, H = case["sc"]["xyz"].shape[0], case["W"], case["H"]
     f = oracle_forward(cpu, case, scale_modifier=sm)
     G = seed_gradient(H, W, seed) * (H * W)
     g = oracle_backward(cpu, case, f, G, scale_modifier=sm)
