@@ -216,7 +216,7 @@ def _view_forward(settings, means3D, opacities, shs, scales, rotations):
     autograd.Function.apply and torch.autograd.grad ran every view's backward on the engine's device thread and cost the
     launch thread 280 us per view at 10^6 Gaussians -- the two-stream batch was bound by that, not by the GPU
     (profiles/r05_c_view_pipelining.md).  GSR_VIEW_AUTOGRAD=1 restores the L1 route."""
-    if _VIEW_AUTOGRAD:
+    if _VIEW_AUTOGRAD or settings.debug:  # (debug renders keep the L1 route: it dumps the inputs of a failing call)
         leaves = [t.detach().requires_grad_(True) for t in (means3D, shs, opacities, scales, rotations)]
         m3, sh, op, sc, rot = leaves
         # the screen-space dummy only carries a gradient; its values are never read (forward.cu ignores means2D), so it is
@@ -239,7 +239,7 @@ def _view_backward(settings, state, dL_dcolor, bucket):
     gradients (views of `bucket` when one is given)."""
     color, radii, depth, saved = state
     names = ("means3D", "sh", "opacities", "scales", "rotations", "means2D")
-    if _VIEW_AUTOGRAD:
+    if len(saved) == 6:  # (the L1 route's leaves, see _view_forward)
         m3, sh, op, sc, rot, m2 = saved
         if bucket is not None:
             bucket.attach(color)
