@@ -4,7 +4,7 @@
 // CDNA4 mapping.  The reference runs one 256-thread block per 16x16 tile (8 warps of 32)
 // with block-wide barriers around a shared-memory staging buffer.  Here the unit of work is
 // ONE WAVE64 = one 8x8 pixel quadrant of a tile, launched as a single-wave workgroup:
-//   * no workgroup barrier exists anywhere in these kernels (a one-wave workgroup's
+//   * the forward and the tracing kernel have no workgroup barrier (a one-wave workgroup's
 //     s_barrier is free), each quadrant terminates as soon as ITS 64 pixels are opaque,
 //     and the CU's wave slots are refilled at wave granularity;
 //   * 8x8 is the most compact 64-pixel footprint, so the exec mask stays coherent and the
@@ -21,8 +21,8 @@
 //     Gaussians through the same 4 MiB L2.  Which wave runs an item never affects results;
 //   * the backward runs one 4-wave workgroup per tile: the quadrant waves reduce the 9 per-Gaussian gradient terms of
 //     four entries at a time across their 64 lanes (two v_permlane32_swap, one v_permlane16_swap, four row_shr DPP adds),
-//     add their totals into a per-chunk LDS accumulator, and ONE global atomic per (tile, instance, term) leaves the CU --
-//     the reference issues one per pixel.
+//     add their totals into a per-chunk LDS accumulator (double-buffered by chunk parity: one workgroup barrier per chunk),
+//     and ONE global atomic per (tile, instance, term) leaves the CU -- the reference issues one per pixel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -30,7 +30,6 @@
 #include "gsr_kernels.h"
 
 namespace gsr {
-
 
 struct PixelWave {
   int tile, px, py;
@@ -383,18 +382,11 @@ struct ChunkWalker {
   }
 };
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-  return v;
-}
-
 // ----------------------------------------------------------------------------------
 // K6: renderCUDA (forward), DGR/cuda_rasterizer/forward.cu:261-379.
 // ----------------------------------------------------------------------------------
-// `range`: the tile's list range (ranges[tile]); `bg`: the background, read once per kernel; `next`: the wave's item
-// stream -- the pop for the item after this one is issued BEHIND this item's first loads.
-// `bg`: the background, read once per kernel (see blend_forward_kernel).
+// One forward item: a quadrant of `tile` (or, on small images, a part of one: SPLIT).  `bg0..2`: the background, read once
+// per kernel into scalar registers (see blend_forward_kernel).
 template <bool PROFILE, bool AUX, int SPLIT, bool FAST, bool CKPT>
 __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, uint32_t quad, const float bg0, const float bg1,
                                              const float bg2, uint32_t& prof_visited, uint64_t* prof_cyc) {

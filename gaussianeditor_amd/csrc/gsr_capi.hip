@@ -145,8 +145,9 @@ inline int bin_legacy(int W, int H) {
 // strides below 256 the segments' start state shows in the per-row parity bar.  A function of what gsr_blend_forward
 // and gsr_blend_backward of a view both receive (R, W, H), so the two agree.  GSR_CK_CHUNKS overrides it (tests use 1 or 2
 // to segment small scenes; 0 = never).  Never changes a result beyond the backward's summation order.
-// Strides below 4 chunks (256 positions) put a list segment's start state -- a difference of two binary32 accumulators of
-// the forward -- inside the per-row parity bar (profiles/r04_d_segments.md): the override is clamped to >= 4 unless
+// Strides below 4 chunks (256 positions) are never a gain, and in round 4 -- when a list segment's start state was a
+// difference of two binary32 accumulators of the forward -- they cost precision (profiles/r04_d_segments.md; since round 5
+// the forward accumulates every segment's colour separately, gsr_blend.hip): the override is clamped to >= 4 unless
 // GSR_CK_DEBUG=1 says the caller knows (the tolerance tests segment small scenes at stride 64).
 inline int checkpoint_chunks(int64_t R, int W, int H) {
   static const int env = [] {
