@@ -34,4 +34,10 @@ def pytest_terminal_summary(terminalreporter):
         return
     n = len(helpers.REF_BACKED)
     req = os.environ.get("GSR_REQUIRE_REF") == "1"
-    terminalreporter.write_line(f"reference-backed tests (oracle/_ref): {n} ran" + (" [GSR_REQUIRE_REF=1]" if req else ""))
+    line = f"reference-backed tests (oracle/_ref): {n} ran" + (" [GSR_REQUIRE_REF=1]" if req else "")
+    # a GPU run in which tests that need the reference build were SKIPPED: say so where the result line is read
+    skipped = [r for r in terminalreporter.stats.get("skipped", []) if "oracle/_ref" in str(getattr(r, "longrepr", ""))]
+    if skipped:
+        line += (f"; {len(skipped)} SKIPPED because oracle/_ref is missing -- the comparison against the reference's own kernels "
+                 "did not run (GSR_REQUIRE_REF=1 turns that into failures)")
+    terminalreporter.write_line(line)
