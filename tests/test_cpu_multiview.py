@@ -513,7 +513,7 @@ def test_speculative_message_size_is_exact_when_it_overflows(oracle, tmp_path):
 KB = 8
 
 
-def _worker_batch(rank, world, port, out_dir, steps):
+def _worker_batch(rank, world, port, out_dir, steps, KB=KB):
     import sys
 
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -541,7 +541,7 @@ def _worker_batch(rank, world, port, out_dir, steps):
         assert len(colors) == len(mine) and bucket.last_route == "rows" and len(bucket.last_counts) == KB
         assert bucket.last_exchange["speculated"] == (steps == 2)  # first step and overflowing step: exact; second: speculated
         assert bucket.last_exchange["views"] == KB and bucket.last_exchange["views_local"] == len(mine)
-        np.savez(os.path.join(out_dir, f"batch_w{world}_r{rank}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
+        np.savez(os.path.join(out_dir, f"batch_w{world}_r{rank}{'' if KB == 8 else f'_k{KB}'}.npz"), flat=_segments(bucket), sh=bucket.views["sh"].numpy(),
                  radii=radii.numpy(), counts=np.array(bucket.last_counts))
     finally:
         mpatch.undo()
@@ -631,3 +631,18 @@ def test_densify_synchronized_on_eight_ranks(tmp_path):
     assert all(np.array_equal(rs[0]["xyz"], r["xyz"]) for r in rs[1:]) and rs[0]["xyz"].shape[0] > 200
     assert len({float(r["before"][0]) for r in rs}) == world  # eight different generators went in
     assert all(np.load(tmp_path / f"dzr_{r}.npz")["raised"][0] for r in range(world))
+
+
+def test_batch_of_sixteen_views_on_eight_ranks_is_bit_identical_to_the_single_process_loop(oracle, tmp_path):
+    """`bench.py --gpus 8 --views 16` in numbers: the fixed batch of 16 views dealt to EIGHT gloo ranks, two per rank (each packed
+    into its message before the next one's backward overwrites the bucket), one 8-way all-gather -- every replica the same bits,
+    equal to one process that renders all sixteen, over two steps (the second on a speculated message size)."""
+    K16, world, steps = 16, 8, 2
+    _worker_batch(0, 1, 0, str(tmp_path), steps, K16)
+    mp.spawn(_worker_batch, args=(world, _free_port(), str(tmp_path), steps, K16), nprocs=world, join=True)
+    one = np.load(tmp_path / f"batch_w1_r0_k{K16}.npz")
+    assert len(one["counts"]) == K16
+    for r in range(world):
+        z = np.load(tmp_path / f"batch_w{world}_r{r}_k{K16}.npz")
+        for k in ("flat", "sh", "radii", "counts"):
+            assert np.array_equal(one[k], z[k]), (r, k)
