@@ -394,17 +394,21 @@ def extra_configs(dev, flags, budget_s=60.0):
         import gaussianeditor_amd.multiview as mv
 
         res = {}
-        for name, pipe_on in (("pipelined", True), ("serial", False)):
-            mv._VIEW_PIPELINE = pipe_on
-            b8 = GradBucket(1_000_000, 16, dev, sh_exchange="rgb")
-            runs = []
-            for _ in range(3):
-                t8 = timed(lambda: multiview_batch_step(rs8, p1, [G2] * 8, b8), 12, 4)
-                runs.append(8.0 / t8)
-            runs.sort()
-            res[name] = {"view_iters_per_s_median": runs[1], "min": runs[0], "max": runs[2], "ms_per_view": 1e3 / runs[1]}
-            del b8
-        mv._VIEW_PIPELINE = True
+        pipe_default = mv._VIEW_PIPELINE
+        try:
+            for name, pipe_on in (("pipelined", True), ("serial", False)):
+                mv._VIEW_PIPELINE = pipe_on
+                b8 = GradBucket(1_000_000, 16, dev, sh_exchange="rgb")
+                runs = []
+                for _ in range(3):
+                    t8 = timed(lambda: multiview_batch_step(rs8, p1, [G2] * 8, b8), 12, 4)
+                    runs.append(8.0 / t8)
+                runs.sort()
+                res[name] = {"view_iters_per_s_median": runs[1], "min": runs[0], "max": runs[2], "ms_per_view": 1e3 / runs[1]}
+                del b8
+        finally:
+            mv._VIEW_PIPELINE = pipe_default
+        res["pipelined_over_serial"] = res["pipelined"]["view_iters_per_s_median"] / res["serial"]["view_iters_per_s_median"]
         out["views8_one_gpu"] = dict(res, what="the 8 ring views of BASELINE configs[3] as ONE batch on one GPU (bench.py --views 8): "
                                                "forward + backward of every view, touched-rows messages, one accumulate; three "
                                                "repetitions of 12 steps each way")

@@ -1043,6 +1043,9 @@ blend_backward_kernel(const BlendArgs a) {
   __shared__ float sacc[2][9][WAVE];
   __shared__ uint32_t s_item;
   for (int i = threadIdx.x; i < 2 * 9 * WAVE; i += WAVE * BWD_WAVES) (&sacc[0][0][0])[i] = 0.f;
+  // (element i was zeroed by thread i % 256, i.e. by any wave: with the deferred flush the placement-assigned first item
+  // reaches its first ds_add_f32 without passing a workgroup barrier otherwise.  Once per kernel, not per item.)
+  __syncthreads();
   // `bg` once per kernel, in scalar registers
   const float bg0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[0])));
   const float bg1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.bg[1])));

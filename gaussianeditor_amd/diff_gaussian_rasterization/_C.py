@@ -46,14 +46,33 @@ def _require_cuda(t: torch.Tensor, name: str) -> None:
             "(device 'cuda') through the HIP extension -- there is no CPU fallback.")
 
 
-def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
-    """contiguous float32, 16-byte aligned (the kernels use dwordx4 loads on (P,4)/(P,16,3) rows)."""
+def _f32(t: torch.Tensor, name: str, dev: Optional[torch.device] = None) -> torch.Tensor:
+    """contiguous float32, 16-byte aligned (the kernels use dwordx4 loads on (P,4)/(P,16,3) rows), and -- with `dev`, the
+    device of `means3D` -- on that device: the native call takes raw pointers, so a tensor on the host or on another GPU
+    would be a fault inside a kernel instead of an error here (the reference has that hole, rasterize_points.cu:46-48
+    checks `means3D` only).  Empty tensors stand for "feature absent" and carry no pointer: they may live anywhere."""
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"diff_gaussian_rasterization: `{name}` must be a tensor, got {type(t).__name__}")
     if t.dtype != torch.float32:
         raise RuntimeError(f"expected float32 for `{name}`, got {t.dtype}")
+    if dev is not None and t.numel() != 0 and t.device != dev:
+        raise RuntimeError(
+            f"diff_gaussian_rasterization: `{name}` is on {t.device} but `means3D` is on {dev}; every tensor of a call "
+            "must live on the device of `means3D` (the native library receives raw device pointers)")
     t = t.contiguous()
     if t.data_ptr() % 16 != 0:
         t = t.clone(memory_format=torch.contiguous_format)
     return t
+
+
+def _on_device(t: torch.Tensor, name: str, dev: torch.device, dtype: torch.dtype) -> None:
+    """device + dtype check for the non-float arguments (radii, the three saved state buffers, cnt)."""
+    if not isinstance(t, torch.Tensor) or t.dtype != dtype:
+        raise RuntimeError(f"diff_gaussian_rasterization: `{name}` must be a {dtype} tensor")
+    if t.numel() != 0 and t.device != dev:
+        raise RuntimeError(
+            f"diff_gaussian_rasterization: `{name}` is on {t.device} but `means3D` is on {dev}; every tensor of a call "
+            "must live on the device of `means3D` (the native library receives raw device pointers)")
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -109,12 +128,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 torch.zeros((1, H, W), dtype=torch.float32, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev),
                 torch.empty(0, **u8), torch.empty(0, **u8), torch.empty(0, **u8))
     M = int(sh.size(1)) if sh.size(0) != 0 else 0
-    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity")
-    background, viewmatrix, projmatrix, campos = (_f32(background, "bg"), _f32(viewmatrix, "viewmatrix"),
-                                                  _f32(projmatrix, "projmatrix"), _f32(campos, "campos"))
-    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp"), _f32(scales, "scales"),
-                                                    _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
-                                                    _f32(sh, "sh"))
+    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity", dev)
+    background, viewmatrix, projmatrix, campos = (_f32(background, "bg", dev), _f32(viewmatrix, "viewmatrix", dev),
+                                                  _f32(projmatrix, "projmatrix", dev), _f32(campos, "campos", dev))
+    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp", dev), _f32(scales, "scales", dev),
+                                                    _f32(rotations, "rotations", dev),
+                                                    _f32(cov3D_precomp, "cov3D_precomp", dev), _f32(sh, "sh", dev))
     out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
     out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -146,7 +165,9 @@ def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binnin
         raise RuntimeError("aux colors must have dimensions (num_points, 3)")
     if P == 0 or geomBuffer.numel() == 0:
         return out.zero_()
-    colors, background = _f32(colors, "colors"), _f32(background, "bg")
+    colors, background = _f32(colors, "colors"), _f32(background, "bg", dev)
+    for name, buf in (("geomBuffer", geomBuffer), ("binningBuffer", binningBuffer), ("imgBuffer", imgBuffer)):
+        _on_device(buf, name, dev, torch.uint8)
     with torch.cuda.device(dev):
         _native.check("gsr_blend_forward_aux", _native.lib().gsr_blend_forward_aux(
             _stream(dev), P, int(num_rendered), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
@@ -197,12 +218,15 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         return z(0, 3), z(0, NUM_CHANNELS), z(0, 1), z(0, 3), z(0, 6), z(0, M, 3), z(0, 3), z(0, 4)
     _require_cuda(means3D, "means3D")
     means3D = _f32(means3D, "means3D")
-    background, viewmatrix, projmatrix, campos = (_f32(background, "bg"), _f32(viewmatrix, "viewmatrix"),
-                                                  _f32(projmatrix, "projmatrix"), _f32(campos, "campos"))
-    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp"), _f32(scales, "scales"),
-                                                    _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp"),
-                                                    _f32(sh, "sh"))
-    dL_dpix = _f32(dL_dout_color, "dL_dout_color")
+    background, viewmatrix, projmatrix, campos = (_f32(background, "bg", dev), _f32(viewmatrix, "viewmatrix", dev),
+                                                  _f32(projmatrix, "projmatrix", dev), _f32(campos, "campos", dev))
+    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp", dev), _f32(scales, "scales", dev),
+                                                    _f32(rotations, "rotations", dev),
+                                                    _f32(cov3D_precomp, "cov3D_precomp", dev), _f32(sh, "sh", dev))
+    dL_dpix = _f32(dL_dout_color, "dL_dout_color", dev)
+    _on_device(radii, "radii", dev, torch.int32)
+    for name, buf in (("geomBuffer", geomBuffer), ("binningBuffer", binningBuffer), ("imageBuffer", imageBuffer)):
+        _on_device(buf, name, dev, torch.uint8)
     radii = radii.contiguous()
     has_scales = scales.numel() != 0
     # accumulated with atomics -> zero-filled (with as few fill launches as possible: one block, or two when a
@@ -312,7 +336,7 @@ def sh_grad_compose(means3D, campos_all, rgb_all, degree, M):
     out = torch.empty((P, int(M), 3), dtype=torch.float32, device=dev)
     if P == 0:
         return out
-    means3D, campos_all, rgb_all = _f32(means3D, "means3D"), _f32(campos_all, "campos"), _f32(rgb_all, "rgb")
+    means3D, campos_all, rgb_all = _f32(means3D, "means3D"), _f32(campos_all, "campos", dev), _f32(rgb_all, "rgb", dev)
     with torch.cuda.device(dev):
         _native.check("gsr_sh_grad_compose", _native.lib().gsr_sh_grad_compose(
             _stream(dev), P, int(degree), int(M), N, means3D.data_ptr(), campos_all.data_ptr(), rgb_all.data_ptr(),
@@ -406,7 +430,8 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     if P != 0:
         _require_cuda(means3D, "means3D")
         dev = means3D.device
-        means3D, viewmatrix, projmatrix = _f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
+        means3D, viewmatrix, projmatrix = (_f32(means3D, "means3D"), _f32(viewmatrix, "viewmatrix", dev),
+                                           _f32(projmatrix, "projmatrix", dev))
         with torch.cuda.device(dev):
             _native.check("gsr_mark_visible", _native.lib().gsr_mark_visible(
                 _stream(dev), P, means3D.data_ptr(), viewmatrix.data_ptr(), projmatrix.data_ptr(), present.data_ptr()))
@@ -433,10 +458,13 @@ def apply_weights(background, means3D, weights, opacity, scales, rotations, scal
         raise RuntimeError("apply_weights: weights must be float32 and cnt int32")
     if weights.numel() != P * C or cnt.numel() != P:
         raise RuntimeError("apply_weights: weights must hold P*C and cnt P elements")
-    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity")
-    viewmatrix, projmatrix = _f32(viewmatrix, "viewmatrix"), _f32(projmatrix, "projmatrix")
-    scales, rotations, cov3D_precomp = _f32(scales, "scales"), _f32(rotations, "rotations"), _f32(cov3D_precomp, "cov3D_precomp")
-    image_weights = _f32(image_weights, "image_weights")
+    _on_device(weights, "weights", dev, torch.float32)
+    _on_device(cnt, "cnt", dev, torch.int32)
+    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity", dev)
+    viewmatrix, projmatrix = _f32(viewmatrix, "viewmatrix", dev), _f32(projmatrix, "projmatrix", dev)
+    scales, rotations, cov3D_precomp = (_f32(scales, "scales", dev), _f32(rotations, "rotations", dev),
+                                        _f32(cov3D_precomp, "cov3D_precomp", dev))
+    image_weights = _f32(image_weights, "image_weights", dev)
     w_work = weights if weights.is_contiguous() else weights.contiguous()
     c_work = cnt if cnt.is_contiguous() else cnt.contiguous()
     radii = torch.empty((P,), dtype=torch.int32, device=dev)

@@ -47,9 +47,28 @@ __all__ = ["GradBucket", "render_view_grads", "allreduce_view_grads", "multiview
            "densify_synchronized", "replicas_identical"]
 
 import os as _os
+import threading as _threading
 
 #: GSR_VIEW_PIPELINE=0: multiview_batch_step renders its views one after the other on the launch stream (default: two streams)
 _VIEW_PIPELINE = _os.environ.get("GSR_VIEW_PIPELINE", "1") != "0"
+
+#: The helper streams of this module, ONE set per device and process, shared by every GradBucket: torch's caching allocator
+#: keeps a block pool per stream, so streams created per bucket stranded the cached blocks of every bucket that was dropped
+#: (bench.py, the tests and every rebuild after densification make new buckets: `reserved` grew by ~700 MiB per bucket at
+#: 10^6 Gaussians, profiles/r05_zzz_views8_probe.txt).  Keyed by (device index, role); created on first use.
+_DEVICE_STREAMS = {}
+_DEVICE_STREAMS_LOCK = _threading.Lock()
+
+
+def _device_stream(dev, role: str):
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), role)
+    st = _DEVICE_STREAMS.get(key)
+    if st is None:
+        with _DEVICE_STREAMS_LOCK:
+            st = _DEVICE_STREAMS.get(key)
+            if st is None:
+                st = _DEVICE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
 
 #: GSR_DEBUG_PERSISTENT_ROWS=1: every backward into a `persistent_rows` bucket first checks that rows marked "holds zeros" do
 _DEBUG_ROWS = _os.environ.get("GSR_DEBUG_PERSISTENT_ROWS", "0") == "1"
@@ -315,9 +334,7 @@ def _start_counts_exchange(bucket: GradBucket, acc4, group, n: int):
         dist.all_gather(gathered, mine, group=group)
         return plan, torch.cat(gathered), None
     main = torch.cuda.current_stream(dev)
-    if bucket._side_stream is None:
-        bucket._side_stream = torch.cuda.Stream(device=dev)
-    side = bucket._side_stream
+    side = bucket._side_stream = _device_stream(dev, "side")
     ready = torch.cuda.Event()
     ready.record(main)  # K7 is enqueued in front of this
     with torch.cuda.stream(side):
@@ -606,9 +623,7 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
             state.update(plan=plan, count=mine, planned=None, done=None)
             return
         main = torch.cuda.current_stream(dev)
-        if bucket._side_stream is None:
-            bucket._side_stream = torch.cuda.Stream(device=dev)
-        side = bucket._side_stream
+        side = bucket._side_stream = _device_stream(dev, "side")
         ready = torch.cuda.Event()
         ready.record(main)
         with torch.cuda.stream(side):
@@ -649,9 +664,7 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
         if pipeline:
             with shared:
                 main = torch.cuda.current_stream(dev)
-                if bucket._view_streams is None:
-                    bucket._view_streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
-                S = bucket._view_streams
+                S = bucket._view_streams = (_device_stream(dev, "view0"), _device_stream(dev, "view1"))
                 for st_ in S:
                     st_.wait_stream(main)
                 args = (params["xyz"], params["opacity"], params["features"], params["scaling"], params["rotation"])

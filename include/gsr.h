@@ -82,6 +82,10 @@ int gsr_last_hip_error(void);
  * sizes[2] = image (per pixel / tile).  sizes[2] with the real R may be smaller than with R = 0 (the forward's checkpoint
  * pool -- 32 KB per tile, 64 MB at most -- is only needed for views with long lists): a caller that allocates the image
  * scratch after gsr_preprocess saves it, one that sized it with R = 0 beforehand is always large enough.
+ * REUSE: the entry points cannot see how large a scratch buffer is.  An image scratch that is kept and reused for later
+ * views (or for a view rendered under the GSR_CK_CHUNKS knob) MUST have been sized with R = 0: one sized with a short-list
+ * R lacks the pool, and a later view with long lists would have its forward write checkpoints behind the buffer's end.
+ * (The Python binding allocates the image scratch per view, with that view's R.)
  * Replaces required<GeometryState/BinningState/ImageState>() (rasterizer_impl.h:63-72). */
 int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]);
 

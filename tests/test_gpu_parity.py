@@ -388,8 +388,8 @@ def test_alpha_tile_bounds_leave_results_unchanged(oracle, P, W, H, s0, seed):
             st = hip_state(P, R, W, H, geom, binning, img)
             grads = _grads_hip(case, G)
             if mode == "reference":
-                # two more runs under the same rule: the atomics' run-to-run spread (largest of the three pairs)
-                out["again"] = [_grads_hip(case, G), _grads_hip(case, G)]
+                # four more runs under the same rule: the atomics' run-to-run spread (largest of the ten pairs)
+                out["again"] = [_grads_hip(case, G) for _ in range(4)]
             w = torch.zeros(P, 1, device=DEV)
             cnt = torch.zeros(P, 1, dtype=torch.int32, device=DEV)
             mask = (torch.rand(1, H, W, generator=torch.Generator().manual_seed(seed)) > 0.5).float()  # 0/1: exact sums
@@ -408,14 +408,15 @@ def test_alpha_tile_bounds_leave_results_unchanged(oracle, P, W, H, s0, seed):
     assert np.array_equal(a["st"]["final_T"], b["st"]["final_T"])
     assert np.array_equal(b["color"], f["color"]) and np.array_equal(b["radii"], f["radii"])
     for k, v in b["grads"].items():
-        r0, r1, r2 = a["grads"][k], out["again"][0][k], out["again"][1][k]
-        spread = max(rel_err(r1, r0), rel_err(r2, r0), rel_err(r2, r1))
+        runs = [a["grads"][k]] + [g_[k] for g_ in out["again"]]
+        r0 = runs[0]
+        spread = max(rel_err(runs[i], runs[j]) for i in range(len(runs)) for j in range(i))
         print(k, "alpha vs reference", rel_err(v, r0), "reference run to run", spread)
         # (the two rules group different list entries into the backward's 4-entry reductions: a few run-to-run spreads;
         #  this scene's faint, 4x elongated splats have the worst-conditioned sums of the suite -- the scale / rotation
-        #  gradients of the SAME rule differ by 2e-6 .. 2.4e-5 of their maximum from one run to the next (six repetitions,
-        #  gpurun_out/r05h_alpha.txt), so the spread is taken from three runs and the floor is 3e-5)
-        assert rel_err(v, r0) <= max(3e-5, 8.0 * spread), k
+        #  gradients of the SAME rule differ by 2e-6 .. 2.4e-5 of their maximum from one run to the next.  The bar is the
+        #  MEASURED spread, now from five runs (ten pairs) so that a quiet pair cannot understate it; the floor stays 2e-5)
+        assert rel_err(v, r0) <= max(2e-5, 8.0 * spread), k
     # per tile: the alpha rule's list is the reference rule's list with some entries removed, order kept
     ra, rb = a["st"]["ranges"], b["st"]["ranges"]
     la, lb = a["st"]["point_list"], b["st"]["point_list"]
