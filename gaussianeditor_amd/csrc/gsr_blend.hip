@@ -204,6 +204,12 @@ constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 #ifndef GSR_BWD_DIV
 #define GSR_BWD_DIV 2
 #endif
+#ifndef GSR_BWD_HYBRID_EXP
+#define GSR_BWD_HYBRID_EXP 1  // 0: the polynomial exponential in the backward as well (rounds 1-5; A/B builds)
+#endif
+#ifndef GSR_BWD_SLOT_REG
+#define GSR_BWD_SLOT_REG 0
+#endif
 #ifndef GSR_BWD_DEFER_FLUSH
 #define GSR_BWD_DEFER_FLUSH 1  // 0: round 4's loop -- flush at the end of its own chunk, two barriers per chunk (A/B builds)
 #endif
@@ -933,6 +939,44 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
       bool contrib[GROUP];
       float4 cos_[GROUP], cols[GROUP];
       bool any = false;
+#if GSR_BWD_HYBRID_EXP
+      // The exponential of the backward (round 6).  The FORWARD's colours are compared bit for bit, so it evaluates the
+      // exactly specified polynomial (12 instructions); here exp(power) enters two things: the decision `alpha < 1/255`,
+      // which must be the forward's, and G / alpha as factors of gradients that are compared at 1e-5.  So: the hardware's
+      // 2^x (v_exp_f32, 1 ulp; with the rounding of power * log2(e) at most 4e-7 relative for the powers that matter,
+      // |power| < 5.6) gives G and alpha, and ONLY a group in which some lane's o * G lies within 2^-18 relative of 1/255
+      // (about one group in 10^4) is evaluated again with the polynomial, wave-uniformly.  A lane further from the
+      // threshold than the two results can differ takes the forward's decision by construction.
+      float pw_[GROUP];
+      bool near = false;
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) {
+        const float4 g = s1[w][j + u];
+        cos_[u] = s0[w][j + u];
+        cols[u] = s2[w][j + u];
+        dxs[u] = g.x - pfx;
+        dys[u] = g.y - pfy;
+        pw_[u] = blend_power_prescaled(cos_[u].x, cos_[u].y, cos_[u].z, dxs[u], dys[u]);
+        G[u] = __builtin_amdgcn_exp2f(pw_[u] * 0x1.715476p+0f);
+        const float ao = cos_[u].w * G[u];
+        al[u] = fminf(0.99f, ao);
+        near = near || (!FAST && __builtin_fabsf(ao - 1.0f / 255.0f) <= (1.0f / 255.0f) * 0x1p-18f);
+      }
+      if (!FAST && __any(near)) {  // wave-uniform, rare
+        asm volatile("; polynomial exp: a lane within 2^-18 of the alpha threshold");  // (keeps hipcc from flattening the branch into selects)
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+          G[u] = gsr_expf_noclamp(pw_[u]);
+          al[u] = fminf(0.99f, cos_[u].w * G[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) {
+        const uint32_t c = __float_as_uint(s1[w][j + u].w);  // 0-based position of this instance in the tile list
+        contrib[u] = (c < last_contributor) && !(pw_[u] > 0.0f) && !(al[u] < 1.0f / 255.0f);
+        any = any || contrib[u];
+      }
+#else
 #pragma unroll
       for (int u = 0; u < GROUP; ++u) {
         const float4 g = s1[w][j + u];
@@ -947,6 +991,7 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
         contrib[u] = (c < last_contributor) && !(power > 0.0f) && !(al[u] < 1.0f / 255.0f);
         any = any || contrib[u];
       }
+#endif
       if (!__any(any)) continue;  // wave-uniform
       if (ABLATE == 4) continue;  // experiment: footprint + exp only
 
@@ -1011,7 +1056,13 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
 #pragma unroll
       for (int k = 0; k < 9; ++k) asm volatile("" : "+v"(tot[k]));
       if ((lane & 15) == 15) {
+#if GSR_BWD_SLOT_REG  // (A/B) the row's accumulator slot from the colour records already in registers: no LDS round trip in the tail
+        const uint32_t row = (uint32_t)lane >> 4;
+        const float sw = row == 0u ? cols[0].w : row == 1u ? cols[1].w : row == 2u ? cols[2].w : cols[3].w;
+        const uint32_t my_slot = __float_as_uint(sw);
+#else
         const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
+#endif
 #pragma unroll
         for (int k = 0; k < 9; ++k) atomicAdd(&sacc[cb][k][my_slot], tot[k]);
       }

@@ -29,6 +29,10 @@ def main():
             steps = args[i + 1]
             i += 2
             continue
+        if a == "--scene":  # (a bench.py option with a non-numeric value)
+            extra += [a, args[i + 1]]
+            i += 2
+            continue
         if a == "--smoke":
             smoke = True
         elif a.startswith("--"):
