@@ -66,3 +66,19 @@ def get_fast_exp() -> bool:
     from . import options
 
     return bool(options.default_flags() & options.FLAG_FAST_EXP)
+
+
+def set_view_reuse(on: bool) -> None:
+    """View reuse (default on; `GSR_VIEW_REUSE=0` in the environment turns it off): a colour-override render of the view
+    the rasterizer rendered last -- the reference's second `render(..., override_color=...)` of every training view and
+    GUI frame -- runs the blend kernel alone on that render's state, after PROVING that camera, positions, scales,
+    rotations and opacities are the first render's (diff_gaussian_rasterization/_reuse.py).  Off: every render runs in full."""
+    from .diff_gaussian_rasterization import _reuse
+
+    _reuse.set_view_reuse(on)
+
+
+def get_view_reuse() -> bool:
+    from .diff_gaussian_rasterization import _reuse
+
+    return _reuse.view_reuse()

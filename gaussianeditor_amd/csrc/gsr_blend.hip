@@ -205,7 +205,10 @@ constexpr int GROUP = 4;  // survivors processed per inner-loop iteration
 #define GSR_BWD_DIV 2
 #endif
 #ifndef GSR_BWD_HYBRID_EXP
-#define GSR_BWD_HYBRID_EXP 1  // 0: the polynomial exponential in the backward as well (rounds 1-5; A/B builds)
+#define GSR_BWD_HYBRID_EXP 0  // 1 (A/B builds, round 6): hardware 2^x + a rare polynomial fallback next to the alpha threshold -- 34 VALU
+                              // instructions fewer per group and NOT faster: the replay of the group body (tools/microbench/k7_group_replay.py)
+                              // takes 835 cycles per group and SIMD at 4 waves either way (a v_exp_f32 costs a SIMD ~7.6 cycles), K7 219.6 vs
+                              // 216.9-217.4 us same box (profiles/r06_a_k7_limiter.md)
 #endif
 #ifndef GSR_BWD_SLOT_REG
 #define GSR_BWD_SLOT_REG 0
@@ -753,7 +756,7 @@ static_assert(BWD_ITEM_TILE + 1u == (uint32_t)GSR_MAX_TILES, "include/gsr.h stat
 // the CU.  The global float atomics execute at the memory side on this chip and were the largest single
 // cost of the backward (about 200 of 530 us with one atomic per quadrant); a Gaussian typically touches
 // 2-3 of a tile's 4 quadrants.
-template <int ABLATE, bool FAST, bool SEG>  // ABLATE: 0 = product; 1..4 = timing experiments only (wrong results), see launch_blend_backward
+template <int ABLATE, bool FAST, bool SEG>  // ABLATE: 0 = product; 1..6 = timing experiments only (wrong results), see launch_blend_backward
 __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint4 item, const float bg0, const float bg1,
                                               const float bg2, float4 (*s0)[WAVE], float4 (*s1)[WAVE], float4 (*s2)[WAVE],
                                               uint32_t (*sid)[WAVE], float4 (*sco)[WAVE], float (*sacc)[9][WAVE]) {
@@ -835,7 +838,7 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
   // read by exactly one thread, which also puts it back to zero for the buffer's next chunk.
   auto flush = [&](uint32_t fb, uint32_t fsize) __attribute__((always_inline)) {
     const uint32_t p = (uint32_t)lane;
-    constexpr bool emit = ABLATE != 2 && ABLATE != 3;  // (experiments: no global atomics)
+    constexpr bool emit = ABLATE != 2 && ABLATE != 3 && ABLATE != 6;  // (experiments: no global atomics)
     float(*acc)[WAVE] = sacc[fb];
     if (p < fsize) {  // (slots >= fsize are never added to)
       const size_t id = sid[fb][p];
@@ -1067,7 +1070,7 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
         for (int k = 0; k < 9; ++k) atomicAdd(&sacc[cb][k][my_slot], tot[k]);
       }
     }
-    __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc[cb]
+    if (ABLATE != 5 && ABLATE != 6) __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc[cb]
 #if !GSR_BWD_DEFER_FLUSH
     flush(cb, csize);
 #endif
@@ -1551,7 +1554,8 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   hipError_t e = prepare_queue(s, a, blend_grid_size(true, s, sh) / BWD_WAVES);
   if (e != hipSuccess) return e;
   a.units = (int)blend_units(BWD_WAVES, s, sh);
-  // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only
+  // GSR_BWD_ABLATE (debug, timing experiments only): 1 no wave reduction, 2 no atomics, 3 neither, 4 footprint only,
+  // 5 no workgroup barrier per chunk (the quadrant waves drift apart), 6 = 5 without the global atomics
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   bool seg_items = false;  // the work list holds list-segment items (views whose forward left checkpoints)
   ClearArgs clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
@@ -1587,6 +1591,8 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false, false>), g, b, 0, s, a); break;
     case 3: hipLaunchKernelGGL((blend_backward_kernel<3, false, false>), g, b, 0, s, a); break;
     case 4: hipLaunchKernelGGL((blend_backward_kernel<4, false, false>), g, b, 0, s, a); break;
+    case 5: hipLaunchKernelGGL((blend_backward_kernel<5, false, false>), g, b, 0, s, a); break;
+    case 6: hipLaunchKernelGGL((blend_backward_kernel<6, false, false>), g, b, 0, s, a); break;
     default:
       if (seg_items) {
         if (a.fast_exp) hipLaunchKernelGGL((blend_backward_kernel<0, true, true>), g, b, 0, s, a);

@@ -99,6 +99,81 @@ HostSlot* host_slot(hipStream_t stream, hipError_t* err) {
   return h;
 }
 
+// Host side of a device-written answer: poll the slot's generation word until the device has stored `seq` behind its data.
+// The spin is BOUNDED in time: after 5 ms (a long queue of earlier work on the stream, or a failed launch) the thread stops
+// burning a core and blocks in hipStreamSynchronize, which also surfaces any launch error; the word is then either there or
+// the call fails.
+hipError_t wait_for_slot(const HostSlot* slot, uint32_t seq, hipStream_t s) {
+  volatile const uint32_t* flag = slot->words + GEOM_HDR_FINAL;
+  bool seen = false;
+  const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
+  for (uint32_t spin = 1;; ++spin) {
+    if (*flag == seq) {
+      seen = true;
+      break;
+    }
+    __builtin_ia32_pause();
+    if ((spin & 0x3ffu) == 0 && std::chrono::steady_clock::now() >= give_up) break;
+  }
+  if (!seen) {
+    const hipError_t e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (*flag != seq) return hipErrorUnknown;  // the stream is idle and nothing was published
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return hipSuccess;
+}
+
+// gsr_arrays_equal: up to 8 pairs of device arrays compared bit for bit in one launch.  A mismatch is reported straight
+// into the caller thread's pinned slot (word GEOM_HDR_DIFFER: at most one store per wave, none when the arrays agree).
+constexpr int EQ_MAX_PAIRS = 8;
+constexpr int GEOM_HDR_DIFFER = 8;  // host slot only (GEOM_HDR_* of gsr_common.h end at 6)
+struct EqualArgs {
+  const uint32_t* a[EQ_MAX_PAIRS];
+  const uint32_t* b[EQ_MAX_PAIRS];
+  unsigned long long words[EQ_MAX_PAIRS];
+  int n;
+};
+__global__ void __launch_bounds__(256) arrays_equal_kernel(const EqualArgs q, uint32_t* __restrict__ slot) {
+  bool differ = false;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull, t0 = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  for (int i = 0; i < q.n; ++i) {
+    const uint32_t* a = q.a[i];
+    const uint32_t* b = q.b[i];
+    const unsigned long long nw = q.words[i];
+    if (a == b) continue;
+    if ((((uintptr_t)a | (uintptr_t)b) & 15u) == 0) {
+      const uint4* a4 = reinterpret_cast<const uint4*>(a);
+      const uint4* b4 = reinterpret_cast<const uint4*>(b);
+      const unsigned long long nv = nw / 4;
+      unsigned long long v = t0;
+      for (; v + 3 * stride < nv; v += 4 * stride) {  // four independent 16-byte loads per array in flight
+        uint4 x[4], y[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          x[u] = a4[v + (unsigned long long)u * stride];
+          y[u] = b4[v + (unsigned long long)u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) differ = differ || x[u].x != y[u].x || x[u].y != y[u].y || x[u].z != y[u].z || x[u].w != y[u].w;
+      }
+      for (; v < nv; v += stride) {
+        const uint4 x = a4[v], y = b4[v];
+        differ = differ || x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+      }
+      for (unsigned long long w = nv * 4 + t0; w < nw; w += stride) differ = differ || a[w] != b[w];
+    } else {
+      for (unsigned long long w = t0; w < nw; w += stride) differ = differ || a[w] != b[w];
+    }
+  }
+  if (__any(differ) && lane_id() == 0) __hip_atomic_store(slot + GEOM_HDR_DIFFER, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (a launch of its own: in stream order behind every store of the compare kernel)
+__global__ void publish_seq_kernel(uint32_t* __restrict__ slot, uint32_t seq) {
+  __threadfence_system();
+  __hip_atomic_store(slot + GEOM_HDR_FINAL, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Guard against the one misuse of GSR_FLAG_FORWARD_ONLY that nothing on the device can report: a backward on a geometry
 // state whose gsr_preprocess skipped what only the backward reads.  gsr_preprocess notes (geom pointer -> forward-only?) in
 // a small fixed-size table, the backward entry points look their `geom` up and refuse with GSR_ERR_BAD_ARGUMENT instead of
@@ -286,24 +361,7 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED in time: after 5 ms (a long
   // queue of earlier work on the stream, or a failed launch) the thread stops burning a core and blocks in
   // hipStreamSynchronize, which also surfaces any launch error; the word is then either there or the call fails.
-  {
-    volatile const uint32_t* flag = slot->words + GEOM_HDR_FINAL;
-    bool seen = false;
-    const auto give_up = std::chrono::steady_clock::now() + std::chrono::milliseconds(5);
-    for (uint32_t spin = 1;; ++spin) {
-      if (*flag == seq) {
-        seen = true;
-        break;
-      }
-      __builtin_ia32_pause();
-      if ((spin & 0x3ffu) == 0 && std::chrono::steady_clock::now() >= give_up) break;
-    }
-    if (!seen) {
-      GSR_HIP(hipStreamSynchronize(s));
-      if (*flag != seq) return hip_fail(hipErrorUnknown);  // the stream is idle and nothing was published
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  }
+  GSR_HIP(wait_for_slot(slot, seq, s));
   const uint32_t* w = slot->words;
   const uint64_t total = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
   const uint32_t kmax = w[GEOM_HDR_KEYMAX], kinv = w[GEOM_HDR_KEYINVMAX];
@@ -325,6 +383,39 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
   counts_host[0] = (int64_t)total;
   counts_host[1] = legacy ? 0 : (int64_t)((uint64_t)w[GEOM_HDR_GROUPS] | ((uint64_t)w[GEOM_HDR_GROUPS + 1] << 32));
+  return GSR_OK;
+}
+
+int gsr_arrays_equal(void* stream, int n, const void* const* a, const void* const* b, const size_t* bytes, int* equal_host) {
+  if (equal_host == nullptr || n < 0 || n > EQ_MAX_PAIRS || (n > 0 && (!a || !b || !bytes))) return GSR_ERR_BAD_ARGUMENT;
+  *equal_host = 1;
+  EqualArgs q;
+  memset(&q, 0, sizeof(q));
+  unsigned long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (bytes[i] == 0 || a[i] == b[i]) continue;
+    if (!a[i] || !b[i] || (bytes[i] & 3u) || (((uintptr_t)a[i] | (uintptr_t)b[i]) & 3u)) return GSR_ERR_BAD_ARGUMENT;
+    q.a[q.n] = (const uint32_t*)a[i];
+    q.b[q.n] = (const uint32_t*)b[i];
+    q.words[q.n] = bytes[i] / 4;
+    total += q.words[q.n];
+    q.n++;
+  }
+  if (q.n == 0) return GSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t slot_err = hipSuccess;
+  HostSlot* slot = host_slot(s, &slot_err);
+  if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT : hip_fail(slot_err);
+  const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;
+  slot->words[GEOM_HDR_DIFFER] = 0;  // (pinned host memory: in place before the launch below is submitted)
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  const unsigned long long per_block = 256ull * 16ull;  // words: four 16-byte vectors per thread
+  const unsigned blocks = (unsigned)(total / per_block < 1 ? 1 : (total / per_block > 2048 ? 2048 : total / per_block));
+  hipLaunchKernelGGL(arrays_equal_kernel, dim3(blocks), dim3(256), 0, s, q, slot->dev_words);
+  hipLaunchKernelGGL(publish_seq_kernel, dim3(1), dim3(1), 0, s, slot->dev_words, seq);
+  GSR_HIP(hipGetLastError());
+  GSR_HIP(wait_for_slot(slot, seq, s));
+  *equal_host = slot->words[GEOM_HDR_DIFFER] == 0 ? 1 : 0;
   return GSR_OK;
 }
 

@@ -484,3 +484,28 @@ def apply_weights(background, means3D, weights, opacity, scales, rotations, scal
     if c_work is not cnt:
         cnt.copy_(c_work)
     return None
+
+
+def arrays_equal(pairs) -> bool:
+    """Extension (include/gsr.h: gsr_arrays_equal): are the (a, b) tensor pairs -- contiguous, same shape and dtype, on one
+    ROCm device, at most 8 -- identical bit for bit?  One compare launch; blocks until the device has answered (~10 us)."""
+    pairs = [(a, b) for a, b in pairs if a.numel() != 0 or b.numel() != 0]
+    if not pairs:
+        return True
+    if len(pairs) > 8:
+        raise RuntimeError("arrays_equal: at most 8 pairs")
+    dev = pairs[0][0].device
+    for a, b in pairs:
+        _require_cuda(a, "arrays_equal argument")
+        if a.shape != b.shape or a.dtype != b.dtype or a.device != dev or b.device != dev:
+            return False
+        if not (a.is_contiguous() and b.is_contiguous()) or (a.numel() * a.element_size()) % 4 != 0:
+            raise RuntimeError("arrays_equal: tensors must be contiguous and a multiple of 4 bytes long")
+    n = len(pairs)
+    A = (ctypes.c_void_p * n)(*[a.data_ptr() for a, _ in pairs])
+    B = (ctypes.c_void_p * n)(*[b.data_ptr() for _, b in pairs])
+    S = (ctypes.c_size_t * n)(*[a.numel() * a.element_size() for a, _ in pairs])
+    eq = ctypes.c_int(0)
+    with torch.cuda.device(dev):
+        _native.check("gsr_arrays_equal", _native.lib().gsr_arrays_equal(_stream(dev), n, A, B, S, ctypes.byref(eq)))
+    return bool(eq.value)

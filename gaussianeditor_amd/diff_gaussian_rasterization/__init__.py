@@ -19,7 +19,7 @@ from typing import NamedTuple
 import torch
 import torch.nn as nn
 
-from . import _C
+from . import _C, _reuse
 from .. import options as _options
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_RasterizeGaussians"]
@@ -80,6 +80,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.gsr_flags = flags
         ctx.num_rendered = num_rendered
+        # view reuse (_reuse.py): a following colour-override render of this view runs the blend kernel on this state
+        _reuse.remember(rs, flags, means3D, scales, rotations, opacities, cov3Ds_precomp, num_rendered, geomBuffer,
+                        binningBuffer, imgBuffer, radii, depth)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -119,8 +122,56 @@ class _RasterizeGaussians(torch.autograd.Function):
                 grad_cov3Ds_precomp, None, None)
 
 
+class _ReusedRender(torch.autograd.Function):
+    """A colour-override render served from the state of the preceding full render of the same view (_reuse.py): the
+    blend kernel alone.  Same outputs as `_RasterizeGaussians`; differentiable like it -- a backward through this image
+    (nobody in GaussianEditor asks for one) first runs the full forward that was skipped, then the ordinary backward."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings,
+                entry):
+        rs = raster_settings
+        flags = _options.current_flags()
+        color = _call_native(lambda *a: _C.rasterize_gaussians_aux(*a, flags=flags),
+                             (rs.bg, colors_precomp.detach(), entry.R, entry.geom, entry.binning, entry.img, rs.image_height,
+                              rs.image_width, rs.debug), rs.debug, "snapshot_fw.dump",
+                             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+        radii, depth = entry.radii.clone(), entry.depth.clone()
+        ctx.raster_settings = rs
+        ctx.gsr_flags = flags
+        ctx.save_for_backward(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs, flags = ctx.raster_settings, ctx.gsr_flags
+        means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        fwd = _C.rasterize_gaussians(rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier,
+                                     cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                     rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, flags=flags)
+        num_rendered, _, _, radii, geomBuffer, binningBuffer, imgBuffer = fwd
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = _C.rasterize_gaussians_backward(
+             rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix,
+             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh, rs.sh_degree, rs.campos, geomBuffer, num_rendered,
+             binningBuffer, imgBuffer, rs.debug, flags=flags)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None, None)
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    if colors_precomp.numel() != 0 and sh.numel() == 0 and means3D.is_cuda:
+        # a colour-override render: is it the view the rasterizer rendered last (the reference's second render() of every
+        # training view / GUI frame)?  Then the blend kernel alone, on that render's state (_reuse.py)
+        entry = _reuse.lookup(raster_settings, _options.current_flags(), means3D, scales, rotations, opacities, cov3Ds_precomp)
+        if entry is not None:
+            return _ReusedRender.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                       raster_settings, entry)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

@@ -56,7 +56,8 @@ extern "C" {
 /* 4 (round 5): adds gsr_near_workspace_size / gsr_near_points (round 4 had left the number at 3), the scratch layouts
  * changed again (sizes come from gsr_scratch_sizes: rebuild nothing, re-query), images of more than GSR_MAX_TILES tiles
  * are refused by the backward entry points instead of being walked wrongly. */
-#define GSR_ABI_VERSION 4
+/* 5 (round 6): adds gsr_arrays_equal. */
+#define GSR_ABI_VERSION 5
 /* Largest image the blend BACKWARD accepts, in 16 x 16 tiles (its work items carry the tile id in 20 bits). */
 #define GSR_MAX_TILES (1 << 20)
 
@@ -158,6 +159,17 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                    int prefiltered, int skip_color, unsigned flags, int32_t* radii, void* geom,
                    int64_t counts_host[2]);
+
+/* Are n <= 8 pairs of device arrays identical bit for bit?  a[i] / b[i]: device pointers (4-byte aligned; a pair with
+ * a[i] == b[i] or bytes[i] == 0 is equal without being read), bytes[i]: their size, a multiple of 4.  One compare launch
+ * over all pairs (16-byte loads where both sides are 16-byte aligned) plus a one-thread launch that publishes the answer
+ * into the calling thread's pinned slot; like gsr_preprocess the call BLOCKS until the answer is there (it polls; ~10 us
+ * + 64 MB per 12 us).  *equal_host = 1 (all pairs equal) or 0.
+ * No reference counterpart: the Python layer uses it to PROVE that a second render() of a view -- the reference renders
+ * every training view and GUI frame twice, with override_color the second time (threestudio/systems/GassuianEditor.py:
+ * 166-191, webui.py:693-713) -- got the opacities / scales / rotations of the first (fresh activation tensors each time),
+ * before it reuses the first render's preprocessing, sort and tile lists ("view reuse"). */
+int gsr_arrays_equal(void* stream, int n, const void* const* a, const void* const* b, const size_t* bytes, int* equal_host);
 
 /* K3 + K4 + K5: the per-tile instance lists (the reference's point_list) and their [begin,end) ranges, in exactly the
  * order of the reference's stable sort on the low gsr_sort_key_bits() bits of (tile << 32 | depth bits): the Gaussians

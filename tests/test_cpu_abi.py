@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_typed():
     # the Python binding types every declared symbol, and nothing that is not declared
     assert sorted(_native.SIGNATURES) == syms
     L = _native.lib()
-    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 4
+    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 5
     # ... and the library exports NOTHING else: no C++ internals, kernel handles or toolchain objects (-fvisibility=hidden
     # + csrc/gsr.map).  Read from the dynamic symbol table with nm.
     import shutil

@@ -1,0 +1,259 @@
+"""-m gpu, round 6: view reuse (the second render() of a view runs the blend kernel alone -- VERDICT r05 next 3), the
+compare primitive behind it (gsr_arrays_equal), and the device checks of every tensor argument of the binding (next 7)."""
+import math
+
+import pytest
+import torch
+
+from helpers import make_case, settings
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _PC:
+    """The part of the reference's GaussianModel that render() reads (scene/gaussian_model.py:222-258): parameters
+    behind activations, so get_opacity / get_scaling / get_rotation are FRESH tensors on every call."""
+
+    def __init__(self, sc, dev):
+        self._xyz = torch.nn.Parameter(sc["xyz"].to(dev))
+        self._opacity = torch.nn.Parameter(torch.logit(sc["opacity"].clamp(1e-4, 1 - 1e-4)).to(dev))
+        self._scaling = torch.nn.Parameter(torch.log(sc["scaling"]).to(dev))
+        self._rotation = torch.nn.Parameter(sc["rotation"].to(dev))
+        self._features = torch.nn.Parameter(sc["features"].to(dev))
+        self.active_sh_degree = self.max_sh_degree = 3
+
+    get_xyz = property(lambda s: s._xyz)
+    get_opacity = property(lambda s: torch.sigmoid(s._opacity))
+    get_scaling = property(lambda s: torch.exp(s._scaling))
+    get_rotation = property(lambda s: torch.nn.functional.normalize(s._rotation))
+    get_features = property(lambda s: s._features)
+
+
+class _Pipe:
+    compute_cov3D_python = False
+    convert_SHs_python = False
+
+
+def _two_renders(pc, cam, bg, mask):
+    """threestudio/systems/GassuianEditor.py:166-191, unmodified call pattern."""
+    from gaussianeditor_amd.gaussian_renderer import render
+
+    a = render(cam, pc, _Pipe, bg)
+    b = render(cam, pc, _Pipe, bg, override_color=mask)
+    return a, b
+
+
+@pytest.fixture
+def reuse():
+    import gaussianeditor_amd
+    from gaussianeditor_amd.diff_gaussian_rasterization import _reuse
+
+    was = gaussianeditor_amd.get_view_reuse()
+    gaussianeditor_amd.set_view_reuse(True)
+    _reuse.forget()
+    for k in _reuse.stats:
+        _reuse.stats[k] = 0
+    yield _reuse
+    _reuse.forget()
+    gaussianeditor_amd.set_view_reuse(was)
+
+
+@pytest.mark.parametrize("P,W,H,s0", [(20000, 512, 512, 0.03), (3000, 250, 131, 0.08)])
+def test_second_render_of_a_view_is_served_by_the_blend_kernel_alone(reuse, P, W, H, s0):
+    """The reference's double render through the unmodified render(): with view reuse the second image, its radii and its
+    depth are bit-identical to two full renders; the first image is untouched; gradients of the first render too."""
+    import gaussianeditor_amd
+
+    case = make_case(P, W, H, seed=5, s0=s0)
+    cam, bg = case["cam"], case["bg"].to(DEV)
+    for a in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, a, getattr(cam, a).to(DEV))
+    pc = _PC(case["sc"], DEV)
+    mask = (torch.rand(P, 1, generator=torch.Generator().manual_seed(1)) > 0.6).float().repeat(1, 3).to(DEV)
+    G = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(DEV)
+
+    def run():
+        for p in (pc._xyz, pc._opacity, pc._scaling, pc._rotation, pc._features):
+            p.grad = None
+        a, b = _two_renders(pc, cam, bg, mask)
+        (a["render"] * G).sum().backward()
+        torch.cuda.synchronize()
+        return a, b, [p.grad.clone() for p in (pc._xyz, pc._opacity, pc._scaling, pc._rotation, pc._features)]
+
+    a1, b1, g1 = run()
+    assert reuse.stats["hits"] == 1 and reuse.stats["compares"] == 1  # opacity / scaling / rotation: fresh tensors, compared
+    gaussianeditor_amd.set_view_reuse(False)
+    a0, b0, g0 = run()
+    assert reuse.stats["hits"] == 1
+    for k in ("render", "radii", "depth_3dgs"):
+        assert torch.equal(a1[k], a0[k]), k
+        assert torch.equal(b1[k], b0[k]), k
+    assert torch.equal(b1["visibility_filter"], b0["visibility_filter"])
+    for x, y in zip(g1, g0):  # (the backward's float atomics: run-to-run rounding only)
+        assert torch.allclose(x, y, rtol=0, atol=2e-5 * float(y.abs().max()))
+
+
+def test_view_reuse_misses_when_anything_changed(reuse):
+    """An in-place parameter update (optimizer step), another camera, another image size, another scale modifier or a
+    densified model between the two calls: the second render runs in full and equals a render without reuse."""
+    import gaussianeditor_amd
+    from gaussianeditor_amd.gaussian_renderer import render
+
+    P, W, H = 8000, 256, 192
+    case = make_case(P, W, H, seed=7, s0=0.05)
+    cam, bg = case["cam"], case["bg"].to(DEV)
+    cam2 = make_case(P, W, H, seed=7, s0=0.05, view=2)["cam"]
+    for c in (cam, cam2):
+        for a in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(c, a, getattr(c, a).to(DEV))
+    pc = _PC(case["sc"], DEV)
+    mask = torch.rand(P, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def full(cam_, **kw):
+        gaussianeditor_amd.set_view_reuse(False)
+        try:
+            return render(cam_, pc, _Pipe, bg, override_color=mask, **kw)["render"].detach().clone()
+        finally:
+            gaussianeditor_amd.set_view_reuse(True)
+
+    # 1. in-place update of a parameter between the renders (what optimizer.step() does)
+    render(cam, pc, _Pipe, bg)
+    with torch.no_grad():
+        pc._opacity.add_(0.25)
+    h = reuse.stats["hits"]
+    out = render(cam, pc, _Pipe, bg, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h and torch.equal(out, full(cam))
+    # 2. ... of the positions (the SAME tensor object on both calls: only its version counter tells)
+    render(cam, pc, _Pipe, bg)
+    with torch.no_grad():
+        pc._xyz.mul_(1.01)
+    out = render(cam, pc, _Pipe, bg, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h and torch.equal(out, full(cam))
+    # 3. another camera; 4. another scale modifier
+    render(cam, pc, _Pipe, bg)
+    out = render(cam2, pc, _Pipe, bg, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h and torch.equal(out, full(cam2))
+    render(cam, pc, _Pipe, bg)
+    out = render(cam, pc, _Pipe, bg, scaling_modifier=0.5, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h and torch.equal(out, full(cam, scaling_modifier=0.5))
+    # 5. the same values in a camera built anew (other tensor objects): compared by content -> hit
+    import copy
+
+    cam3 = copy.copy(cam)
+    cam3.world_view_transform = cam.world_view_transform.clone()
+    cam3.full_proj_transform = cam.full_proj_transform.clone()
+    render(cam, pc, _Pipe, bg)
+    out = render(cam3, pc, _Pipe, bg, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h + 1 and torch.equal(out, full(cam))
+    # 6. under no_grad (the web UI's frames, webui.py:693-713): activations are fresh leaves -- compared, hit
+    with torch.no_grad():
+        render(cam, pc, _Pipe, bg)
+        out = render(cam, pc, _Pipe, bg, override_color=mask)["render"]
+    assert reuse.stats["hits"] == h + 2 and torch.equal(out, full(cam))
+
+
+def test_backward_through_a_reused_render_runs_the_skipped_forward(reuse):
+    """Nobody in GaussianEditor differentiates through the semantic image -- but a caller may: the gradients of a served
+    render equal those of a full colour-override render (run-to-run rounding of the float atomics)."""
+    import gaussianeditor_amd
+    from gaussianeditor_amd.gaussian_renderer import render
+
+    P, W, H = 6000, 160, 128
+    case = make_case(P, W, H, seed=9, s0=0.06)
+    cam, bg = case["cam"], case["bg"].to(DEV)
+    for a in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, a, getattr(cam, a).to(DEV))
+    pc = _PC(case["sc"], DEV)
+    col = torch.rand(P, 3, generator=torch.Generator().manual_seed(4)).to(DEV).requires_grad_(True)
+    G = torch.rand(3, H, W, generator=torch.Generator().manual_seed(5)).to(DEV)
+    params = (pc._xyz, pc._opacity, pc._scaling, pc._rotation, col)
+
+    def grads(on):
+        gaussianeditor_amd.set_view_reuse(on)
+        for p in params:
+            p.grad = None
+        render(cam, pc, _Pipe, bg)
+        out = render(cam, pc, _Pipe, bg, override_color=col)
+        (out["render"] * G).sum().backward()
+        return [p.grad.clone() for p in params] + [out["viewspace_points"].grad.clone()]
+
+    h = reuse.stats["hits"]
+    g1 = grads(True)
+    assert reuse.stats["hits"] == h + 1
+    g0 = grads(False)
+    for x, y in zip(g1, g0):
+        assert float(y.abs().max()) > 0 and torch.allclose(x, y, rtol=0, atol=2e-5 * float(y.abs().max()))
+
+
+def test_arrays_equal():
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 3, 4, 1000, 4099, 3_000_001):
+        a = torch.rand(n, generator=g).to(DEV)
+        b = a.clone()
+        assert _C.arrays_equal([(a, b)])
+        b[-1] += 1.0
+        assert not _C.arrays_equal([(a, b)])
+        b = a.clone()
+        b[n // 2] = float("nan")
+        assert not _C.arrays_equal([(a, b)])
+    # several pairs, one of them unaligned to 16 bytes; NaN equals NaN bit for bit; identical pointers are not read
+    base = torch.rand(70001, generator=g).to(DEV)
+    base[5] = float("nan")
+    u, v = base[1:], base[1:].clone()
+    w = torch.randint(0, 1 << 30, (977, 3), generator=g, dtype=torch.int32).to(DEV)
+    assert _C.arrays_equal([(u, v), (w, w.clone()), (base, base)])
+    v[-3] = 0.0
+    assert not _C.arrays_equal([(w, w.clone()), (u, v)])
+    assert _C.arrays_equal([])
+    assert not _C.arrays_equal([(base[:10], base[:11])])  # shapes differ: unequal without a launch
+
+
+def test_every_tensor_argument_is_device_checked():
+    """rasterize_points.cu:46-48 checks `means3D` only; a `bg` or a matrix left on the host would hand a foreign pointer
+    to a kernel.  Here every argument is checked against the device of `means3D`, by name."""
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+    case = make_case(500, 64, 64, seed=1)
+    sc, rs = case["sc"], settings(case, DEV)
+    x, o, f = sc["xyz"].to(DEV), sc["opacity"].to(DEV), sc["features"].to(DEV)
+    s, r = sc["scaling"].to(DEV), sc["rotation"].to(DEV)
+
+    def call(rs_=rs, **kw):
+        a = dict(means3D=x, means2D=torch.zeros_like(x), opacities=o, shs=f, scales=s, rotations=r)
+        a.update(kw)
+        return GaussianRasterizer(rs_)(**a)
+
+    call()
+    for field, name in (("bg", "bg"), ("viewmatrix", "viewmatrix"), ("projmatrix", "projmatrix"), ("campos", "campos")):
+        bad = rs._replace(**{field: getattr(rs, field).cpu()})
+        with pytest.raises(RuntimeError, match=f"`{name}` is on cpu"):
+            call(bad)
+    for kw, name in ((dict(opacities=o.cpu()), "opacity"), (dict(shs=f.cpu()), "sh"), (dict(scales=s.cpu()), "scales"),
+                     (dict(rotations=r.cpu()), "rotations")):
+        with pytest.raises(RuntimeError, match=f"`{name}` is on cpu"):
+            call(**kw)
+    with pytest.raises(RuntimeError, match="expected float32 for `opacity`"):
+        call(opacities=o.double())
+    # backward: a gradient image on the host
+    xg = x.clone().requires_grad_(True)
+    color, _, _ = GaussianRasterizer(rs)(means3D=xg, means2D=torch.zeros_like(x), opacities=o, shs=f, scales=s, rotations=r)
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+    node = color.grad_fn
+    with pytest.raises(RuntimeError, match="`dL_dout_color` is on cpu"):
+        _C.rasterize_gaussians_backward(rs.bg, x, torch.zeros(500, dtype=torch.int32, device=DEV), torch.empty(0, device=DEV), s, r,
+                                        1.0, torch.empty(0, device=DEV), rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                                        torch.zeros(3, 64, 64), f, 3, rs.campos, node.saved_tensors[7], node.num_rendered,
+                                        node.saved_tensors[8], node.saved_tensors[9], False)
+    # apply_weights: the mask image and the counters
+    w = torch.zeros(500, 1, device=DEV)
+    cnt = torch.zeros(500, 1, dtype=torch.int32, device=DEV)
+    with pytest.raises(RuntimeError, match="`image_weights` is on cpu"):
+        GaussianRasterizer(rs).apply_weights(x, None, o, None, w, s, r, None, cnt, torch.ones(1, 64, 64))
+    with pytest.raises(RuntimeError, match="`cnt` is on cpu"):
+        GaussianRasterizer(rs).apply_weights(x, None, o, None, w, s, r, None, cnt.cpu(), torch.ones(1, 64, 64, device=DEV))
+    if torch.cuda.device_count() > 1:  # a cross-device argument (only where two GPUs are visible)
+        with pytest.raises(RuntimeError, match="`sh` is on cuda:1"):
+            call(shs=f.to("cuda:1"))
