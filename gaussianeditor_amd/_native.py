@@ -17,6 +17,8 @@ LIB_PATH = os.environ.get("GSR_LIBRARY_PATH") or os.path.join(_HERE, "libgsr_hip
 GSR_ABI_VERSION = 5
 
 _P = c_void_p
+#: floats per row of the blend backward's accumulator table and its columns (include/gsr.h: GSR_ACC_*)
+ACC_ROW, ACC_MEAN2D, ACC_OPACITY, ACC_CONIC, ACC_COLOR = 16, 0, 3, 4, 8
 
 
 class AdamTensor(ctypes.Structure):
@@ -55,17 +57,21 @@ SIGNATURES = {
     "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
                              _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
-    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
+    # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags)
+    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
+    # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots)
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
-                                        c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                        c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_drgb, dL_dscales, dL_drots)
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                             c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_drgb, dL_dscales, dL_drots, row_state)
     "gsr_preprocess_backward_rows": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
-                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_view_message_words": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
     "gsr_view_message_plan": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, POINTER(c_int64)]),
-    "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P, _P, _P, _P, _P]),
+    "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P, _P]),
     "gsr_view_message_pack": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, _P, c_int64, _P]),
     "gsr_view_messages_accumulate": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads)]),
     "gsr_view_messages_accumulate_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads), _P]),
@@ -86,7 +92,7 @@ SIGNATURES = {
     "gsr_debug_export_geom": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_debug_cov3d": (c_int, [_P, c_int, _P, c_float, _P, _P]),
     "gsr_debug_export_binning": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P]),
-    "gsr_debug_blend_backward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+    "gsr_debug_blend_backward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                                  c_int64, POINTER(c_int64)]),
     "gsr_debug_blend_forward_profile": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_int64,
                                                 POINTER(c_int64)]),

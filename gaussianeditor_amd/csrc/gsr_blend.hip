@@ -738,6 +738,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 }
 
 constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile (or two quadrants of a heavy one)
+constexpr int ACC_LDS_ROW = 9;  // floats per chunk slot of the backward's LDS accumulators: the nine raw moments
 constexpr uint32_t BWD_ITEM_HALF = 0x80000000u;   // item code: the workgroup handles one half of the tile ...
 constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead of {0,1}
 // ... or (round 4) ONE LIST SEGMENT of a deep tile: positions [seg * stride, (seg + 1) * stride) of its list, the last
@@ -759,7 +760,7 @@ static_assert(BWD_ITEM_TILE + 1u == (uint32_t)GSR_MAX_TILES, "include/gsr.h stat
 template <int ABLATE, bool FAST, bool SEG>  // ABLATE: 0 = product; 1..6 = timing experiments only (wrong results), see launch_blend_backward
 __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint4 item, const float bg0, const float bg1,
                                               const float bg2, float4 (*s0)[WAVE], float4 (*s1)[WAVE], float4 (*s2)[WAVE],
-                                              uint32_t (*sid)[WAVE], float4 (*sco)[WAVE], float (*sacc)[9][WAVE]) {
+                                              uint32_t (*sid)[WAVE], float4 (*sco)[WAVE], float (*sacc)[WAVE][ACC_LDS_ROW]) {
   const int w = (int)(threadIdx.x >> 6), lane = lane_id();
   // The item's descriptor (assembled by the caller from three scalar loads): x = code -- a whole tile, wave w = quadrant w; or
   // half a tile, waves (0,1) and (2,3) = the upper / lower 8x4 pixels of its two quadrants; or one list segment --, y = first
@@ -832,58 +833,48 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
     B_acc = (b0 * dpx[0] + b1 * dpx[1] + b2 * dpx[2]) / T;
   }
 
-  // Flush of one chunk's accumulators: thread (w, lane) owns chunk slot `lane`; wave 0 forms dL_dmean2D from moments 1, 2
-  // and the conic, wave 1 dL_dconic from moments 3-5, wave 2 dL_dopacity + the first colour channel, wave 3 the other two.
-  // One global atomic per (tile, instance, term); slots no pixel of the tile touched are skipped.  Every (term, slot) is
-  // read by exactly one thread, which also puts it back to zero for the buffer's next chunk.
+  // Flush of one chunk's accumulators (round 6: ONE memory-side request per (tile, instance) instead of up to nine).
+  // Device-scope float atomics execute at the memory side on this chip, and what they cost is the REQUEST: a wave instruction's
+  // lanes that hit the same 64-byte line travel as one (tools/microbench/atomic_merge.hip: 9 values into each of 4 M random
+  // rows -- 1 819 us from four arrays, 37.7 M requests; 206 us into 64-byte rows, 4.2 M requests).  With the nine accumulators
+  // of a Gaussian in four arrays every atomic was a request of its own: 47 of K7's 215 us on the headline view, 200 of
+  // 757 us on synth-v2 (GSR_BWD_ABLATE=2).  Now a Gaussian's accumulators are ONE 64-byte row of `acc` (ACC_* columns,
+  // include/gsr.h), and the flush puts the sixteen columns of a row on sixteen adjacent lanes: instruction j of wave w
+  // covers the chunk slots 16 w + 4 j .. + 3.  Lane (slot, column) forms its column's term from the slot's raw moments and
+  // the entry's conic / opacity (sco) -- backward.cu:545-554 --, skips what is exactly zero, and the lanes of the raw
+  // moments' indices put the LDS accumulator back to zero for the buffer's next chunk.
   auto flush = [&](uint32_t fb, uint32_t fsize) __attribute__((always_inline)) {
-    const uint32_t p = (uint32_t)lane;
     constexpr bool emit = ABLATE != 2 && ABLATE != 3 && ABLATE != 6;  // (experiments: no global atomics)
-    float(*acc)[WAVE] = sacc[fb];
-    if (p < fsize) {  // (slots >= fsize are never added to)
-      const size_t id = sid[fb][p];
-      if (w == 0) {
-        const float t1 = acc[1][p], t2 = acc[2][p];
-        if (t1 != 0.f || t2 != 0.f) {
-          acc[1][p] = 0.f;
-          acc[2][p] = 0.f;
-          const float4 co = sco[fb][p];  // conic.x, conic.y, conic.z, opacity
-          // backward.cu:545-546: dL_dmean2D = -o (A t1 + B t2, B t1 + C t2) * (0.5 W, 0.5 H)
-          if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id], -(ddelx_dx * co.w) * (co.x * t1 + co.y * t2));
-          if (emit) unsafeAtomicAdd(&a.dL_dmean2D[3 * id + 1], -(ddely_dy * co.w) * (co.y * t1 + co.z * t2));
-        }
-      } else if (w == 1) {
-        const float t3 = acc[3][p], t4 = acc[4][p], t5 = acc[5][p];
-        if (t3 != 0.f || t4 != 0.f || t5 != 0.f) {
-          acc[3][p] = 0.f;
-          acc[4][p] = 0.f;
-          acc[5][p] = 0.f;
-          const float h = -0.5f * sco[fb][p].w;
-          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id], h * t3);      // backward.cu:549
-          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 1], h * t4);  // backward.cu:550
-          if (emit) unsafeAtomicAdd(&a.dL_dconic[4 * id + 3], h * t5);  // backward.cu:551
-        }
-      } else if (w == 2) {
-        const float t0 = acc[0][p], t6 = acc[6][p];
-        if (t0 != 0.f) {
-          acc[0][p] = 0.f;
-          if (emit) unsafeAtomicAdd(&a.dL_dopacity[id], t0);  // backward.cu:554
-        }
-        if (t6 != 0.f) {
-          acc[6][p] = 0.f;
-          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id], t6);  // backward.cu:523
-        }
+    const uint32_t col = (uint32_t)lane & 15u, sub = (uint32_t)lane >> 4;
+    // raw moments a column reads: dL_dmean2D needs (1, 2); conic x / y / w: 3 / 4 / 5; opacity: 0; colour: 6 / 7 / 8
+    const uint32_t ia = col == ACC_MEAN2D || col == ACC_MEAN2D + 1u ? 1u
+                        : col == ACC_OPACITY ? 0u
+                        : col == ACC_CONIC ? 3u : col == ACC_CONIC + 1u ? 4u : col == ACC_CONIC + 3u ? 5u
+                        : col >= ACC_COLOR && col < ACC_COLOR + 3u ? 6u + (col - ACC_COLOR) : 9u;  // 9: the column is not used
+#pragma unroll
+    for (uint32_t jj = 0; jj < 4u; ++jj) {
+      const uint32_t p = 16u * (uint32_t)w + 4u * jj + sub;
+      if (16u * (uint32_t)w + 4u * jj >= fsize) break;  // (wave-uniform: slots >= fsize are never added to)
+      float* const row = sacc[fb][p];
+      const bool used = p < fsize && ia < 9u;
+      const float ma = used ? row[ia] : 0.f;
+      const float mb = used && ia == 1u ? row[2] : 0.f;
+      const float4 co = sco[fb][p];  // conic.x, conic.y, conic.z, opacity
+      float val;
+      bool nz;
+      if (ia == 1u) {
+        // backward.cu:545-546: dL_dmean2D = -o (A t1 + B t2, B t1 + C t2) * (0.5 W, 0.5 H)
+        const bool xcol = col == ACC_MEAN2D;
+        const float scale = xcol ? ddelx_dx : ddely_dy, c1 = xcol ? co.x : co.y, c2 = xcol ? co.y : co.z;
+        val = -(scale * co.w) * (c1 * ma + c2 * mb);
+        nz = ma != 0.f || mb != 0.f;
       } else {
-        const float t7 = acc[7][p], t8 = acc[8][p];
-        if (t7 != 0.f) {
-          acc[7][p] = 0.f;
-          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 1], t7);
-        }
-        if (t8 != 0.f) {
-          acc[8][p] = 0.f;
-          if (emit) unsafeAtomicAdd(&a.dL_dcolors[3 * id + 2], t8);
-        }
+        const bool conic = ia >= 3u && ia <= 5u;  // backward.cu:549-551: -0.5 o t; opacity (:554) and colour (:523): the moment itself
+        val = conic ? (-0.5f * co.w) * ma : ma;
+        nz = ma != 0.f;
       }
+      if (used && nz && emit) unsafeAtomicAdd(&a.acc[(size_t)sid[fb][p] * ACC_ROW + col], val);
+      if (p < fsize && col < 9u) row[col] = 0.f;  // (every read of this instruction precedes it: one wave, program order)
     }
   };
 
@@ -1067,7 +1058,7 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
         const uint32_t my_slot = __float_as_uint(s2[w][j + (uint32_t)(lane >> 4)].w);
 #endif
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[cb][k][my_slot], tot[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&sacc[cb][my_slot][k], tot[k]);
       }
     }
     if (ABLATE != 5 && ABLATE != 6) __syncthreads();  // (B) every quadrant's contribution to this chunk is in sacc[cb]
@@ -1094,9 +1085,9 @@ blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 s0[BWD_WAVES][WAVE], s1[BWD_WAVES][WAVE], s2[BWD_WAVES][WAVE];
   __shared__ uint32_t sid[2][WAVE];  // (sid, sco, sacc: double-buffered by chunk parity, see backward_tile)
   __shared__ float4 sco[2][WAVE];
-  __shared__ float sacc[2][9][WAVE];
+  __shared__ float sacc[2][WAVE][ACC_LDS_ROW];  // raw moments 0..8 of every chunk slot (row stride 9: odd, the four rows of a flush instruction spread over the banks)
   __shared__ uint32_t s_item;
-  for (int i = threadIdx.x; i < 2 * 9 * WAVE; i += WAVE * BWD_WAVES) (&sacc[0][0][0])[i] = 0.f;
+  for (int i = threadIdx.x; i < 2 * WAVE * ACC_LDS_ROW; i += WAVE * BWD_WAVES) (&sacc[0][0][0])[i] = 0.f;
   // (element i was zeroed by thread i % 256, i.e. by any wave: with the deferred flush the placement-assigned first item
   // reaches its first ds_add_f32 without passing a workgroup barrier otherwise.  Once per kernel, not per item.)
   __syncthreads();
@@ -1561,10 +1552,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   ClearArgs clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
   if (a.clear_grads) {
     const long long P = a.P;
-    clear.ptr[0] = a.dL_dmean2D; clear.n[0] = 3 * P;
-    clear.ptr[1] = a.dL_dconic; clear.n[1] = 4 * P;
-    clear.ptr[2] = a.dL_dopacity; clear.n[2] = P;
-    clear.ptr[3] = a.dL_dcolors; clear.n[3] = 3 * P;
+    clear.ptr[0] = a.acc; clear.n[0] = (long long)ACC_ROW * P;
   }
   if (a.work_est == nullptr || a.work_maxc == nullptr || a.bwd_order == nullptr) return hipErrorInvalidValue;
   {

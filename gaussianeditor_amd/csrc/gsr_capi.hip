@@ -495,34 +495,25 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 }
 
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags) {
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags) {
   // (a backward of a view whose forward was declared forward-only: the flags of one view travel together)
   if ((flags & ~GSR_FLAG_ALL) || (flags & GSR_FLAG_FORWARD_ONLY)) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0) return GSR_OK;
-  if (R == 0) {  // nothing to blend: the accumulators stay zero -- or become zero
-    if (flags & GSR_FLAG_CLEAR_GRADS) {
-      if (P < 0 || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors) return GSR_ERR_BAD_ARGUMENT;
-      float* const acc[4] = {dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors};
-      const size_t len[4] = {3, 4, 1, 3};
-      for (int k = 0; k < 4; ++k) GSR_HIP(hipMemsetAsync(acc[k], 0, sizeof(float) * len[k] * (size_t)P, (hipStream_t)stream));
-    }
+  if (P < 0 || !acc || ((uintptr_t)acc & 63u)) return GSR_ERR_BAD_ARGUMENT;  // (a row must not straddle two 64-byte lines)
+  if (R == 0) {  // nothing to blend: the accumulator rows stay zero -- or become zero
+    if (flags & GSR_FLAG_CLEAR_GRADS) GSR_HIP(hipMemsetAsync(acc, 0, sizeof(float) * ACC_ROW * (size_t)P, (hipStream_t)stream));
     return GSR_OK;
   }
-  if (P < 0 || R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
+  if (R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
   // (the backward's work items carry the tile id in 20 bits, next to the half / segment fields: gsr_blend.hip BWD_ITEM_TILE)
   if ((int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE) > (int64_t)GSR_MAX_TILES) return GSR_ERR_BAD_ARGUMENT;
-  if (!bg || !geom || !binning || !image || !dL_dpix || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors)
-    return GSR_ERR_BAD_ARGUMENT;
+  if (!bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Image im = carve_image(const_cast<void*>(image), W, H);
   const Binning b = carve_binning_view(binning, R, W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1, R);
   a.dL_dpix = dL_dpix;
-  a.dL_dmean2D = dL_dmeans2D;
-  a.dL_dconic = dL_dconic;
-  a.dL_dopacity = dL_dopacity;
-  a.dL_dcolors = dL_dcolors;
+  a.acc = acc;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   a.P = P;
@@ -535,15 +526,15 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
                                     const float* scales, float scale_modifier, const float* rotations,
                                     const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                     const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                    const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                                    const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                    const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                    float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                     float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state = nullptr) {
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
   // this geometry state was left by gsr_preprocess(GSR_FLAG_FORWARD_ONLY): what K8+K9 reads of it was never written
   if (shs && geom_is_forward_only(geom)) return GSR_ERR_BAD_ARGUMENT;
-  if (!dL_dmeans2D || !dL_dconic || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
+  if (!acc || ((uintptr_t)acc & 63u) || !dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
   if (shs && ((!dL_dsh && !dL_drgb) || !campos)) return GSR_ERR_BAD_ARGUMENT;
   if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
   if (!cov3D_precomp && !scales) return GSR_ERR_BAD_ARGUMENT;  // the 3D covariance is recomputed, not read from `geom`
@@ -559,7 +550,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   pa.h_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:308-309
   pa.h_x = W / (2.0f * tan_fovx);
   pa.tan_fovx = tan_fovx; pa.tan_fovy = tan_fovy;
-  pa.dL_dmean2D = dL_dmeans2D; pa.dL_dconic = dL_dconic; pa.dL_dcolor = dL_dcolors;
+  pa.acc = acc; pa.dL_dmean2D = dL_dmeans2D; pa.dL_dopacity = dL_dopacity; pa.dL_dcolor = dL_dcolors;
   pa.dL_dmeans3D = dL_dmeans3D; pa.dL_dcov3D = dL_dcov3D;
   pa.dL_dsh = shs ? dL_dsh : nullptr;
   pa.dL_drgb = shs ? dL_drgb : nullptr;
@@ -571,24 +562,20 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
 }
 
 int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                                     const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                                     float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
-                                     int64_t max_records, int64_t* n_records_host) {
+                                     const void* binning, const void* image, const float* dL_dpix, float* acc,
+                                     uint64_t* records, int64_t max_records, int64_t* n_records_host) {
   if (!records || !n_records_host) return GSR_ERR_BAD_ARGUMENT;
   const int64_t n = (int64_t)blend_grid_size(true, (hipStream_t)stream) / 4;
   *n_records_host = n;
   if (max_records < n) return GSR_ERR_BAD_ARGUMENT;
   if (P < 0 || R <= 0 || W <= 0 || H <= 0 || !bg || !geom || !binning || !image || !dL_dpix) return GSR_ERR_BAD_ARGUMENT;
-  if (!dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors) return GSR_ERR_BAD_ARGUMENT;
+  if (!acc || ((uintptr_t)acc & 63u)) return GSR_ERR_BAD_ARGUMENT;
   const Geom g = carve_geom(const_cast<void*>(geom), P);
   const Binning b = carve_binning_view(binning, R, W, H);
   const Image im = carve_image(const_cast<void*>(image), W, H);
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1, R);
   a.dL_dpix = dL_dpix;
-  a.dL_dmean2D = dL_dmeans2D;
-  a.dL_dconic = dL_dconic;
-  a.dL_dopacity = dL_dopacity;
-  a.dL_dcolors = dL_dcolors;
+  a.acc = acc;
   a.profile = records;
   // optional extension: with room for T more records, 4 x u64 per (tile, half) follow the workgroup records:
   // {cycles, the forward's four per-quadrant counts (16 bits each), positions the backward walked, item code}
@@ -604,12 +591,12 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                             const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                            float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                             float* dL_dscales, float* dL_drots) {
   if (shs && !dL_dsh) return GSR_ERR_BAD_ARGUMENT;
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
-                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
                                   dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, nullptr, dL_dscales, dL_drots);
 }
 
@@ -617,26 +604,26 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
                                 const float* scales, float scale_modifier, const float* rotations,
                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                                const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
+                                const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
                                 float* dL_dscales, float* dL_drots) {
   if (!shs || !dL_drgb) return GSR_ERR_BAD_ARGUMENT;
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
-                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
-                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots);
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
+                                  nullptr, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots);
 }
 
 int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                                  const float* scales, float scale_modifier, const float* rotations,
                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                  const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                 const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                                 const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                 const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                 float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                  float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state) {
   if (!row_state || (dL_dsh && dL_drgb)) return GSR_ERR_BAD_ARGUMENT;
   if (shs && !dL_dsh && !dL_drgb) return GSR_ERR_BAD_ARGUMENT;
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
-                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
                                   dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_drgb, dL_dscales, dL_drots, row_state);
 }
 
@@ -677,14 +664,13 @@ int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local,
   return GSR_OK;
 }
 
-int gsr_view_message_plan_blend(void* stream, int64_t P, const float* dL_dmeans2D, const float* dL_dconic,
-                                const float* dL_dopacity, const float* dL_dcolors, uint8_t* mask, void* workspace) {
+int gsr_view_message_plan_blend(void* stream, int64_t P, const float* acc, uint8_t* mask, void* workspace) {
   if (P == 0) return GSR_OK;
-  if (P < 0 || !dL_dmeans2D || !dL_dconic || !dL_dopacity || !dL_dcolors || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  if (P < 0 || !acc || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
   hipStream_t s = (hipStream_t)stream;
-  const float* data[4] = {dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors};
-  const int row_len[4] = {3, 4, 1, 3};
-  GSR_HIP(launch_touched_rows(s, P, 4, data, row_len, mask));
+  const float* data[1] = {acc};
+  const int row_len[1] = {(int)ACC_ROW};
+  GSR_HIP(launch_touched_rows(s, P, 1, data, row_len, mask));
   GSR_HIP(launch_compact_plan(s, P, mask, workspace));
   return GSR_OK;
 }
@@ -736,17 +722,16 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                  const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii, const void* geom,
-                 const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
+                 const void* binning, const void* image, const float* dL_dpix, float* acc, float* dL_dmeans2D,
                  float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                  float* dL_dscales, float* dL_drots, unsigned flags) {
   (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
   if (P == 0) return GSR_OK;
   if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
-  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, dL_dmeans2D, dL_dconic,
-                              dL_dopacity, dL_dcolors, flags);
+  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags);
   if (st != GSR_OK) return st;
   return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
-                                 viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, dL_dmeans2D, dL_dconic,
+                                 viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
 }
 

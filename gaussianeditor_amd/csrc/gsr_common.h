@@ -16,6 +16,12 @@ constexpr int TILE = 16;        // tile edge in pixels (reference: BLOCK_X/BLOCK
 constexpr int QUAD = 8;         // one wave = 8x8 pixels
 constexpr int WAVE = 64;
 constexpr int GAUSS_BLOCK = 256;  // Gaussians per block in the per-Gaussian kernels
+// The blend backward's accumulators: ONE 64-byte row per Gaussian, so that the (up to nine) float atomics of a (tile,
+// Gaussian) pair leave as one memory-side request (gsr_blend.hip: flush).  Columns as include/gsr.h states them:
+// [0] [1] dL_dmean2D.xy  [3] dL_dopacity  [4] [5] [7] dL_dconic.x .y .w  [8..10] dL_dcolor; 2, 6, 11..15 stay zero.
+constexpr uint32_t ACC_ROW = GSR_ACC_ROW, ACC_MEAN2D = GSR_ACC_MEAN2D, ACC_OPACITY = GSR_ACC_OPACITY, ACC_CONIC = GSR_ACC_CONIC,
+                   ACC_COLOR = GSR_ACC_COLOR;
+static_assert(ACC_ROW == 16 && ACC_MEAN2D == 0 && ACC_OPACITY == 3 && ACC_CONIC == 4 && ACC_COLOR == 8, "float4-aligned column groups");
 // Binning works on GROUPS of 8 x 8 tiles (128 x 128 pixels): a Gaussian's tile rectangle inside one group is a 64-bit
 // mask, one bit per tile, bit = (tile_y & 7) * 8 + (tile_x & 7) (gsr_binning.hip).
 constexpr int GROUP_SHIFT = 3;

@@ -44,9 +44,10 @@ struct PreBwdArgs {
   const float* projmatrix;
   const float* campos;
   float h_x, h_y, tan_fovx, tan_fovy;
-  const float* dL_dmean2D;  // (P,3)
-  const float* dL_dconic;   // (P,4)
-  const float* dL_dcolor;   // (P,3)
+  const float* acc;         // (P, ACC_ROW): the blend backward's accumulator rows (dL_dmean2D, dL_dopacity, dL_dconic, dL_dcolor)
+  float* dL_dmean2D;        // (P,3) out: columns ACC_MEAN2D .. + 1 of the rows, z = 0
+  float* dL_dopacity;       // (P)   out: column ACC_OPACITY
+  float* dL_dcolor;         // (P,3) out | null: columns ACC_COLOR .. + 2 (the gradient of colors_precomp)
   float* dL_dmeans3D;       // (P,3)
   float* dL_dcov3D;         // (P,6)
   float* dL_dsh;            // (P,M,3) | null
@@ -81,17 +82,14 @@ struct BlendArgs {
   float* out_depth;
   // backward
   const float* dL_dpix;
-  float* dL_dmean2D;
-  float* dL_dconic;
-  float* dL_dopacity;
-  float* dL_dcolors;
+  float* acc;      // (P, ACC_ROW): one 64-byte row of accumulators per Gaussian (ACC_* columns, gsr_common.h / include/gsr.h)
   // tracing
   int C;
   const float* image_weights;
   float* weights;
   int32_t* cnt;
-  int P;           // number of Gaussians (rows of the backward's accumulators)
-  int clear_grads; // GSR_FLAG_CLEAR_GRADS: the backward clears its four accumulators itself (launch_blend_backward)
+  int P;           // number of Gaussians (rows of the backward's accumulator table)
+  int clear_grads; // GSR_FLAG_CLEAR_GRADS: the backward clears its accumulator rows itself (launch_blend_backward)
   int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)
   int shared_simds;  // GSR_FLAG_SHARED_SIMDS: 2 persistent waves per SIMD instead of 4 (another stream's kernels run alongside)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)

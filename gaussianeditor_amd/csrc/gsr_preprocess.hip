@@ -569,7 +569,13 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   V3 dscale = {0.f, 0.f, 0.f};
   float4 drot = make_float4(0.f, 0.f, 0.f, 0.f);
   V3 drgb = {0.f, 0.f, 0.f};  // dL_dRGB with the clamped channels zeroed (output of the "rgb" mode)
-  bool nonzero_in = false;    // ROWS: some entry of the Gaussian's accumulator rows is not zero (NaN != 0: counts)
+  bool nonzero_in = false;    // ROWS: some entry of the Gaussian's accumulator row is not zero (NaN != 0: counts)
+  // The Gaussian's accumulator row (round 6: K7 adds into ONE 64-byte row per Gaussian, gsr_common.h ACC_*): requested for
+  // every thread, visible or not -- the screen-space and opacity gradients leave through this kernel now (K7 used to add
+  // into the caller's arrays directly), and a Gaussian without a pixel has an all-zero row.
+  const float4* const acc_row = reinterpret_cast<const float4*>(a.acc + (size_t)idx * ACC_ROW);
+  const float4 acc_m2d = acc_row[ACC_MEAN2D / 4];  // dL_dmean2D.x, .y, (0), dL_dopacity
+  const float4 acc_col = acc_row[ACC_COLOR / 4];   // dL_dcolor r, g, b, (0)
 
   if (live && a.radii[idx] > 0) {
     Cam cam;
@@ -588,8 +594,8 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       sc2 = a.scales[3 * idx + 2];
       quat = reinterpret_cast<const float4*>(a.rotations)[idx];
     }
-    const float4 gc = reinterpret_cast<const float4*>(a.dL_dconic)[idx];
-    const float g2x = a.dL_dmean2D[3 * (size_t)idx], g2y = a.dL_dmean2D[3 * (size_t)idx + 1];
+    const float4 gc = acc_row[ACC_CONIC / 4];  // (the row's three float4 were requested above, in front of the branch)
+    const float g2x = acc_m2d.x, g2y = acc_m2d.y;
     V3 dRGBdx = {0.f, 0.f, 0.f}, dRGBdy = {0.f, 0.f, 0.f}, dRGBdz = {0.f, 0.f, 0.f}, dL_dRGB = {0.f, 0.f, 0.f};
     uint8_t cl = 0;
     if (a.shs != nullptr) {
@@ -602,7 +608,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
         dRGBdz = *reinterpret_cast<const V3*>(a.dcol[2] + 3 * (size_t)idx);
       }
       cl = a.clamped[idx];
-      dL_dRGB = {a.dL_dcolor[3 * (size_t)idx], a.dL_dcolor[3 * (size_t)idx + 1], a.dL_dcolor[3 * (size_t)idx + 2]};
+      dL_dRGB = {acc_col.x, acc_col.y, acc_col.z};
     }
     float c3[6];
     if (a.cov3D_precomp != nullptr) {
@@ -612,7 +618,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       cov3d_from_values(sc0, sc1, sc2, a.scale_modifier, quat, c3);  // what K1 computed, bit for bit
     }
     const V3 dL_dcon = {gc.x, gc.y, gc.w};
-    nonzero_in = gc.x != 0.f || gc.y != 0.f || gc.w != 0.f;
+    nonzero_in = gc.x != 0.f || gc.y != 0.f || gc.w != 0.f || acc_m2d.w != 0.f || acc_col.x != 0.f || acc_col.y != 0.f || acc_col.z != 0.f;
 
     // ---- computeCov2DCUDA, backward.cu:159-273 ----
     V3 t = {view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12],
@@ -806,6 +812,17 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx], dmean.x);
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 1], dmean.y);
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 2], dmean.z);
+  // the two gradients K7 accumulates for the caller (backward.cu:545-546, 554) and, with precomputed colours, the colour's
+  // (:523): copied out of the accumulator row (a Gaussian that is not visible has a zero row: K7 never touched it)
+  K9_ST(&a.dL_dmean2D[3 * (size_t)idx], acc_m2d.x);
+  K9_ST(&a.dL_dmean2D[3 * (size_t)idx + 1], acc_m2d.y);
+  K9_ST(&a.dL_dmean2D[3 * (size_t)idx + 2], 0.f);
+  K9_ST(&a.dL_dopacity[idx], acc_m2d.w);
+  if (a.dL_dcolor != nullptr) {
+    K9_ST(&a.dL_dcolor[3 * (size_t)idx], acc_col.x);
+    K9_ST(&a.dL_dcolor[3 * (size_t)idx + 1], acc_col.y);
+    K9_ST(&a.dL_dcolor[3 * (size_t)idx + 2], acc_col.z);
+  }
   if (!ROWS) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);
@@ -916,6 +933,13 @@ __global__ void __launch_bounds__(256) touched_rows_kernel(int64_t P, RowSet rs,
   bool any = false;
   for (int t = 0; t < rs.n; ++t) {
     const float* r = rs.data[t] + (size_t)i * rs.row_len[t];
+    if (rs.row_len[t] == (int)ACC_ROW && (reinterpret_cast<uintptr_t>(rs.data[t]) & 15u) == 0) {  // the backward's accumulator rows
+      const float4* r4 = reinterpret_cast<const float4*>(r);
+      const float4 v0 = r4[0], v1 = r4[1], v2 = r4[2];  // (columns 12..15 are never written)
+      any = any || !(v0.x == 0.f) || !(v0.y == 0.f) || !(v0.z == 0.f) || !(v0.w == 0.f) || !(v1.x == 0.f) || !(v1.y == 0.f) ||
+            !(v1.z == 0.f) || !(v1.w == 0.f) || !(v2.x == 0.f) || !(v2.y == 0.f) || !(v2.z == 0.f) || !(v2.w == 0.f);
+      continue;
+    }
     for (int k = 0; k < rs.row_len[t]; ++k) any = any || !(r[k] == 0.0f);  // NaN counts as touched
   }
   mask[i] = any ? 1 : 0;

@@ -193,21 +193,19 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     `flags` (extension, keyword): the flags the forward of this view ran with; None = options.current_flags().
     `grad_allocator` (extension, keyword): fn(name, shape, zero) -> tensor | None for the gradient outputs, asked for
     "means2D", "opacities", "means3D", "cov3Ds_precomp", "sh", "scales", "rotations" with the tensor's shape.  An allocator
-    may answer None to anything (the gradient is then allocated privately).  Four special names, all optional:
-      "accumulators"       shape (11 P,): -> (dL_dmeans2D (P,3), dL_dopacity (P,1), dL_dconic (P,4), dL_dcolors (P,3)), the
-                           four buffers the blend backward adds into (asked with zero = False since round 3: the blend
-                           backward clears them itself, GSR_FLAG_CLEAR_GRADS);
-      "means2D+opacities"  shape (4 P,): -> (dL_dmeans2D, dL_dopacity) only, zeroed likewise;
-                           (anything but a tuple of the right length and shapes is ignored: an allocator that answers
-                           unknown names with a plain tensor keeps working)
+    may answer None to anything (the gradient is then allocated privately).  Special names, all optional:
+      "acc_rows"           shape (16 P,), asked FIRST: the blend backward's accumulator table (include/gsr.h: GSR_ACC_*, one
+                           64-byte row per Gaussian; workspace, never a gradient -- since round 6 dL_dmeans2D / dL_dopacity
+                           are copied out of it by K8+K9).  Asked with zero = False: the blend backward clears it itself
+                           (GSR_FLAG_CLEAR_GRADS).  A float32 tensor of 16 P elements, 64-byte aligned, or None;
       "sh_rgb"             shape (P,3): a tensor here asks for the clamp-masked colour gradient INSTEAD of dL_dsh (which is
                            then returned as None; gaussianeditor_amd.multiview rebuilds it after the exchange);
-      "after_blend_backward"  a notification, only in the "sh_rgb" mode: `shape` is the tuple of the four accumulators,
-                           K7 has been enqueued and K8+K9 has not; the return value is ignored;
-      "row_state"          shape (P,): a uint8 tensor here says that "means3D", "sh" / "sh_rgb", "scales" and "rotations" were
-                           answered with tensors the allocator keeps across calls, with this per-Gaussian state next to them
-                           (include/gsr.h: gsr_preprocess_backward_rows): rows that still hold the zeros of an earlier call
-                           are not rewritten."""
+      "after_blend_backward"  a notification, only in the "sh_rgb" mode: `shape` is the accumulator table as a (P,16)
+                           tensor, K7 has been enqueued and K8+K9 has not; the return value is ignored;
+      "row_state"          shape (P,): a uint8 tensor here says that "means2D", "opacities", "means3D", "sh" / "sh_rgb",
+                           "scales" and "rotations" were answered with tensors the allocator keeps across calls, with this
+                           per-Gaussian state next to them (include/gsr.h: gsr_preprocess_backward_rows): rows that still
+                           hold the zeros of an earlier call are not rewritten."""
     flags = _flags(flags)
     dev = means3D.device
     P = int(means3D.size(0))
@@ -229,42 +227,23 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         _on_device(buf, name, dev, torch.uint8)
     radii = radii.contiguous()
     has_scales = scales.numel() != 0
-    # accumulated with atomics -> zero-filled (with as few fill launches as possible: one block, or two when a
-    # gradient allocator owns means2D + opacities); the rest is fully written by the kernels
     grad_alloc = grad_allocator
-    # "means2D+opacities": an allocator may hand back BOTH accumulators, already zeroed by ONE fill of the span that
-    # holds them, as a pair (dL_dmeans2D (P,3), dL_dopacity (P,1))
-    # "accumulators": all four buffers the blend backward adds into -- dL_dmeans2D (P,3), dL_dopacity (P,1) and the internal
-    # dL_dconic (P,4), dL_dcolors (P,3) -- zeroed by ONE fill (an allocator that owns them contiguously)
-    def _views(ans, shapes):  # a well-formed tuple of tensors with the expected shapes, or None
-        if not isinstance(ans, (tuple, list)) or len(ans) != len(shapes):
-            return None
-        for t, shp in zip(ans, shapes):
-            if not isinstance(t, torch.Tensor) or tuple(t.shape) != shp or t.dtype != torch.float32 or t.device != dev:
-                return None
-        return tuple(ans)
-
-    # (none of them is zero-filled here: the blend backward clears all four itself, inside the launch that builds its work
-    # list -- GSR_FLAG_CLEAR_GRADS; a separate fill of 44 bytes per Gaussian cost 8 us at 10^6 Gaussians)
-    four = _views(grad_alloc("accumulators", (11 * P,), False), ((P, 3), (P, 1), (P, 4), (P, NUM_CHANNELS))) \
-        if grad_alloc is not None else None
-    joint = None if (four is not None or grad_alloc is None) else \
-        _views(grad_alloc("means2D+opacities", (4 * P,), False), ((P, 3), (P, 1)))
-    if four is not None:
-        dL_dmeans2D, dL_dopacity, dL_dconic, dL_dcolors = four
-    elif joint is not None:
-        dL_dmeans2D, dL_dopacity = joint
-        rest = torch.empty((7 * P,), dtype=torch.float32, device=dev)
-        dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
-    elif grad_alloc is not None:
-        dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), False, dev)
-        dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), False, dev)
-        rest = torch.empty((7 * P,), dtype=torch.float32, device=dev)
-        dL_dconic, dL_dcolors = rest[:4 * P].view(P, 4), rest[4 * P:].view(P, NUM_CHANNELS)  # conic rows: dwordx4
-    else:
-        acc = torch.empty((11 * P,), dtype=torch.float32, device=dev)  # conic first: its rows are dwordx4-accessed
-        dL_dconic, dL_dmeans2D = acc[:4 * P].view(P, 4), acc[4 * P:7 * P].view(P, 3)
-        dL_dcolors, dL_dopacity = acc[7 * P:10 * P].view(P, NUM_CHANNELS), acc[10 * P:].view(P, 1)
+    # The accumulator table of the blend backward (one 64-byte row per Gaussian; not zero-filled here: K7's own launch clears
+    # it -- GSR_FLAG_CLEAR_GRADS; a separate fill cost 8 us at 10^6 Gaussians).  dL_dmeans2D / dL_dopacity / dL_dcolors leave
+    # through K8+K9, which writes every row.
+    acc = grad_alloc("acc_rows", (_native.ACC_ROW * P,), False) if grad_alloc is not None else None
+    if not (isinstance(acc, torch.Tensor) and acc.dtype == torch.float32 and acc.numel() == _native.ACC_ROW * P
+            and acc.device == dev and acc.is_contiguous() and acc.data_ptr() % 64 == 0):
+        acc = torch.empty((_native.ACC_ROW * P,), dtype=torch.float32, device=dev)
+    acc = acc.view(P, _native.ACC_ROW)
+    dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), False, dev)
+    dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), False, dev)
+    # the gradient of colors_precomp (rasterize_points.cu:133): written only for a caller that passed colours; with SHs the
+    # reference's tensor holds the colour accumulator nobody reads -- here a view of that column group
+    has_colors = colors.numel() != 0
+    # (zeros, not empty, under an allocator: its "row_state" mode leaves rows that are zero again unwritten)
+    dL_dcolors = (torch.zeros if grad_alloc is not None else torch.empty)((P, NUM_CHANNELS), dtype=torch.float32, device=dev) \
+        if has_colors else acc[:, _native.ACC_COLOR:_native.ACC_COLOR + NUM_CHANNELS]
     dL_dmeans3D = _alloc(grad_alloc, "means3D", (P, 3), False, dev)
     dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev)
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
@@ -273,26 +252,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)
-    bwd_flags = flags | options.FLAG_CLEAR_GRADS  # (the accumulators above are not zero: the blend backward clears them)
+    bwd_flags = flags | options.FLAG_CLEAR_GRADS  # (the accumulator table is not zero: the blend backward clears it)
     row_state = grad_alloc("row_state", (P,), False) if grad_alloc is not None else None
     if row_state is not None and not (isinstance(row_state, torch.Tensor) and row_state.dtype == torch.uint8 and
                                       row_state.numel() == P and row_state.is_contiguous() and row_state.device == dev):
         row_state = None
     L = _native.lib()
     with torch.cuda.device(dev):
+        col_out = dL_dcolors.data_ptr() if has_colors else None
         if row_state is not None:  # gradient arrays kept across calls: only the rows that change are written
-            # (also when nothing was rendered: the call then only clears the accumulators)
+            # (also when nothing was rendered: the call then only clears the accumulator table)
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
-                dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
             if dL_drgb is not None:
-                grad_alloc("after_blend_backward", (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), False)
+                grad_alloc("after_blend_backward", acc, False)
             _native.check("gsr_preprocess_backward_rows", L.gsr_preprocess_backward_rows(
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
-                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), dL_dmeans2D.data_ptr(),
-                dL_dconic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), acc.data_ptr(),
+                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), col_out, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 _ptr(dL_dsh) if dL_drgb is None else None, None if dL_drgb is None else dL_drgb.data_ptr(),
                 dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None,
                 row_state.data_ptr()))
@@ -302,23 +281,22 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp),
                 viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
-                dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                acc.data_ptr(), dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), col_out,
                 dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
                 dL_drotations.data_ptr() if has_scales else None, bwd_flags))
         else:
-            # (also when nothing was rendered: the call then only clears the accumulators)
+            # (also when nothing was rendered: the call then only clears the accumulator table)
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(),
-                dL_dopacity.data_ptr(), dL_dcolors.data_ptr(), bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
             # notification (no allocation): K7 is enqueued, K8+K9 not yet -- multiview.py starts the exchange of the
             # touched-row counts here, so that it (and the host's wait for it) runs underneath K8+K9
-            grad_alloc("after_blend_backward", (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), False)
+            grad_alloc("after_blend_backward", acc, False)
             _native.check("gsr_preprocess_backward_rgb", L.gsr_preprocess_backward_rgb(
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
-                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), dL_dmeans2D.data_ptr(),
-                dL_dconic.data_ptr(), dL_dcolors.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_drgb.data_ptr(),
+                float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), acc.data_ptr(),
+                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_drgb.data_ptr(),
                 dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None))
         if debug:
             torch.cuda.synchronize(dev)
@@ -378,15 +356,16 @@ def view_message_plan(grads5, rgb, readback=True):
     return (mask, work, P, dev), (int(count.value) if readback else work[:8].view(torch.int64))
 
 
-def view_message_plan_blend(acc4):
-    """The same plan from the blend backward's four accumulators (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors), i.e.
-    BEFORE K8+K9 has run -- gsr_view_message_plan_blend.  Never synchronises: returns (plan, count) with count a 1-element
-    int64 device tensor valid in stream order."""
-    m2, conic, op, col = acc4
-    _require_cuda(m2, "dL_dmeans2D")
-    dev, P = m2.device, int(m2.size(0))
+def view_message_plan_blend(acc):
+    """The same plan from the blend backward's accumulator table (P,16), i.e. BEFORE K8+K9 has run --
+    gsr_view_message_plan_blend.  Never synchronises: returns (plan, count) with count a 1-element int64 device tensor
+    valid in stream order."""
+    _require_cuda(acc, "acc")
+    dev, P = acc.device, int(acc.size(0))
     if P == 0:
         return (None, None, 0, dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    if acc.dim() != 2 or acc.size(1) != _native.ACC_ROW or not acc.is_contiguous() or acc.dtype != torch.float32:
+        raise RuntimeError("view_message_plan_blend: expected the (P,16) float32 accumulator table")
     L = _native.lib()
     mask = torch.empty(P, dtype=torch.uint8, device=dev)
     nbytes = ctypes.c_size_t(0)
@@ -394,7 +373,7 @@ def view_message_plan_blend(acc4):
     work = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _native.check("gsr_view_message_plan_blend", L.gsr_view_message_plan_blend(
-            _stream(dev), P, m2.data_ptr(), conic.data_ptr(), op.data_ptr(), col.data_ptr(), mask.data_ptr(), work.data_ptr()))
+            _stream(dev), P, acc.data_ptr(), mask.data_ptr(), work.data_ptr()))
     return (mask, work, P, dev), work[:8].view(torch.int64)
 
 

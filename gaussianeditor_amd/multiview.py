@@ -86,8 +86,8 @@ class GradBucket:
     = (14 + 3M) * P floats (248 MB at P = 1M, M = 16), every segment START rounded up to a multiple of 4 floats:
     the kernels use dwordx4 accesses on (P,4) / (P,M,3) rows, so a segment must begin on a 16-byte boundary whatever
     P is (P is arbitrary after a densification or a prune; the padding words stay zero and travel with the all-reduce).
-    means2D and opacities, the two gradients the backward accumulates with atomics, are adjacent -- and followed, outside
-    the exchanged part, by the backward's two internal accumulators -- so that one fill clears all four."""
+    The blend backward's accumulator table (16 floats per Gaussian, include/gsr.h GSR_ACC_*) is a buffer of the bucket's own
+    next to `flat`: workspace, never exchanged (means2D / opacities are copied out of it by K8+K9)."""
 
     def __init__(self, P: int, M: int, device, sh_exchange: str = "auto", sparse_rows: bool = False,
                  persistent_rows: bool = False):
@@ -117,20 +117,19 @@ class GradBucket:
         for name in slots:
             offs[name] = off
             off = _pad4(off + int(torch.Size(shapes[name]).numel()))
-        # Behind the exchanged part: 7 P floats for the backward's two INTERNAL accumulators (dL_dconic (P,4), dL_dcolors
-        # (P,3)).  They follow means2D / opacities directly, so ONE fill clears everything the blend backward accumulates
-        # into with atomics ("accumulators" request below); they are not part of `flat` and never travel.
-        self._buf = torch.zeros(off + 7 * P, dtype=torch.float32, device=device)
+        self._buf = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat = self._buf[:off]
-        self._scratch_off = off
+        # the blend backward's accumulator table ("acc_rows" request below): one 64-byte row per Gaussian, cleared by the
+        # backward itself (GSR_FLAG_CLEAR_GRADS); not part of `flat`, never travels
+        self._acc = torch.empty(16 * int(P), dtype=torch.float32, device=device)
         if self.flat.data_ptr() % 16 != 0:  # (torch's allocators hand out >= 256-byte alignment; be explicit anyway)
             raise RuntimeError("GradBucket: the flat buffer is not 16-byte aligned")
         self.views: Dict[str, torch.Tensor] = {}
         #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
         self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
         self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
-        #: called with the blend backward's four accumulators between K7 and K8+K9 (multiview_step sets it: the touched-row
-        #: counts are exchanged from there, underneath K8+K9)
+        #: called with the blend backward's accumulator table (P,16) between K7 and K8+K9 (multiview_step sets it: the
+        #: touched-row counts are exchanged from there, underneath K8+K9)
         self.on_blend_done = None
         self._pending_counts = None
         self._side_stream = None
@@ -142,8 +141,6 @@ class GradBucket:
         for name in slots:
             cnt = int(torch.Size(shapes[name]).numel())
             self.views[name] = self.flat[offs[name]:offs[name] + cnt].view(shapes[name])
-        # the span one fill clears for the two atomically accumulated gradients (means2D .. end of opacities)
-        self._acc_span = (offs["means2D"], offs["opacities"] + P)
 
     def check_persistent_rows(self) -> None:
         """Debug (GSR_DEBUG_PERSISTENT_ROWS=1 runs it in front of every backward): the contract of `persistent_rows` is
@@ -171,12 +168,12 @@ class GradBucket:
         if name == "row_state":
             # asked last.  Only if every gradient the state stands for was answered with this bucket's own tensor in THIS
             # backward: a row that is not rewritten must be a row of a tensor that lives across iterations
-            own = {"means3D", "scales", "rotations"} <= self._handed and ({"sh", "sh_rgb"} & self._handed)
+            own = {"means2D", "opacities", "means3D", "scales", "rotations"} <= self._handed and ({"sh", "sh_rgb"} & self._handed)
             ok = self.row_state is not None and own and tuple(shape) == (self.P,)
             if ok and _DEBUG_ROWS:
                 self.check_persistent_rows()
             return self.row_state if ok else None
-        if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the four accumulators)
+        if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the accumulator table, (P,16))
             if self.on_blend_done is not None:
                 self.on_blend_done(shape)
             return None
@@ -185,22 +182,9 @@ class GradBucket:
             if ok:
                 self._handed.add("sh_rgb")
             return self.rgb if ok else None
-        if name in ("accumulators", "means2D+opacities", "means2D"):
-            self._handed = set()  # (the first request of a backward)
-        if name == "accumulators":  # means2D, opacities and the two internal accumulators, zeroed by ONE fill
-            if tuple(shape) != (11 * self.P,):
-                return None
-            P, so = self.P, self._scratch_off
-            if zero:
-                self._buf[self._acc_span[0]:so + 7 * P].zero_()
-            return (self.views["means2D"], self.views["opacities"], self._buf[so:so + 4 * P].view(P, 4),
-                    self._buf[so + 4 * P:so + 7 * P].view(P, 3))
-        if name == "means2D+opacities":  # both accumulators, zeroed by ONE fill of the span that holds them
-            if tuple(shape) != (4 * self.P,):
-                return None
-            if zero:
-                self.flat[self._acc_span[0]:self._acc_span[1]].zero_()
-            return self.views["means2D"], self.views["opacities"]
+        if name == "acc_rows":  # (the first request of a backward) the blend backward's accumulator table: workspace
+            self._handed = set()
+            return self._acc if tuple(shape) == (16 * self.P,) and self._acc.data_ptr() % 64 == 0 else None
         v = self.views.get(name)
         if v is None or tuple(v.shape) != tuple(shape):
             return None
@@ -322,14 +306,14 @@ _ROW_BYTES = 4 * 18
 _ROW_SEGS = ("means3D", "scales", "rotations", "means2D", "opacities")
 
 
-def _start_counts_exchange(bucket: GradBucket, acc4, group, n: int):
-    """Called between K7 and K8+K9 of this rank's backward: marks the touched rows from the blend backward's four
-    accumulators, and exchanges the ranks' row counts -- on a side stream, so that the plan kernels, the tiny all-gather AND
+def _start_counts_exchange(bucket: GradBucket, acc, group, n: int):
+    """Called between K7 and K8+K9 of this rank's backward: marks the touched rows from the blend backward's accumulator
+    table, and exchanges the ranks' row counts -- on a side stream, so that the plan kernels, the tiny all-gather AND
     the host's wait for its result all run while K8+K9 (~100 us) occupies the launch stream.  The step's one host
     synchronisation then costs the GPU nothing: when K8+K9 retires, pack / all-gather / accumulate are already queued."""
-    dev = acc4[0].device
+    dev = acc.device
     if dev.type != "cuda":  # gloo on CPU (tests): nothing to overlap
-        plan, mine = _C.view_message_plan_blend(acc4)
+        plan, mine = _C.view_message_plan_blend(acc)
         gathered = [torch.empty_like(mine) for _ in range(n)]
         dist.all_gather(gathered, mine, group=group)
         return plan, torch.cat(gathered), None
@@ -339,7 +323,7 @@ def _start_counts_exchange(bucket: GradBucket, acc4, group, n: int):
     ready.record(main)  # K7 is enqueued in front of this
     with torch.cuda.stream(side):
         side.wait_event(ready)
-        plan, mine = _C.view_message_plan_blend(acc4)
+        plan, mine = _C.view_message_plan_blend(acc)
         gathered = torch.empty(n, dtype=torch.int64, device=dev)
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
@@ -519,8 +503,8 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
     if exchanging and bucket.sh_exchange == "rgb" and rows in ("auto", True):
         n = dist.get_world_size(group)
 
-        def start_counts(acc4):  # between K7 and K8+K9 of this rank's backward
-            bucket._pending_counts = _start_counts_exchange(bucket, acc4, group, n)
+        def start_counts(acc):  # between K7 and K8+K9 of this rank's backward
+            bucket._pending_counts = _start_counts_exchange(bucket, acc, group, n)
 
         bucket.on_blend_done = start_counts
     try:
@@ -617,9 +601,9 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
     speculate = spec_cap is not None
     state = {}
 
-    def after_blend(acc4):  # between K7 and K8+K9 of a local view: mask + count on a side stream, underneath K8+K9
+    def after_blend(acc):  # between K7 and K8+K9 of a local view: mask + count on a side stream, underneath K8+K9
         if not on_gpu:
-            plan, mine = _C.view_message_plan_blend(acc4)
+            plan, mine = _C.view_message_plan_blend(acc)
             state.update(plan=plan, count=mine, planned=None, done=None)
             return
         main = torch.cuda.current_stream(dev)
@@ -628,7 +612,7 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
         ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            plan, mine = _C.view_message_plan_blend(acc4)
+            plan, mine = _C.view_message_plan_blend(acc)
             planned = torch.cuda.Event()
             planned.record(side)
             host, done = mine, None

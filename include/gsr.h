@@ -56,8 +56,24 @@ extern "C" {
 /* 4 (round 5): adds gsr_near_workspace_size / gsr_near_points (round 4 had left the number at 3), the scratch layouts
  * changed again (sizes come from gsr_scratch_sizes: rebuild nothing, re-query), images of more than GSR_MAX_TILES tiles
  * are refused by the backward entry points instead of being walked wrongly. */
-/* 5 (round 6): adds gsr_arrays_equal. */
+/* 5 (round 6): adds gsr_arrays_equal; the blend backward accumulates into ONE table of 64-byte rows (`acc`, GSR_ACC_*)
+ * instead of four arrays, and gsr_preprocess_backward* copies dL_dmeans2D / dL_dopacity (/ dL_dcolors) out of it: the
+ * signatures of gsr_backward, gsr_blend_backward, gsr_preprocess_backward{,_rgb,_rows}, gsr_view_message_plan_blend and
+ * gsr_debug_blend_backward_profile changed. */
 #define GSR_ABI_VERSION 5
+/* The blend backward's accumulator table: GSR_ACC_ROW floats (one 64-byte line) per Gaussian, 64-byte aligned.  Columns:
+ *   [GSR_ACC_MEAN2D] .x [+1] .y of dL_dmean2D      (backward.cu:545-546)
+ *   [GSR_ACC_OPACITY] dL_dopacity                  (backward.cu:554)
+ *   [GSR_ACC_CONIC] .x [+1] .y [+3] .w of dL_dconic (backward.cu:549-551; the reference's float4 layout, .z unused)
+ *   [GSR_ACC_COLOR .. +2] dL_dcolor                (backward.cu:523)
+ * every other column stays zero.  Why one row: float atomics execute at the memory side on this chip and cost per REQUEST;
+ * the lanes of a wave instruction that fall into one 64-byte line travel as one request, so the (up to nine) adds of a
+ * (tile, Gaussian) pair leave as one instead of nine (tools/microbench/atomic_merge.hip: 8.8x). */
+#define GSR_ACC_ROW 16
+#define GSR_ACC_MEAN2D 0
+#define GSR_ACC_OPACITY 3
+#define GSR_ACC_CONIC 4
+#define GSR_ACC_COLOR 8
 /* Largest image the blend BACKWARD accepts, in 16 x 16 tiles (its work items carry the tile id in 20 bits). */
 #define GSR_MAX_TILES (1 << 20)
 
@@ -101,8 +117,8 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *                        forward.cu:340-344, so images, depths, radii, traced weights and gradients are unchanged --
  *                        but num_rendered, the instance lists in the binning scratch and n_contrib differ from the
  *                        reference's.
- *   GSR_FLAG_CLEAR_GRADS (read by gsr_blend_backward / gsr_backward) dL_dmeans2D, dL_dconic, dL_dopacity and dL_dcolors
- *       need not be zero on entry: the call clears them before it accumulates (inside the launch that builds the backward's
+ *   GSR_FLAG_CLEAR_GRADS (read by gsr_blend_backward / gsr_backward) the accumulator table `acc`
+ *       need not be zero on entry: the call clears it before it accumulates (inside the launch that builds the backward's
  *       work list, while that one workgroup runs: 14 us instead of 8 + 9 at 10^6 Gaussians, and one launch less);
  *   GSR_FLAG_FORWARD_ONLY (read by gsr_preprocess) no gsr_preprocess_backward / gsr_backward will be called on the geometry
  *       state this call leaves: the 48 bytes per Gaussian only the backward reads (the colour's derivative by the view
@@ -200,36 +216,38 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
 /* K7 + K8 + K9: the whole backward.  Reference: Rasterizer::backward,
  * rasterizer_impl.cu:289-341 (BACKWARD::render then BACKWARD::preprocess).
  *   dL_dpix (3,H,W) in.
- *   Accumulated with atomics, MUST be zero-filled by the caller (or cleared by the call: GSR_FLAG_CLEAR_GRADS):
- *       dL_dmeans2D (P,3), dL_dcolors (P,3), dL_dopacity (P), dL_dconic (P,4) [workspace].
- *       These four arrays MUST live in ordinary (coarse-grained) device memory -- hipMalloc, torch's caching allocator --,
- *       not in fine-grained / host-coherent allocations (hipMallocManaged, hipHostMalloc, hipExtMallocWithFlags(...
- *       hipDeviceMallocFinegrained)): the library is built with -munsafe-fp-atomics, i.e. its float adds are the hardware's
- *       global_atomic_add_f32, which is only defined on coarse-grained memory (on fine-grained memory the adds are silently
- *       lost).  The same holds for `weights` / `cnt` of gsr_trace_weights.
- *   Fully written by the library (no need to zero): dL_dmeans3D (P,3), dL_dcov3D (P,6),
+ *   acc (P, GSR_ACC_ROW) workspace: the accumulator table K7 adds into with atomics and K8+K9 reads.  MUST be zero on entry
+ *       (or is cleared by the call: GSR_FLAG_CLEAR_GRADS), 64-byte aligned, and MUST live in ordinary (coarse-grained)
+ *       device memory -- hipMalloc, torch's caching allocator --, not in fine-grained / host-coherent allocations
+ *       (hipMallocManaged, hipHostMalloc, hipExtMallocWithFlags(... hipDeviceMallocFinegrained)): the library is built with
+ *       -munsafe-fp-atomics, i.e. its float adds are the hardware's global_atomic_add_f32, which is only defined on
+ *       coarse-grained memory (on fine-grained memory the adds are silently lost).  The same holds for `weights` / `cnt` of
+ *       gsr_trace_weights.
+ *   Fully written by the library (no need to zero): dL_dmeans2D (P,3) [z = 0], dL_dopacity (P), dL_dcolors (P,3) [may be
+ *       NULL: only a caller with precomputed colours needs it], dL_dmeans3D (P,3), dL_dcov3D (P,6),
  *       dL_dsh (P,M,3) [NULL if shs == NULL], dL_dscales (P,3) and dL_drots (P,4) [NULL if scales == NULL].
- *   (The reference zero-fills all nine, rasterize_points.cu:120-128.) */
+ *   (The reference zero-fills all nine of its outputs, rasterize_points.cu:120-128, and accumulates into four of them.) */
 int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
                  const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                 const void* geom, const void* binning, const void* image, const float* dL_dpix,
-                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 const void* geom, const void* binning, const void* image, const float* dL_dpix, float* acc,
+                 float* dL_dmeans2D, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dsh, float* dL_dscales, float* dL_drots, unsigned flags);
 
 /* The two halves of gsr_backward as separate entry points (same argument meaning), so a caller
  * can time or overlap them: K7 = BACKWARD::render (backward.cu:399-557), K8+K9 = BACKWARD::preprocess
- * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward. */
+ * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward.
+ * After gsr_blend_backward alone `acc` holds the sums in the GSR_ACC_* columns; gsr_preprocess_backward reads them and
+ * writes dL_dmeans2D / dL_dopacity (/ dL_dcolors) next to its own outputs. */
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                       float* dL_dconic, float* dL_dopacity, float* dL_dcolors, unsigned flags);
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags);
 int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                             const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                            const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                            const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                            const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                            float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                             float* dL_dscales, float* dL_drots);
 
 /* Multi-GPU exchange support (gaussianeditor_amd/multiview.py).  Per view the SH gradient is
@@ -244,19 +262,19 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
                                 const float* scales, float scale_modifier, const float* rotations,
                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                                const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
+                                const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
                                 float* dL_dscales, float* dL_drots);
 
 /* The same kernel for gradient arrays the caller keeps ACROSS calls (a training loop's gradient bucket).  A view leaves
  * nine Gaussians of ten with all-zero gradients (culled, or blended by no pixel), and rewriting those zeros is most of
  * this kernel's traffic (248 B per Gaussian at M = 16).  row_state (P bytes, device) travels with the arrays
- * dL_dmeans3D, dL_dsh or dL_drgb (exactly one of the two, the other NULL), dL_dscales, dL_drots:
+ * dL_dmeans2D, dL_dopacity, dL_dcolors (if given), dL_dmeans3D, dL_dsh or dL_drgb (exactly one of the two, the other NULL),
+ * dL_dscales, dL_drots:
  *   row_state[g] != 0  the rows of g may hold anything: they are written (values, or zeros) -- initialise to 1;
  *   row_state[g] == 0  the rows of g hold the zeros this function wrote before: if g's gradients are zero again, nothing
  *                      is written.
- * On return row_state[g] = 1 iff g's accumulator rows (dL_dconic, dL_dmeans2D, and dL_dcolors when shs != NULL) had a
- * non-zero entry.  After the call every row holds what gsr_preprocess_backward(_rgb) would have written, for finite
+ * On return row_state[g] = 1 iff g's accumulator row (`acc`) had a non-zero entry.  After the call every row holds what gsr_preprocess_backward(_rgb) would have written, for finite
  * parameters (all-zero accumulator rows give all-zero gradients; with a non-finite parameter that kernel computes 0 x inf
  * on every call, this one only when it writes the row).  Whoever else writes to these arrays must set row_state to 1 for
  * the rows it touched.  dL_dcov3D is written for every Gaussian. */
@@ -264,8 +282,8 @@ int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H
                                  const float* scales, float scale_modifier, const float* rotations,
                                  const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                  const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                 const void* geom, const float* dL_dmeans2D, const float* dL_dconic,
-                                 const float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
+                                 const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                 float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                  float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state);
 int gsr_sh_grad_compose(void* stream, int P, int D, int M, int num_views, const float* means3D, const float* campos,
                         const float* dL_drgb, float* dL_dsh);
@@ -356,9 +374,9 @@ int gsr_adam_step_rows(void* stream, int num_tensors, const gsr_adam_tensor* ten
  *                                 does not block: the count is then the uint64 at the start of `workspace`, in
  *                                 stream order (multiview.py all-gathers it from there: one host sync for all ranks'
  *                                 counts instead of two);
- *   gsr_view_message_plan_blend   the same plan from what gsr_blend_backward ALONE leaves behind -- its four accumulators
- *                                 dL_dmeans2D (P,3), dL_dconic (P,4), dL_dopacity (P), dL_dcolors (P,3): a Gaussian no pixel
- *                                 blended has all-zero rows there, and gsr_preprocess_backward turns all-zero rows into
+ *   gsr_view_message_plan_blend   the same plan from what gsr_blend_backward ALONE leaves behind -- its accumulator table
+ *                                 `acc` (P, GSR_ACC_ROW): a Gaussian no pixel
+ *                                 blended has an all-zero row there, and gsr_preprocess_backward turns all-zero rows into
  *                                 all-zero gradients, so this mask is a superset of gsr_view_message_plan's (a row it
  *                                 adds carries zeros: the sums do not change).  It never blocks; the count is the uint64 at
  *                                 the start of `workspace`.  Purpose: the ranks can exchange their counts and the host can
@@ -385,8 +403,7 @@ typedef struct gsr_dense_grads {
 int gsr_view_message_words(int64_t P, int64_t cap, int64_t* words);
 int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
                           void* workspace, int64_t* count_host);
-int gsr_view_message_plan_blend(void* stream, int64_t P, const float* dL_dmeans2D, const float* dL_dconic,
-                                const float* dL_dopacity, const float* dL_dcolors, uint8_t* mask, void* workspace);
+int gsr_view_message_plan_blend(void* stream, int64_t P, const float* acc, uint8_t* mask, void* workspace);
 int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
                           const uint8_t* mask, void* workspace, int64_t cap, float* message);
 int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,
@@ -462,9 +479,8 @@ int gsr_debug_export_image(void* stream, int W, int H, const void* image, uint32
 /* The same for K7: one record of 8 x u64 per 4-wave workgroup: {start, end, XCC_ID<<32 | HW_ID, tiles<<32 | forward work
  * estimate of those tiles, longest tile (ticks), first tile (ticks), 0, 0}.  Arguments as gsr_blend_backward. */
 int gsr_debug_blend_backward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                                     const void* binning, const void* image, const float* dL_dpix, float* dL_dmeans2D,
-                                     float* dL_dconic, float* dL_dopacity, float* dL_dcolors, uint64_t* records,
-                                     int64_t max_records, int64_t* n_records_host);
+                                     const void* binning, const void* image, const float* dL_dpix, float* acc,
+                                     uint64_t* records, int64_t max_records, int64_t* n_records_host);
 int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                                     const void* binning, void* image, float* out_color, float* out_depth,
                                     uint64_t* records, int64_t max_records, int64_t* n_records_host);

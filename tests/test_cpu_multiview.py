@@ -58,10 +58,10 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
             touched_of = []
             orig = allreduce_view_grads.__globals__["_C"].view_message_plan_blend
 
-            def spy(acc4):  # the whole step plans from the blend backward's accumulators, between K7 and K8+K9
-                rows_of = torch.cat([g.reshape(P, -1) for g in acc4], dim=1)
-                touched_of.append(float((rows_of != 0).any(dim=1).float().mean()))
-                return orig(acc4)
+            def spy(acc):  # the whole step plans from the blend backward's accumulator table (P,16), between K7 and K8+K9
+                assert tuple(acc.shape) == (P, 16)
+                touched_of.append(float((acc != 0).any(dim=1).float().mean()))
+                return orig(acc)
 
             mpatch.setattr(allreduce_view_grads.__globals__["_C"], "view_message_plan_blend", spy)
             params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}
@@ -216,22 +216,16 @@ def test_bucket_layout_and_allocator():
     assert v is b.views["means2D"] and float(v.abs().sum()) == 0.0 and float(b.views["sh"].sum()) == 8 * 48
     assert b.allocator("sh", (8, 4, 3), False) is None          # shape mismatch -> private tensor
     assert b.allocator("colors_precomp", (8, 3), True) is None  # not a parameter gradient
-    # the two atomically accumulated gradients are adjacent: one fill clears both
+    # the blend backward's accumulator table (16 floats per Gaussian, include/gsr.h GSR_ACC_*): the bucket's own workspace,
+    # 64-byte aligned, outside the exchanged buffer; asking for it opens a backward
     b.flat.fill_(1.0)
-    m2, op = b.allocator("means2D+opacities", (32,), True)
-    assert m2.data_ptr() == b.views["means2D"].data_ptr() and op.data_ptr() == b.views["opacities"].data_ptr()
-    assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
-    # ... and so are the backward's two internal accumulators, behind the exchanged part: one fill for all four
-    b.flat.fill_(1.0)
-    m2, op, conic, cols = b.allocator("accumulators", (88,), True)
-    assert m2.data_ptr() == b.views["means2D"].data_ptr() and op.data_ptr() == b.views["opacities"].data_ptr()
-    assert tuple(conic.shape) == (8, 4) and tuple(cols.shape) == (8, 3) and conic.data_ptr() % 16 == 0
-    assert conic.data_ptr() == op.data_ptr() + 4 * 8 and cols.data_ptr() == conic.data_ptr() + 4 * 32
-    assert float(m2.abs().sum()) == float(op.abs().sum()) == 0.0 and float(b.views["rotations"].sum()) == 32
-    conic.fill_(2.0)
-    cols.fill_(3.0)
-    assert float(b.flat.sum()) == float(b.flat.numel() - 32)  # the internal accumulators are not part of the exchanged buffer
-    assert b.allocator("accumulators", (87,), True) is None
+    acc = b.allocator("acc_rows", (128,), False)
+    assert acc.numel() == 128 and acc.data_ptr() % 64 == 0 and acc.dtype == torch.float32
+    lo, hi = b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.flat.numel()
+    assert not (lo <= acc.data_ptr() < hi)
+    acc.fill_(2.0)
+    assert float(b.flat.sum()) == float(b.flat.numel())
+    assert b.allocator("acc_rows", (127,), False) is None
     # P % 4 != 0: every segment still starts on a 16-byte boundary (padding words between the segments), so the
     # backward's gradients always ARE the bucket's segments -- a bucket that handed out None here lost them silently
     for P_ in (1, 5, 6, 7, 1201):
@@ -239,12 +233,7 @@ def test_bucket_layout_and_allocator():
         for name, v in b2.views.items():
             assert v.data_ptr() % 16 == 0, (P_, name)
             assert b2.allocator(name, tuple(v.shape), False) is v
-        b2.flat.fill_(1.0)
-        m2, op = b2.allocator("means2D+opacities", (4 * P_,), True)
-        assert float(m2.abs().sum()) == 0.0 and float(op.abs().sum()) == 0.0
-        assert float(b2.views["rotations"].sum()) == 4 * P_ and float(b2.views["means3D"].sum()) == 3 * P_
-        four = b2.allocator("accumulators", (11 * P_,), True)
-        assert four[2].data_ptr() % 16 == 0 and tuple(four[2].shape) == (P_, 4) and tuple(four[3].shape) == (P_, 3)
+        assert b2.allocator("acc_rows", (16 * P_,), False).numel() == 16 * P_
         b3 = GradBucket(P_, 16, "cpu", sh_exchange="rgb")
         assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
         # the two opt-in row masks: absent by default; persistent rows start out "may hold anything" and return there
@@ -253,13 +242,13 @@ def test_bucket_layout_and_allocator():
         assert b4.row_valid.dtype == b4.row_state.dtype == torch.uint8 and int(b4.row_state.min()) == int(b4.row_valid.min()) == 1
         # the state is only handed out in a backward whose gradients were all answered with the bucket's own tensors
         assert b4.allocator("row_state", (P_,), False) is None
-        b4.allocator("accumulators", (11 * P_,), False)
-        for nm in ("means3D", "scales", "rotations"):
+        b4.allocator("acc_rows", (16 * P_,), False)
+        for nm in ("means2D", "opacities", "means3D", "scales", "rotations"):
             assert b4.allocator(nm, tuple(b4.views[nm].shape), False) is b4.views[nm]
         assert b4.allocator("row_state", (P_,), False) is None  # (the SH / colour gradient is missing)
         assert b4.allocator("sh", (P_, 16, 3), False) is b4.views["sh"]
         assert b4.allocator("row_state", (P_,), False) is b4.row_state and b4.allocator("row_state", (P_ + 1,), False) is None
-        b4.allocator("accumulators", (11 * P_,), False)  # the next backward starts from nothing again
+        b4.allocator("acc_rows", (16 * P_,), False)  # the next backward starts from nothing again
         assert b4.allocator("row_state", (P_,), False) is None
         b4.row_state.zero_()
         b4.invalidate_rows()

@@ -36,8 +36,8 @@ R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
 L = _native.lib()
 s = torch.cuda.current_stream(dev).cuda_stream
 G = seed_gradient(H, W, 0).to(dev)
-z = torch.zeros(P * 11, device=dev)
-ptrs = [z[:3 * P].data_ptr(), z[7 * P:].data_ptr(), z[6 * P:7 * P].data_ptr(), z[3 * P:6 * P].data_ptr()]
+z = torch.zeros(P * _native.ACC_ROW, device=dev)  # the blend backward's accumulator table (include/gsr.h: GSR_ACC_*)
+ptrs = [z.data_ptr()]
 n = ctypes.c_int64(0)
 L.gsr_debug_blend_backward_profile(s, P, R, W, H, bg.data_ptr(), geom.data_ptr(), binning.data_ptr(), img.data_ptr(),
                                    G.data_ptr(), *ptrs, 1, 0, ctypes.byref(n))
