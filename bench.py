@@ -62,8 +62,10 @@ def algorithmic_bytes(P, V, R, N, T, M):
 def compulsory_bytes(P, V, R, N, T, M):
     """The same model with the blend stages' per-instance terms put right: a Gaussian's 48-byte gather
     record has to cross the HBM interface once per VIEW, not once per (tile, Gaussian) instance, and its reduced gradient
-    (the four accumulators, 44 B) is written once per visible Gaussian -- an instance costs only its 4-byte list entry.
-    With section 8(d)'s figures a deep-tile scene (R = 49 x V) reported a fraction above 1 of the HBM peak."""
+    (its accumulator row: nine floats that matter of a 64-byte line) is written once per visible Gaussian -- an instance
+    costs only its 4-byte list entry.  With section 8(d)'s figures a deep-tile scene (R = 49 x V) reported a fraction above
+    1 of the HBM peak.  (The 44 is kept from rounds 3-5 -- 11 floats in four arrays -- so that the fraction stays comparable
+    across rounds; the row the kernels move since round 6 is 64 bytes.)"""
     b = algorithmic_bytes(P, V, R, N, T, M)
     b["blend_forward"] = 4 * R + 48 * V + 24 * N
     b["blend_backward"] = 20 * N + 4 * R + (48 + 44) * V
@@ -142,8 +144,10 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
         color = torch.empty((3, H, W), device=dev)
         depth = torch.empty((1, H, W), device=dev)
         if backward:
-            z = torch.empty(P * 11, device=dev)  # (cleared by the blend backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does)
-            d_m2, d_col, d_op, d_con = z[:3 * P], z[3 * P:6 * P], z[6 * P:7 * P], z[7 * P:]
+            # the blend backward's accumulator table, one 64-byte row per Gaussian (include/gsr.h: GSR_ACC_*; cleared by the blend
+            # backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does); dL_dmeans2D / dL_dopacity leave through K8+K9
+            acc_rows = torch.empty(P * _native.ACC_ROW, device=dev)
+            d_m2, d_op = torch.empty(P * 3, device=dev), torch.empty(P, device=dev)
             d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
             d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(names) + 1)]
@@ -162,13 +166,14 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
         _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
         ev[3].record(s)
         if backward:
-            _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(d_m2),
-                                                      p(d_con), p(d_op), p(d_col), flags | 4))
+            _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc_rows),
+                                                      flags | 4))
             ev[4].record(s)
             _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
                                                            p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
-                                                           p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom), p(d_m2),
-                                                           p(d_con), p(d_col), p(d_m3), p(d_cov), p(d_sh), p(d_sc), p(d_rot)))
+                                                           p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom),
+                                                           p(acc_rows), p(d_m2), p(d_op), None, p(d_m3), p(d_cov), p(d_sh), p(d_sc),
+                                                           p(d_rot)))
             ev[5].record(s)
         torch.cuda.synchronize(dev)
         if it >= 2:

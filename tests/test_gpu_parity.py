@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import hip_state, make_case, oracle_backward, oracle_forward, rel_err, seed_gradient, settings
+from helpers import assert_grads_close, hip_state, make_case, oracle_backward, oracle_forward, rel_err, seed_gradient, settings
 
 pytestmark = pytest.mark.gpu
 
@@ -143,6 +143,7 @@ def test_backward_vs_oracle(oracle, P, W, H, s0, seed):
         e = rel_err(v, g[k].reshape(v.shape))
         print(k, "rel err", e)
         assert e <= 1e-5, k
+    assert_grads_close(h, g, tag="product vs oracle")  # (+ the per-row bar: a small row must not be grossly wrong)
 
 
 def test_backward_precomp_paths(oracle):
@@ -340,6 +341,7 @@ def test_random_configuration_sweep(oracle, seed):
     h = _grads_hip(case, G, scale_modifier=sm)
     for k, v in h.items():
         assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, (k, P, W, H, D, sm)
+    assert_grads_close(h, g, tag=f"sweep seed {seed}")  # (+ the per-row bar)
 
 
 def test_degenerate_inputs(oracle):

@@ -133,7 +133,10 @@ def test_product_vs_reference_nofma_integers():
 
 
 @pytest.mark.parametrize("P,W,H,s0,C,big", [(6000, 256, 256, 0.04, 1, False), (20000, 512, 512, 0.02, 3, False),
-                                            (20000, 512, 512, 0.02, 2, False), (1_000_000, 1920, 1088, 0.01, 1, True)])
+                                            (20000, 512, 512, 0.02, 2, False), (1_000_000, 1920, 1088, 0.01, 1, True),
+                                            # the exact workload of bench.py's C3 / C5 entries (round 6): 1 M Gaussians through the
+                                            # editor's 512 x 512 image, SPLIT items + list segments together
+                                            (1_000_000, 512, 512, 0.01, 1, True)])
 def test_apply_weights_vs_reference(oracle, P, W, H, s0, C, big):
     """K11+K12 against the reference's own apply_weights.cu (contraction-free build), C = 1, 2, 3 and at the headline size
     (1088 rows: the reference reads image_weights out of bounds unless both sides are multiples of 16).  `cnt` is an

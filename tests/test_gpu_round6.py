@@ -257,3 +257,29 @@ def test_every_tensor_argument_is_device_checked():
     if torch.cuda.device_count() > 1:  # a cross-device argument (only where two GPUs are visible)
         with pytest.raises(RuntimeError, match="`sh` is on cuda:1"):
             call(shs=f.to("cuda:1"))
+
+
+# ---- full-size parity beyond ring view 0 and beyond 1080p ---------------------------------------------------
+@pytest.mark.parametrize("view", range(1, 8))
+def test_three_way_parity_headline_every_ring_view(oracle, view):
+    """BASELINE configs[3] is EIGHT views of the 1 M-Gaussian scene at 1920x1080; rounds 2-5 pinned view 0 only.  The other
+    seven, three ways: the reference's own kernels (contraction-free gfx950 build) == oracle == product -- integers and lists
+    bit for bit, images / depth / every gradient within 1e-5 incl. the per-row bar (test_gpu_round2.three_way)."""
+    from helpers import seed_gradient
+    from test_gpu_round2 import three_way
+
+    case = make_case(1_000_000, 1920, 1080, seed=0, s0=0.01, view=view, nviews=8, bg=(0.0, 0.0, 0.0))
+    three_way(oracle, case, seed_gradient(1080, 1920, view), 3)
+
+
+def test_three_way_parity_edit_loop_workload_1M_at_512(oracle):
+    """The exact workload of `extra_configs.C3_edit_loop_512_1M` / `C5_apply_weights...`: 1 M Gaussians seen through the
+    editor's 512 x 512 image (K12 on the same workload: tests/test_gpu_reference.py::test_apply_weights_vs_reference)
+    -- ~2 250 list entries per tile, so the forward's SPLIT items (a quadrant cut into 2 or 4 items:
+    1 024 tiles for 4 096 persistent waves) and its checkpoints / the backward's list segments are live TOGETHER, which no
+    smaller case exercises at this density."""
+    from helpers import seed_gradient
+    from test_gpu_round2 import three_way
+
+    case = make_case(1_000_000, 512, 512, seed=0, s0=0.01, view=0, nviews=8, bg=(0.0, 0.0, 0.0))
+    three_way(oracle, case, seed_gradient(512, 512, 0), 3)
