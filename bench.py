@@ -136,6 +136,10 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
     p = lambda t: t.data_ptr()  # noqa: E731
     op_flat = params["opacity"].contiguous()
     R = V = pix_inst = 0
+    # the blend backward's accumulator table, one 64-byte row per Gaussian (include/gsr.h: GSR_ACC_*), kept across the
+    # iterations as the binding keeps it across backwards: zero on entry, left zero again by K8+K9 (GSR_FLAG_ACC_SELF_CLEAN);
+    # dL_dmeans2D / dL_dopacity leave through K8+K9
+    acc_rows = torch.zeros(P * _native.ACC_ROW, device=dev) if backward else None
     for it in range(iters + 2):
         gb, _, ib = _native.scratch_sizes(P, 0, W, H)
         geom = torch.empty(gb, dtype=torch.uint8, device=dev)
@@ -144,9 +148,6 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
         color = torch.empty((3, H, W), device=dev)
         depth = torch.empty((1, H, W), device=dev)
         if backward:
-            # the blend backward's accumulator table, one 64-byte row per Gaussian (include/gsr.h: GSR_ACC_*; cleared by the blend
-            # backward itself: GSR_FLAG_CLEAR_GRADS, as the binding does); dL_dmeans2D / dL_dopacity leave through K8+K9
-            acc_rows = torch.empty(P * _native.ACC_ROW, device=dev)
             d_m2, d_op = torch.empty(P * 3, device=dev), torch.empty(P, device=dev)
             d_m3, d_cov = torch.empty(P * 3, device=dev), torch.empty(P * 6, device=dev)
             d_sh, d_sc, d_rot = torch.empty(P * M * 3, device=dev), torch.empty(P * 3, device=dev), torch.empty(P * 4, device=dev)
@@ -167,13 +168,13 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
         ev[3].record(s)
         if backward:
             _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc_rows),
-                                                      flags | 4))
+                                                      flags))
             ev[4].record(s)
             _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
                                                            p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
                                                            p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom),
                                                            p(acc_rows), p(d_m2), p(d_op), None, p(d_m3), p(d_cov), p(d_sh), p(d_sc),
-                                                           p(d_rot)))
+                                                           p(d_rot), 32))
             ev[5].record(s)
         torch.cuda.synchronize(dev)
         if it >= 2:

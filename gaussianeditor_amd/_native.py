@@ -59,9 +59,9 @@ SIGNATURES = {
                              _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags)
     "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
-    # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots)
+    # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots, flags)
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
-                                        c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                        c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_drgb, dL_dscales, dL_drots)
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                             c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

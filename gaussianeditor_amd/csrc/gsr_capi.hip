@@ -497,7 +497,7 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
                        const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags) {
   // (a backward of a view whose forward was declared forward-only: the flags of one view travel together)
-  if ((flags & ~GSR_FLAG_ALL) || (flags & GSR_FLAG_FORWARD_ONLY)) return GSR_ERR_BAD_ARGUMENT;
+  if ((flags & ~GSR_FLAG_ALL) || (flags & (GSR_FLAG_FORWARD_ONLY | GSR_FLAG_ACC_SELF_CLEAN))) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0) return GSR_OK;
   if (P < 0 || !acc || ((uintptr_t)acc & 63u)) return GSR_ERR_BAD_ARGUMENT;  // (a row must not straddle two 64-byte lines)
   if (R == 0) {  // nothing to blend: the accumulator rows stay zero -- or become zero
@@ -528,7 +528,8 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
                                     const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
                                     const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
                                     float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                                    float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state = nullptr) {
+                                    float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state = nullptr,
+                                    bool self_clean = false) {
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
@@ -557,6 +558,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   pa.dL_dscale = scales ? dL_dscales : nullptr;
   pa.dL_drot = scales ? dL_drots : nullptr;
   pa.row_state = row_state;
+  pa.acc_clean = self_clean ? const_cast<float*>(acc) : nullptr;  // (GSR_FLAG_ACC_SELF_CLEAN: the caller's table, writable by contract)
   GSR_HIP(launch_preprocess_backward((hipStream_t)stream, pa));
   return GSR_OK;
 }
@@ -591,13 +593,15 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                             const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                            const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                            const void* geom, float* acc, float* dL_dmeans2D, float* dL_dopacity,
                             float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                            float* dL_dscales, float* dL_drots) {
+                            float* dL_dscales, float* dL_drots, unsigned flags) {
   if (shs && !dL_dsh) return GSR_ERR_BAD_ARGUMENT;
+  if (flags & ~GSR_FLAG_ACC_SELF_CLEAN) return GSR_ERR_BAD_ARGUMENT;  // (the one flag this half reads)
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                   viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
-                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, nullptr, dL_dscales, dL_drots);
+                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, nullptr, dL_dscales, dL_drots, nullptr,
+                                  (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0);
 }
 
 int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
@@ -728,11 +732,14 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
   (void)colors_precomp;  // the blend kernels read the colour copy held in the geometry records
   if (P == 0) return GSR_OK;
   if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
-  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags);
+  const bool self_clean = (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0;
+  if (self_clean && (flags & GSR_FLAG_CLEAR_GRADS)) return GSR_ERR_BAD_ARGUMENT;
+  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags & ~GSR_FLAG_ACC_SELF_CLEAN);
   if (st != GSR_OK) return st;
   return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
-                                 dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots);
+                                 dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots,
+                                 self_clean ? GSR_FLAG_ACC_SELF_CLEAN : 0u);
 }
 
 int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

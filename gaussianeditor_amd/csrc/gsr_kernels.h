@@ -45,6 +45,7 @@ struct PreBwdArgs {
   const float* campos;
   float h_x, h_y, tan_fovx, tan_fovy;
   const float* acc;         // (P, ACC_ROW): the blend backward's accumulator rows (dL_dmean2D, dL_dopacity, dL_dconic, dL_dcolor)
+  float* acc_clean;         // == acc (GSR_FLAG_ACC_SELF_CLEAN: rows that are not zero are put back to zero) | null
   float* dL_dmean2D;        // (P,3) out: columns ACC_MEAN2D .. + 1 of the rows, z = 0
   float* dL_dopacity;       // (P)   out: column ACC_OPACITY
   float* dL_dcolor;         // (P,3) out | null: columns ACC_COLOR .. + 2 (the gradient of colors_precomp)

@@ -573,9 +573,34 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   // The Gaussian's accumulator row (round 6: K7 adds into ONE 64-byte row per Gaussian, gsr_common.h ACC_*): requested for
   // every thread, visible or not -- the screen-space and opacity gradients leave through this kernel now (K7 used to add
   // into the caller's arrays directly), and a Gaussian without a pixel has an all-zero row.
-  const float4* const acc_row = reinterpret_cast<const float4*>(a.acc + (size_t)idx * ACC_ROW);
-  const float4 acc_m2d = acc_row[ACC_MEAN2D / 4];  // dL_dmean2D.x, .y, (0), dL_dopacity
-  const float4 acc_col = acc_row[ACC_COLOR / 4];   // dL_dcolor r, g, b, (0)
+  // (streaming loads: a row is read exactly once, and kept out of the caches it would push out the parameters K1 streams
+  //  again at the start of the next iteration -- as the SH-gradient rows' streaming stores do in the other direction)
+#ifndef GSR_K9_NT_ACC
+#define GSR_K9_NT_ACC 1
+#endif
+  typedef float acc_f4 __attribute__((ext_vector_type(4)));
+  const acc_f4* const acc_row = reinterpret_cast<const acc_f4*>(a.acc + (size_t)idx * ACC_ROW);
+#if GSR_K9_NT_ACC
+#define K9_ACC_LD(i) __builtin_nontemporal_load(acc_row + (i))
+#else
+#define K9_ACC_LD(i) acc_row[i]
+#endif
+  const acc_f4 acc_m2d_ = K9_ACC_LD(ACC_MEAN2D / 4), acc_col_ = K9_ACC_LD(ACC_COLOR / 4), acc_con_ = K9_ACC_LD(ACC_CONIC / 4);
+#undef K9_ACC_LD
+  const float4 acc_m2d = make_float4(acc_m2d_.x, acc_m2d_.y, acc_m2d_.z, acc_m2d_.w);  // dL_dmean2D.x, .y, (0), dL_dopacity
+  const float4 acc_col = make_float4(acc_col_.x, acc_col_.y, acc_col_.z, acc_col_.w);  // dL_dcolor r, g, b, (0)
+  const float4 acc_con = make_float4(acc_con_.x, acc_con_.y, acc_con_.z, acc_con_.w);  // dL_dconic x, y, (0), w
+  if (a.acc_clean != nullptr && live) {
+    // GSR_FLAG_ACC_SELF_CLEAN: the table is the caller's across backwards -- a row K7 touched (one in ten on the benchmark
+    // view) goes back to zero here, whole 64-byte lines, so that the next backward starts from a zero table without a clear
+    const bool dirty = !(acc_m2d.x == 0.f) || !(acc_m2d.y == 0.f) || !(acc_m2d.w == 0.f) || !(acc_con.x == 0.f) ||
+                       !(acc_con.y == 0.f) || !(acc_con.w == 0.f) || !(acc_col.x == 0.f) || !(acc_col.y == 0.f) || !(acc_col.z == 0.f);
+    if (dirty) {
+      float4* const w = reinterpret_cast<float4*>(a.acc_clean + (size_t)idx * ACC_ROW);
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      w[0] = z; w[1] = z; w[2] = z; w[3] = z;
+    }
+  }
 
   if (live && a.radii[idx] > 0) {
     Cam cam;
@@ -594,7 +619,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       sc2 = a.scales[3 * idx + 2];
       quat = reinterpret_cast<const float4*>(a.rotations)[idx];
     }
-    const float4 gc = acc_row[ACC_CONIC / 4];  // (the row's three float4 were requested above, in front of the branch)
+    const float4 gc = acc_con;  // (the row's three float4 were requested above, in front of the branch)
     const float g2x = acc_m2d.x, g2y = acc_m2d.y;
     V3 dRGBdx = {0.f, 0.f, 0.f}, dRGBdy = {0.f, 0.f, 0.f}, dRGBdz = {0.f, 0.f, 0.f}, dL_dRGB = {0.f, 0.f, 0.f};
     uint8_t cl = 0;
@@ -814,10 +839,16 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   K9_ST(&a.dL_dmeans3D[3 * (size_t)idx + 2], dmean.z);
   // the two gradients K7 accumulates for the caller (backward.cu:545-546, 554) and, with precomputed colours, the colour's
   // (:523): copied out of the accumulator row (a Gaussian that is not visible has a zero row: K7 never touched it)
-  K9_ST(&a.dL_dmean2D[3 * (size_t)idx], acc_m2d.x);
-  K9_ST(&a.dL_dmean2D[3 * (size_t)idx + 1], acc_m2d.y);
-  K9_ST(&a.dL_dmean2D[3 * (size_t)idx + 2], 0.f);
-  K9_ST(&a.dL_dopacity[idx], acc_m2d.w);
+#if GSR_K9_NT_ACC
+#define K9_ST2(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define K9_ST2(p, v) K9_ST(p, v)
+#endif
+  K9_ST2(&a.dL_dmean2D[3 * (size_t)idx], acc_m2d.x);
+  K9_ST2(&a.dL_dmean2D[3 * (size_t)idx + 1], acc_m2d.y);
+  K9_ST2(&a.dL_dmean2D[3 * (size_t)idx + 2], 0.f);
+  K9_ST2(&a.dL_dopacity[idx], acc_m2d.w);
+#undef K9_ST2
   if (a.dL_dcolor != nullptr) {
     K9_ST(&a.dL_dcolor[3 * (size_t)idx], acc_col.x);
     K9_ST(&a.dL_dcolor[3 * (size_t)idx + 1], acc_col.y);

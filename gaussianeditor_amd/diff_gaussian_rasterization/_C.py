@@ -177,6 +177,22 @@ def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binnin
     return out
 
 
+#: The blend backward's accumulator table kept ACROSS backwards (GSR_FLAG_ACC_SELF_CLEAN, include/gsr.h): one zeroed (P,16)
+#: buffer per (device, stream), checked out for the duration of a backward's two native calls and put back only when both were
+#: enqueued -- K8+K9 leaves it all zero again in stream order, so the next backward on that stream needs no clear (64 MB in
+#: front of every backward at 10^6 Gaussians: 8 of the 14 us of K7's work-list launch).  A backward that fails between the two
+#: calls simply does not return its table.  GSR_ACC_PERSIST=0 turns it off (every backward then clears a fresh table).
+_ACC_TABLES = {}
+_ACC_PERSIST = __import__("os").environ.get("GSR_ACC_PERSIST", "1") != "0"
+
+
+def _checkout_acc(dev, stream: int, P: int):
+    t = _ACC_TABLES.pop((dev.index, stream), None)
+    if t is not None and t.numel() == _native.ACC_ROW * P:
+        return t
+    return torch.zeros((_native.ACC_ROW * P,), dtype=torch.float32, device=dev)  # (dropped: another P -- a densification)
+
+
 def _alloc(fn, name: str, shape, zero: bool, dev) -> torch.Tensor:
     if fn is not None:
         t = fn(name, tuple(shape), zero)
@@ -234,8 +250,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     acc = grad_alloc("acc_rows", (_native.ACC_ROW * P,), False) if grad_alloc is not None else None
     if not (isinstance(acc, torch.Tensor) and acc.dtype == torch.float32 and acc.numel() == _native.ACC_ROW * P
             and acc.device == dev and acc.is_contiguous() and acc.data_ptr() % 64 == 0):
-        acc = torch.empty((_native.ACC_ROW * P,), dtype=torch.float32, device=dev)
-    acc = acc.view(P, _native.ACC_ROW)
+        acc = None
     dL_dmeans2D = _alloc(grad_alloc, "means2D", (P, 3), False, dev)
     dL_dopacity = _alloc(grad_alloc, "opacities", (P, 1), False, dev)
     # the gradient of colors_precomp (rasterize_points.cu:133): written only for a caller that passed colours; with SHs the
@@ -243,7 +258,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     has_colors = colors.numel() != 0
     # (zeros, not empty, under an allocator: its "row_state" mode leaves rows that are zero again unwritten)
     dL_dcolors = (torch.zeros if grad_alloc is not None else torch.empty)((P, NUM_CHANNELS), dtype=torch.float32, device=dev) \
-        if has_colors else acc[:, _native.ACC_COLOR:_native.ACC_COLOR + NUM_CHANNELS]
+        if has_colors else None  # (with SHs: set below, once the table is chosen)
     dL_dmeans3D = _alloc(grad_alloc, "means3D", (P, 3), False, dev)
     dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev)
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
@@ -252,11 +267,26 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dsh = None if dL_drgb is not None else _alloc(grad_alloc, "sh", (P, M, 3), M == 0, dev)
     dL_dscales = _alloc(grad_alloc, "scales", (P, 3), not has_scales, dev)
     dL_drotations = _alloc(grad_alloc, "rotations", (P, 4), not has_scales, dev)
-    bwd_flags = flags | options.FLAG_CLEAR_GRADS  # (the accumulator table is not zero: the blend backward clears it)
     row_state = grad_alloc("row_state", (P,), False) if grad_alloc is not None else None
     if row_state is not None and not (isinstance(row_state, torch.Tensor) and row_state.dtype == torch.uint8 and
                                       row_state.numel() == P and row_state.is_contiguous() and row_state.device == dev):
         row_state = None
+    # Which table?  The plain route (gsr_backward, nobody reads the table between K7 and K8+K9) uses the one kept across
+    # backwards on this stream: zero on entry, zeroed again by K8+K9 -- no clear.  The exchange routes hand the table to a
+    # side stream between the two kernels (after_blend_backward): a fresh table, cleared by K7's own launch.
+    stream = _stream(dev)
+    persist = _ACC_PERSIST and acc is None and row_state is None and dL_drgb is None
+    if persist:
+        acc = _checkout_acc(dev, stream, P)
+        bwd_flags = flags | options.FLAG_ACC_SELF_CLEAN
+    else:
+        if acc is None:
+            acc = torch.empty((_native.ACC_ROW * P,), dtype=torch.float32, device=dev)
+        bwd_flags = flags | options.FLAG_CLEAR_GRADS  # (the table is not zero: the blend backward clears it)
+    acc = acc.view(P, _native.ACC_ROW)
+    if not has_colors:
+        dL_dcolors = acc[:, _native.ACC_COLOR:_native.ACC_COLOR + NUM_CHANNELS] if not persist else \
+            torch.zeros((0, NUM_CHANNELS), dtype=torch.float32, device=dev)
     L = _native.lib()
     with torch.cuda.device(dev):
         col_out = dL_dcolors.data_ptr() if has_colors else None
@@ -300,6 +330,8 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None))
         if debug:
             torch.cuda.synchronize(dev)
+    if persist:  # both halves are enqueued: in stream order the table is all zero again
+        _ACC_TABLES[(dev.index, stream)] = acc.view(-1)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -86,8 +86,8 @@ class GradBucket:
     = (14 + 3M) * P floats (248 MB at P = 1M, M = 16), every segment START rounded up to a multiple of 4 floats:
     the kernels use dwordx4 accesses on (P,4) / (P,M,3) rows, so a segment must begin on a 16-byte boundary whatever
     P is (P is arbitrary after a densification or a prune; the padding words stay zero and travel with the all-reduce).
-    The blend backward's accumulator table (16 floats per Gaussian, include/gsr.h GSR_ACC_*) is a buffer of the bucket's own
-    next to `flat`: workspace, never exchanged (means2D / opacities are copied out of it by K8+K9)."""
+    (The blend backward's accumulator table -- 16 floats per Gaussian, include/gsr.h GSR_ACC_* -- is workspace of the binding,
+    not of the bucket: means2D / opacities are copied out of it by K8+K9.)"""
 
     def __init__(self, P: int, M: int, device, sh_exchange: str = "auto", sparse_rows: bool = False,
                  persistent_rows: bool = False):
@@ -119,9 +119,6 @@ class GradBucket:
             off = _pad4(off + int(torch.Size(shapes[name]).numel()))
         self._buf = torch.zeros(off, dtype=torch.float32, device=device)
         self.flat = self._buf[:off]
-        # the blend backward's accumulator table ("acc_rows" request below): one 64-byte row per Gaussian, cleared by the
-        # backward itself (GSR_FLAG_CLEAR_GRADS); not part of `flat`, never travels
-        self._acc = torch.empty(16 * int(P), dtype=torch.float32, device=device)
         if self.flat.data_ptr() % 16 != 0:  # (torch's allocators hand out >= 256-byte alignment; be explicit anyway)
             raise RuntimeError("GradBucket: the flat buffer is not 16-byte aligned")
         self.views: Dict[str, torch.Tensor] = {}
@@ -182,9 +179,9 @@ class GradBucket:
             if ok:
                 self._handed.add("sh_rgb")
             return self.rgb if ok else None
-        if name == "acc_rows":  # (the first request of a backward) the blend backward's accumulator table: workspace
-            self._handed = set()
-            return self._acc if tuple(shape) == (16 * self.P,) and self._acc.data_ptr() % 64 == 0 else None
+        if name == "acc_rows":  # (the first request of a backward) the blend backward's accumulator table: the binding's own
+            self._handed = set()  # -- kept across backwards and left zero by K8+K9 where nothing reads it in between
+            return None
         v = self.views.get(name)
         if v is None or tuple(v.shape) != tuple(shape):
             return None

@@ -17,6 +17,7 @@ FLAG_ALL = 3             # the behaviour switches a caller may set
 FLAG_CLEAR_GRADS = 4     # (internal to the binding: the backward clears its accumulators itself; include/gsr.h)
 FLAG_FORWARD_ONLY = 8    # (internal to the binding: a render none of whose inputs requires a gradient)
 FLAG_SHARED_SIMDS = 16   # (set by multiview_batch_step for a rank's pipelined views: 2 persistent blend waves per SIMD)
+FLAG_ACC_SELF_CLEAN = 32  # (internal to the binding: the backward's accumulator table is kept across calls and left zero by K8+K9)
 
 _default = 0
 _local = threading.local()

@@ -135,6 +135,13 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *                        bar, but a pixel whose alpha or transmittance sits within a rounding of a threshold
  *                        (1/255, 1e-4) may take the other branch than the CPU oracle, so n_contrib / final_T are no
  *                        longer bit-identical to it (they are not bit-identical to the reference's libm build either).
+ *   GSR_FLAG_ACC_SELF_CLEAN (ABI 5; read by gsr_backward / gsr_preprocess_backward) the accumulator table `acc` is one the caller KEEPS between
+ *       backwards: it is all zero on entry (the caller's promise -- hipMemset it once) and all zero again when the call has
+ *       run: K8+K9, which reads every row anyway, writes zeros over the rows K7 touched (one Gaussian in ten on the
+ *       benchmark view: 6 MB instead of a 64 MB clear in front of every backward).  Not combined with GSR_FLAG_CLEAR_GRADS
+ *       (which it makes unnecessary).  With the two halves called separately: gsr_blend_backward WITHOUT GSR_FLAG_CLEAR_GRADS
+ *       on the zero table, then gsr_preprocess_backward with this flag.  A caller that reads `acc` between the two halves
+ *       on ANOTHER stream (gsr_view_message_plan_blend under K8+K9) must not use it;
  *   GSR_FLAG_SHARED_SIMDS (ABI 4; read by the blend / trace entry points) the caller overlaps this view's kernels with
  *                        another view's on a second stream: the persistent blend kernels are launched with 2 waves per
  *                        SIMD instead of 4, which leaves wave slots and registers for the other stream's kernels (a rank
@@ -146,7 +153,8 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
 #define GSR_FLAG_CLEAR_GRADS 4u
 #define GSR_FLAG_FORWARD_ONLY 8u
 #define GSR_FLAG_SHARED_SIMDS 16u
-#define GSR_FLAG_ALL 31u
+#define GSR_FLAG_ACC_SELF_CLEAN 32u
+#define GSR_FLAG_ALL 63u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);
@@ -246,9 +254,9 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                             const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                            const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                            const void* geom, float* acc, float* dL_dmeans2D, float* dL_dopacity,
                             float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                            float* dL_dscales, float* dL_drots);
+                            float* dL_dscales, float* dL_drots, unsigned flags /* 0 | GSR_FLAG_ACC_SELF_CLEAN */);
 
 /* Multi-GPU exchange support (gaussianeditor_amd/multiview.py).  Per view the SH gradient is
  * rank one, dL_dsh[k] = c_k(dir) * dL_dRGB with dir = normalize(mean - campos) (backward.cu:44-98), so ranks exchange

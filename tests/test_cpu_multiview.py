@@ -216,16 +216,8 @@ def test_bucket_layout_and_allocator():
     assert v is b.views["means2D"] and float(v.abs().sum()) == 0.0 and float(b.views["sh"].sum()) == 8 * 48
     assert b.allocator("sh", (8, 4, 3), False) is None          # shape mismatch -> private tensor
     assert b.allocator("colors_precomp", (8, 3), True) is None  # not a parameter gradient
-    # the blend backward's accumulator table (16 floats per Gaussian, include/gsr.h GSR_ACC_*): the bucket's own workspace,
-    # 64-byte aligned, outside the exchanged buffer; asking for it opens a backward
-    b.flat.fill_(1.0)
-    acc = b.allocator("acc_rows", (128,), False)
-    assert acc.numel() == 128 and acc.data_ptr() % 64 == 0 and acc.dtype == torch.float32
-    lo, hi = b.flat.data_ptr(), b.flat.data_ptr() + 4 * b.flat.numel()
-    assert not (lo <= acc.data_ptr() < hi)
-    acc.fill_(2.0)
-    assert float(b.flat.sum()) == float(b.flat.numel())
-    assert b.allocator("acc_rows", (127,), False) is None
+    # the blend backward's accumulator table is the binding's workspace: asking for it only opens a backward
+    assert b.allocator("acc_rows", (128,), False) is None
     # P % 4 != 0: every segment still starts on a 16-byte boundary (padding words between the segments), so the
     # backward's gradients always ARE the bucket's segments -- a bucket that handed out None here lost them silently
     for P_ in (1, 5, 6, 7, 1201):
@@ -233,7 +225,6 @@ def test_bucket_layout_and_allocator():
         for name, v in b2.views.items():
             assert v.data_ptr() % 16 == 0, (P_, name)
             assert b2.allocator(name, tuple(v.shape), False) is v
-        assert b2.allocator("acc_rows", (16 * P_,), False).numel() == 16 * P_
         b3 = GradBucket(P_, 16, "cpu", sh_exchange="rgb")
         assert all(v.data_ptr() % 16 == 0 for v in b3.views.values()) and b3.allocator("sh_rgb", (P_, 3), False) is b3.rgb
         # the two opt-in row masks: absent by default; persistent rows start out "may hold anything" and return there

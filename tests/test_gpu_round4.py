@@ -48,15 +48,15 @@ def test_backward_on_a_forward_only_state_is_refused():
     P, W, H = 3000, 128, 96
     t, geom, radii = _preprocess(L, case, 8)
     z = lambda *shape: torch.zeros(shape, device=DEV)  # noqa: E731
-    g = dict(m2=z(P, 3), con=z(P, 4), col=z(P, 3), m3=z(P, 3), cov=z(P, 6), sh=z(P, 16, 3), sc=z(P, 3), rot=z(P, 4))
+    g = dict(acc=z(P, 16), m2=z(P, 3), op=z(P, 1), m3=z(P, 3), cov=z(P, 6), sh=z(P, 16, 3), sc=z(P, 3), rot=z(P, 4))
     p = lambda x: x.data_ptr()  # noqa: E731
     s = torch.cuda.current_stream().cuda_stream
 
     def pbw(geom_):
         return L.gsr_preprocess_backward(s, P, 3, 16, W, H, p(t["xyz"]), p(t["sh"]), p(t["sca"]), 1.0, p(t["rot"]), None,
                                          p(t["view"]), p(t["proj"]), p(t["cp"]), case["tfx"], case["tfy"], p(radii), p(geom_),
-                                         p(g["m2"]), p(g["con"]), p(g["col"]), p(g["m3"]), p(g["cov"]), p(g["sh"]), p(g["sc"]),
-                                         p(g["rot"]))
+                                         p(g["acc"]), p(g["m2"]), p(g["op"]), None, p(g["m3"]), p(g["cov"]), p(g["sh"]), p(g["sc"]),
+                                         p(g["rot"]), 0)
 
     assert pbw(geom) == -1
     # a copy of the state elsewhere is (documented) not recognised, and another buffer is unaffected

@@ -283,3 +283,47 @@ def test_three_way_parity_edit_loop_workload_1M_at_512(oracle):
 
     case = make_case(1_000_000, 512, 512, seed=0, s0=0.01, view=0, nviews=8, bg=(0.0, 0.0, 0.0))
     three_way(oracle, case, seed_gradient(512, 512, 0), 3)
+
+
+def test_accumulator_table_kept_across_backwards_is_left_zero():
+    """GSR_FLAG_ACC_SELF_CLEAN: the binding keeps the blend backward's accumulator table between backwards (per device and
+    stream), K8+K9 puts every row K7 touched back to zero, and no clear runs in front of the next backward.  Over a sequence
+    of different views (Gaussians go from touched to untouched and back) every gradient equals the one a freshly cleared
+    table gives, and the kept table is all zero after every backward."""
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer, _C
+
+    P, W, H = 20000, 256, 192
+    sc = make_case(P, W, H, seed=3, s0=0.04)["sc"]
+    leaves = {k: sc[k].to(DEV).requires_grad_(True) for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+    G = torch.rand(3, H, W, generator=torch.Generator().manual_seed(8)).to(DEV)
+
+    def grads(view):
+        case = make_case(P, W, H, seed=3, s0=0.04, view=view, nviews=5)
+        for t in leaves.values():
+            t.grad = None
+        m2 = torch.zeros_like(leaves["xyz"], requires_grad=True)
+        color, _, _ = GaussianRasterizer(settings(case, DEV))(leaves["xyz"], m2, leaves["opacity"], shs=leaves["features"],
+                                                               scales=leaves["scaling"], rotations=leaves["rotation"])
+        (color * G).sum().backward()
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in leaves.values()] + [m2.grad.clone()]
+
+    was = _C._ACC_PERSIST
+    try:
+        _C._ACC_PERSIST = True
+        _C._ACC_TABLES.clear()
+        kept = []
+        for view in (0, 3, 1, 3, 4, 0):
+            kept.append(grads(view))
+            tables = list(_C._ACC_TABLES.values())
+            assert len(tables) == 1 and tables[0].numel() == 16 * P and float(tables[0].abs().max()) == 0.0
+        first = tables[0].data_ptr()
+        _C._ACC_PERSIST = False
+        for view, k in zip((0, 3, 1, 3, 4, 0), kept):
+            fresh = grads(view)
+            for a, b in zip(k, fresh):  # (the backward's float atomics: run-to-run rounding only)
+                assert float(b.abs().max()) > 0 and torch.allclose(a, b, rtol=0, atol=2e-5 * float(b.abs().max()))
+        assert list(_C._ACC_TABLES.values())[0].data_ptr() == first  # (untouched while the option is off)
+    finally:
+        _C._ACC_PERSIST = was
+        _C._ACC_TABLES.clear()
