@@ -45,6 +45,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 MAX_CLOCK_HZ = 2.4e9   # MI355X_MICROARCH.md: max engine clock 2400 MHz (the issue ceiling is priced at it: DVFS runs these kernels
 #                        at ~2.1-2.3 GHz, so the fraction understates the share of the cycles actually clocked)
 STAGES = ("preprocess", "bin", "blend_forward", "blend_backward", "preprocess_backward")
+# Issue ceiling of the blend kernels' instruction mix, MEASURED (round 6; rounds 3-5 priced a VALU instruction at 4 cycles per
+# SIMD, the review of round 5 at 2.1-2.4 from dependent-chain microbenchmarks -- both wrong for this mix): K7's own 4-entry
+# group body as hipcc emits it (299 VALU + 15 SALU + 24 LDS instructions), replayed without memory, barriers or list walk at
+# 4 waves per SIMD on every SIMD of the chip, takes 834.6 cycles per group and SIMD (tools/microbench/k7_group_replay.py,
+# profiles/r06_a_k7_replay.md) = 2.79 cycles per VALU instruction with the scalar / LDS instructions that accompany it.
+ISSUE_CYCLES_PER_VALU = 834.6 / 299.0
 
 
 def algorithmic_bytes(P, V, R, N, T, M):
@@ -117,7 +123,7 @@ def workload_key(P, W, H, s0, scene="v1") -> str:
     return f"synth-v1:{int(P)}:{int(W)}x{int(H)}:s0={float(s0):g}"
 
 
-def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
+def stage_times(dev, params, rs, G, D, flags, iters, backward=True, info=None):
     """Per-stage GPU time of one view through the individual C-ABI calls (HIP events on the launch stream), plus what the
     byte models need: num_rendered R, visible V, and the pixel-instances of the view (sum over tiles of pixels x list length:
     SURVEY.md section 8(d) "flops (secondary)")."""
@@ -180,6 +186,31 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
         if it >= 2:
             for i, k in enumerate(names):
                 acc[k] += ev[i].elapsed_time(ev[i + 1])
+        if it == iters + 1 and backward and info is not None:
+            # K7's critical path: the longest single work item / the span of the launch, from the kernel's own per-item
+            # cycle counts (gsr_debug_blend_backward_profile; a 4-wave workgroup per tile, 1.6 items per workgroup on the
+            # headline view -- a launch cannot end before its longest item does)
+            nrec = ctypes.c_int64(0)
+            L.gsr_debug_blend_backward_profile(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc_rows), 1, 0,
+                                               ctypes.byref(nrec))
+            nwg, Tt = int(nrec.value), ((W + 15) // 16) * ((H + 15) // 16)
+            rec = torch.zeros((nwg + Tt, 8), dtype=torch.int64, device=dev)
+            acc_rows.zero_()
+            _native.check("k7 profile", L.gsr_debug_blend_backward_profile(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img),
+                                                                            p(G), p(acc_rows), p(rec), nwg + Tt, ctypes.byref(nrec)))
+            torch.cuda.synchronize(dev)
+            acc_rows.zero_()  # (the profile launch runs K7 alone: nothing cleans the table behind it)
+            wg = rec[:nwg]
+            livewg = wg[:, 1] > 0
+            if bool(livewg.any()):
+                span = int((wg[livewg, 1].max() - wg[livewg, 0].min()).item())
+                items = rec[nwg:].reshape(-1, 4)[:, 0]
+                longest = int(items.max().item())
+                mean_wg = float((wg[livewg, 1] - wg[livewg, 0]).float().mean().item())
+                info["critical_item_frac"] = longest / max(span, 1)
+                info["mean_workgroup_frac"] = mean_wg / max(span, 1)
+                info["k7_items"] = int((items > 0).sum().item())
+                info["k7_workgroups"] = int(livewg.sum().item())
         if it == iters + 1:
             V = int((radii_t > 0).sum().item())
             T = ((W + 15) // 16) * ((H + 15) // 16)
@@ -192,6 +223,49 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True):
             ph = torch.clamp(H - (t // gx) * 16, max=16)
             pix_inst = int((lens * pw * ph).sum().item())
     return {k: acc[k] / iters for k in names}, R, V, pix_inst
+
+
+def trace_stage_times(dev, params, rs, image_weights, flags, iters):
+    """The three C-ABI calls of one GaussianRasterizer.apply_weights view (preprocessing without colours, binning, K12), HIP
+    events between them -> ({stage: ms}, R)."""
+    import ctypes
+
+    from gaussianeditor_amd import _native
+
+    L = _native.lib()
+    s = torch.cuda.current_stream(dev)
+    sp = s.cuda_stream
+    P, H, W, C = int(params["xyz"].shape[0]), int(rs.image_height), int(rs.image_width), int(image_weights.shape[0])
+    p = lambda t: t.data_ptr()  # noqa: E731
+    op_flat = params["opacity"].contiguous()
+    names = ("preprocess", "bin", "trace_weights")
+    acc, R = {k: 0.0 for k in names}, 0
+    for it in range(iters + 2):
+        gb, _, ib = _native.scratch_sizes(P, 0, W, H)
+        geom = torch.empty(gb, dtype=torch.uint8, device=dev)
+        img = torch.empty(ib, dtype=torch.uint8, device=dev)
+        radii_t = torch.empty(P, dtype=torch.int32, device=dev)
+        w = torch.zeros((P, C), device=dev)
+        cnt = torch.zeros((P,), dtype=torch.int32, device=dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        Rc = (ctypes.c_int64 * 2)()
+        ev[0].record(s)
+        _native.check("pre", L.gsr_preprocess(sp, P, 0, 0, p(params["xyz"]), p(params["scaling"]), 1.0, p(params["rotation"]),
+                                              p(op_flat), None, None, None, p(rs.viewmatrix), p(rs.projmatrix), None, W, H,
+                                              float(rs.tanfovx), float(rs.tanfovy), 0, 1, flags | 8, p(radii_t), p(geom), Rc))
+        ev[1].record(s)
+        R, Gi = int(Rc[0]), int(Rc[1])
+        _, bb, _ = _native.scratch_sizes(P, R, W, H, Gi)
+        binning = torch.empty(bb, dtype=torch.uint8, device=dev)
+        _native.check("bin", L.gsr_bin(sp, P, R, Gi, W, H, p(geom), p(binning), p(img)))
+        ev[2].record(s)
+        _native.check("trace", L.gsr_trace_weights(sp, P, R, W, H, C, p(geom), p(binning), p(img), p(image_weights), p(w), p(cnt), flags))
+        ev[3].record(s)
+        torch.cuda.synchronize(dev)
+        if it >= 2:
+            for i, k in enumerate(names):
+                acc[k] += ev[i].elapsed_time(ev[i + 1])
+    return {k: acc[k] / iters for k in names}, R
 
 
 def load_counters(key):
@@ -211,7 +285,7 @@ def load_counters(key):
     return w, tj.get("source")
 
 
-def roofline_block(stage_ms, ab, cb, dominant, counters, source, dev, pix_inst):
+def roofline_block(stage_ms, ab, cb, dominant, counters, source, dev, pix_inst, info=None):
     """The line's `roofline` object for the stage that takes the most time."""
     t = stage_ms[dominant] * 1e-3
     ach = ab[dominant] / t / 1e9
@@ -236,13 +310,19 @@ def roofline_block(stage_ms, ab, cb, dominant, counters, source, dev, pix_inst):
             out["frac_counter"] = tb / t / 1e9 / HBM_PEAK_GBS
         if vi is not None:
             simds = torch.cuda.get_device_properties(dev).multi_processor_count * 4
-            # a SIMD issues at most one VALU instruction of a wave per 4 cycles (64 lanes over a 16-wide datapath)
-            out["valu_issue_frac"] = vi / (simds * t * MAX_CLOCK_HZ / 4.0)
+            # time the SIMDs would need for these instructions at the measured issue rate of the blend kernels' own mix
+            # (ISSUE_CYCLES_PER_VALU) / the stage's time.  (Rounds 3-5: 4 cycles per instruction -- kept as *_4cycle.)
+            out["valu_issue_frac"] = vi * ISSUE_CYCLES_PER_VALU / (simds * t * MAX_CLOCK_HZ)
+            out["valu_issue_frac_4cycle"] = vi / (simds * t * MAX_CLOCK_HZ / 4.0)
+            out["valu_issue_model"] = (f"{ISSUE_CYCLES_PER_VALU:.2f} cycles per VALU wave-instruction and SIMD: K7's group body "
+                                       "replayed at 4 waves per SIMD (tools/microbench/k7_group_replay.py)")
             out["valu_wave_insts"] = vi
     if dominant in ("blend_forward", "blend_backward"):
         out["limiter"] = ("instruction issue / per-item latency, not HBM: see valu_issue_frac and pixel_instances_per_s "
                           "(DESIGN.md section 3.1)")
         out["pixel_instances_per_s"] = pix_inst / t
+    if info and dominant == "blend_backward":
+        out.update({k: info[k] for k in ("critical_item_frac", "mean_workgroup_frac", "k7_items", "k7_workgroups") if k in info})
     return out
 
 
@@ -323,6 +403,19 @@ def extra_configs(dev, flags, budget_s=60.0):
     out["C3_edit_loop_512_1M_no_reuse"] = {"ms_per_step": 1e3 * t, "what": "the same with GSR_VIEW_REUSE=0: two full renders (rounds 1-5)"}
     t = timed(edit_step_fused, 30, 5)
     out["C3_edit_loop_512_1M_fused_semantic"] = {"ms_per_step": 1e3 * t}
+    # stage times + roofline of ONE 512 x 512 view of this loop (the editor's resolution: the K1 -> K6 chain and K8+K9 are most
+    # of the step here, the blend kernels run as SPLIT items / list segments)
+    rs512 = GaussianRasterizationSettings(512, 512, math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2), bg, 1.0, cam.world_view_transform,
+                                          cam.full_proj_transform, 3, cam.camera_center, False, False)
+    p512 = {k: pc.t[k].detach() for k in ("xyz", "opacity", "features", "scaling", "rotation")}
+    info512 = {}
+    st5, R5, V5, pix5 = stage_times(dev, p512, rs512, G, 3, flags, 10, info=info512)
+    N5, T5 = 512 * 512, 32 * 32
+    ab5, cb5 = algorithmic_bytes(1_000_000, V5, R5, N5, T5, 16), compulsory_bytes(1_000_000, V5, R5, N5, T5, 16)
+    dom5 = max(st5, key=st5.get)
+    out["C3_edit_loop_512_1M"].update({"stage_ms": st5, "num_rendered": R5, "visible": V5,
+                                       "roofline": roofline_block(st5, ab5, cb5, dom5, None, "no PMC pass for this workload", dev,
+                                                                  pix5, info512)})
 
     # ... and with the reference's GaussianModel in front of it: parameters behind activations, so opacity / scaling / rotation
     # are FRESH tensors on every render() (scene/gaussian_model.py:222-258) and reuse has to compare them on the device
@@ -376,6 +469,19 @@ def extra_configs(dev, flags, budget_s=60.0):
 
     t = timed(trace_all, 5, 1)
     out["C5_apply_weights_12views_512_1M"] = {"ms_per_view": 1e3 * t / len(cams), "ms_total": 1e3 * t}
+    rs_tr = GaussianRasterizationSettings(512, 512, math.tan(cams[0].FoVx / 2), math.tan(cams[0].FoVy / 2), zero_bg, 1.0,
+                                          cams[0].world_view_transform, cams[0].full_proj_transform, 0, cams[0].camera_center,
+                                          False, False)
+    st_tr, R_tr = trace_stage_times(dev, p512, rs_tr, masks[0], flags, 10)
+    # (K12 has no byte model in SURVEY.md section 8(d) -- "VALU / atomics" --: the fraction below is its compulsory traffic, the
+    #  4-byte list entries + one 32-byte record pair per visible Gaussian + 4 B per pixel, against the stage's time)
+    out["C5_apply_weights_12views_512_1M"].update({
+        "stage_ms": st_tr, "num_rendered": R_tr,
+        "roofline": {"bound": "hbm", "kernel": "trace_weights", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                     "achieved": (4 * R_tr + 32 * V5 + 4 * 512 * 512) / (st_tr["trace_weights"] * 1e-3) / 1e9,
+                     "frac": (4 * R_tr + 32 * V5 + 4 * 512 * 512) / (st_tr["trace_weights"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": None, "limiter": "instruction issue and memory-side atomics (one per (quadrant, Gaussian) and "
+                                                  "channel), not HBM"}})
     del pc, mask
     torch.cuda.empty_cache()
     # ---- C2: 6 M Gaussians, forward only, 1080p
@@ -430,7 +536,8 @@ def extra_configs(dev, flags, budget_s=60.0):
                 rast(params["xyz"], m2d, params["opacity"], shs=params["features"], scales=params["scaling"], rotations=params["rotation"])
 
         t_fwd = timed(fwd, 100, 10)
-        st, R, V, pix = stage_times(dev, params, rs, G2, 3, flags, 10)
+        v2_info = {}
+        st, R, V, pix = stage_times(dev, params, rs, G2, 3, flags, 10, info=v2_info)
         N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), 16
         ab, cb = algorithmic_bytes(P2, V, R, N, T, M), compulsory_bytes(P2, V, R, N, T, M)
         dom = max(st, key=st.get)
@@ -441,8 +548,29 @@ def extra_configs(dev, flags, budget_s=60.0):
                     "forward, wall clock over 100 iterations each; stage times from HIP events around the C-ABI calls",
             "train_ms_per_step": 1e3 * t_train, "train_iters_per_s": 1.0 / t_train, "forward_ms": 1e3 * t_fwd,
             "forward_mpixels_per_s": N / t_fwd / 1e6, "stage_ms": st, "num_rendered": R, "visible": V,
-            "roofline": roofline_block(st, ab, cb, dom, counters, src, dev, pix)}
+            "roofline": roofline_block(st, ab, cb, dom, counters, src, dev, pix, v2_info)}
         del bucket
+        # ---- the headline iteration through the drop-in route itself: render() (L2) -> GaussianRasterizer (L1 autograd.Function)
+        # -> loss.backward(), i.e. gaussian_renderer/__init__.py:45-150 as an unmodified caller uses it.  The headline `value`
+        # calls the L0 entry points directly (same native calls): this entry says what L1 / L2 + the autograd engine add.
+        sch = synth_scene(1_000_000, seed=0, s0=0.01)
+        pch = PC(sch, grad=True)
+        camh = ring[0].to(dev)
+        bgh = sch["bg"].to(dev)
+        Gh = seed_gradient(H, W, 0).to(dev)
+
+        def l2_step():
+            a = render(camh, pch, pipe, bgh)
+            (a["render"] * Gh).sum().backward()
+            for v in pch.t.values():
+                v.grad = None
+
+        t_l2 = timed(l2_step, 100, 30)
+        out["headline_via_render_l2"] = {"ms_per_step": 1e3 * t_l2, "iters_per_s": 1.0 / t_l2,
+                                         "what": "synth-v1 1 M Gaussians, 1920x1080, ring view 0: render() + (image * G).sum()."
+                                                 "backward() per step (two extra elementwise kernels over the image for the "
+                                                 "loss), wall clock over 100 steps"}
+        del pch
         # ---- the fixed 8-view batch of configs[3] on ONE GPU (multiview_batch_step: two-stream view pipelining, the blend kernels
         # at 2 waves per SIMD by the library's own choice), headline scene; 3 repetitions each way -> median and range
         sc1 = synth_scene(1_000_000, seed=0, s0=0.01)
@@ -740,7 +868,7 @@ def main():
         }
 
     fwd_s, fwd_ms = None, []
-    stage_ms, ab, cb, R, V, pix_inst = {}, {}, {}, 0, 0, 0
+    stage_ms, ab, cb, R, V, pix_inst, k7_info = {}, {}, {}, 0, 0, 0, {}
     if not args.train_only:
         # ---------------- forward only ----------------
         rast = GaussianRasterizer(rs)
@@ -765,7 +893,8 @@ def main():
         fwd_ms = [fwd_ev[i].elapsed_time(fwd_ev[i + 1]) for i in range(args.steps)]
 
         # ---------------- per-stage GPU time (HIP events on the launch stream), rank-local ----------------
-        stage_ms, R, V, pix_inst = stage_times(dev, params, rs, G, ply_degree, flags, max(5, min(args.steps, 20)))
+        k7_info = {}
+        stage_ms, R, V, pix_inst = stage_times(dev, params, rs, G, ply_degree, flags, max(5, min(args.steps, 20)), info=k7_info)
         ab, cb = algorithmic_bytes(P, V, R, N, T, M), compulsory_bytes(P, V, R, N, T, M)
 
     # ---------------- CPU baseline: the oracle on this box's host cores (rank 0, N == 1) ----------------
@@ -899,9 +1028,13 @@ def main():
                 "stage_ms": stage_ms,
                 "stage_algorithmic_bytes": ab,
                 "stage_compulsory_bytes": cb,
+                # the whole iteration against 8 TB/s, the honest figures first: what the memory controllers counted (PMC passes,
+                # when they belong to this build), then the compulsory-byte model; section 8(d)'s per-instance model last
+                "hbm_fraction_train_iter_counter": ((len(my_views) * sum(counters["per_launch_bytes"].values()) / (train_s / args.steps))
+                                                    / (HBM_PEAK_GBS * 1e9)) if counters and counters.get("per_launch_bytes") else None,
                 "hbm_fraction_train_iter": (len(my_views) * sum(cb.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
                 "hbm_fraction_train_iter_8d": (len(my_views) * sum(ab.values()) / (train_s / args.steps)) / (HBM_PEAK_GBS * 1e9),
-                "roofline": roofline_block(stage_ms, ab, cb, dominant, counters, src, dev, pix_inst),
+                "roofline": roofline_block(stage_ms, ab, cb, dominant, counters, src, dev, pix_inst, k7_info),
                 "cpu_baseline": cpu,
             })
             if extra is not None:

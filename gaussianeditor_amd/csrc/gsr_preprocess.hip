@@ -573,10 +573,12 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   // The Gaussian's accumulator row (round 6: K7 adds into ONE 64-byte row per Gaussian, gsr_common.h ACC_*): requested for
   // every thread, visible or not -- the screen-space and opacity gradients leave through this kernel now (K7 used to add
   // into the caller's arrays directly), and a Gaussian without a pixel has an all-zero row.
-  // (streaming loads: a row is read exactly once, and kept out of the caches it would push out the parameters K1 streams
-  //  again at the start of the next iteration -- as the SH-gradient rows' streaming stores do in the other direction)
+  // (GSR_K9_NT_ACC=1, A/B builds: streaming loads of the rows and streaming stores of the two copied-out gradients, to keep
+  //  them out of the memory-side cache that holds the parameters K1 streams again next -- measured: K1 does not notice either
+  //  way once the table is no longer cleared per backward, and this kernel is 3-4 us SLOWER with them, 10 us on synth-v2,
+  //  profiles/r06_e_accumulator_rows.md)
 #ifndef GSR_K9_NT_ACC
-#define GSR_K9_NT_ACC 1
+#define GSR_K9_NT_ACC 0
 #endif
   typedef float acc_f4 __attribute__((ext_vector_type(4)));
   const acc_f4* const acc_row = reinterpret_cast<const acc_f4*>(a.acc + (size_t)idx * ACC_ROW);

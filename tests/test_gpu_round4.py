@@ -150,7 +150,12 @@ def test_default_bench_line_carries_extra_configs_and_both_roofline_fractions():
     if rf["kernel"].startswith("blend"):
         assert rf["pixel_instances_per_s"] > 1e9
     if rf["traffic"] is not None:  # (counters are quoted only while their source hash matches this build)
-        assert 0 < rf["frac_counter"] <= 1 and 0 < rf["valu_issue_frac"] <= 1
+        # round 6: the issue fraction is priced at the MEASURED rate of K7's own group body (2.79 cycles per VALU instruction and
+        # SIMD), the 4-cycle figure of rounds 3-5 stays next to it
+        assert 0 < rf["frac_counter"] <= 1 and 0 < rf["valu_issue_frac"] < rf["valu_issue_frac_4cycle"] <= 1
+        assert 0 < line["hbm_fraction_train_iter_counter"] <= 1
+    if rf["kernel"] == "blend_backward":  # K7's critical path from its own per-item cycle counts
+        assert 0.3 < rf["critical_item_frac"] <= 1.0 and 0.3 < rf["mean_workgroup_frac"] <= 1.0 and rf["k7_items"] > 1000
     assert 0 < line["hbm_fraction_train_iter"] <= 1
     ex = line["extra_configs"]
     assert ex["C2_synth6M_1080p_forward"]["visible"] == 6_000_000 and 0.3 < ex["C2_synth6M_1080p_forward"]["forward_ms"] < 5
@@ -166,7 +171,16 @@ def test_default_bench_line_carries_extra_configs_and_both_roofline_fractions():
     pr = ex["persistent_rows_1M_1080p"]
     assert 0.3 < pr["train_ms_per_step"] < 1.02 * line["ms_per_step"]
     assert 0.2 < ex["C3_edit_loop_512_1M"]["ms_per_step"] < 10 and 0.05 < ex["C5_apply_weights_12views_512_1M"]["ms_per_view"] < 5
-    assert ex["seconds"] < 150
+    # round 6: the unmodified double render is served by view reuse (the second render: the blend kernel alone); stage times and
+    # a roofline for the two 512 x 512 entries; the headline through render() + autograd
+    c3 = ex["C3_edit_loop_512_1M"]
+    assert c3["view_reuse_hits"] >= 30 and c3["ms_per_step"] < ex["C3_edit_loop_512_1M_no_reuse"]["ms_per_step"]
+    assert set(c3["stage_ms"]) == set(line["stage_ms"]) and 0 < c3["roofline"]["frac_compulsory"] <= 1
+    assert set(ex["C5_apply_weights_12views_512_1M"]["stage_ms"]) == {"preprocess", "bin", "trace_weights"}
+    assert ex["C3_edit_loop_512_1M_reference_model"]["reuse"]["compare_launches"] >= 30
+    l2 = ex["headline_via_render_l2"]
+    assert 0.3 < l2["ms_per_step"] < 10
+    assert ex["seconds"] < 300
 
 
 def test_bench_stdout_is_one_json_line_even_when_rccl_is_initialised():
