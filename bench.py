@@ -173,21 +173,14 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True, info=None):
         _native.check("fwd", L.gsr_blend_forward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(color), p(depth), flags))
         ev[3].record(s)
         if backward:
-            # (as gsr_backward does it: the zeros of every output are written by the side blocks of K7's launch, K8+K9 visits
-            #  the touched Gaussians only -- GSR_FLAG_OUTPUTS_ZEROED = 64, GSR_FLAG_ACC_SELF_CLEAN = 32)
-            outs = (d_m2, d_op, d_m3, d_cov, d_sh, d_sc, d_rot)
-            fl = _native.FillList()
-            for i, t_ in enumerate(outs):
-                fl.ptr[i], fl.bytes[i] = t_.data_ptr(), t_.numel() * 4
-            fl.count = len(outs)
             _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc_rows),
-                                                      ctypes.byref(fl), flags))
+                                                      flags))
             ev[4].record(s)
             _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
                                                            p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
                                                            p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom),
                                                            p(acc_rows), p(d_m2), p(d_op), None, p(d_m3), p(d_cov), p(d_sh), p(d_sc),
-                                                           p(d_rot), 32 | 64))
+                                                           p(d_rot), 32))
             ev[5].record(s)
         torch.cuda.synchronize(dev)
         if it >= 2:

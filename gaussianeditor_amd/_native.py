@@ -32,11 +32,6 @@ class DenseGrads(ctypes.Structure):
     _fields_ = [("means3D", _P), ("scales", _P), ("rotations", _P), ("means2D", _P), ("opacities", _P), ("sh", _P)]
 
 
-class FillList(ctypes.Structure):
-    """gsr_fill_list (include/gsr.h): arrays gsr_blend_backward zero-fills with the side blocks of its launch."""
-    _fields_ = [("ptr", _P * 8), ("bytes", c_size_t * 8), ("count", c_int)]
-
-
 class AppendTensor(ctypes.Structure):
     """gsr_append_tensor (include/gsr.h)."""
     _fields_ = [("src", _P), ("ext", _P), ("dst", _P), ("row_bytes", c_int64)]
@@ -62,8 +57,8 @@ SIGNATURES = {
     "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
                              _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
-    # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, zero_fill, flags)
-    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
+    # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags)
+    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
     # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots, flags)
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),

@@ -86,8 +86,8 @@ __device__ __forceinline__ bool setup_item(const BlendArgs& a, uint32_t tile, ui
 // (Every pop of every other workgroup has returned before that workgroup's retire increment is issued.)
 // Two levels, one counter per 64 workgroups and one on top: memory-side atomics on ONE line serialise at ~6 ns
 // each, which for 4096 workgroups retiring together measured 20 us on the tail of the forward kernel.
-__device__ __forceinline__ void retire_queue(uint32_t* queue, uint32_t nwg) {  // nwg: the launch's PERSISTENT workgroups
-  const uint32_t grp = blockIdx.x >> 6, ngrp = (nwg + 63u) >> 6;
+__device__ __forceinline__ void retire_queue(uint32_t* queue) {
+  const uint32_t nwg = gridDim.x, grp = blockIdx.x >> 6, ngrp = (nwg + 63u) >> 6;
   if (ngrp > (uint32_t)QUEUE_GROUPS) return;  // (launchers fall back to a memset for such grids)
   const uint32_t gsize = min(64u, nwg - (grp << 6));
   uint32_t* top = queue + 8 * QUEUE_STRIDE;
@@ -111,13 +111,13 @@ __device__ __forceinline__ void retire_queue(uint32_t* queue, uint32_t nwg) {  /
 // slot 1 item 2n-1-u, slot 2 item 2n+u, slot 3 item 4n-1-u, ... (n = units per XCD): every unit gets one item from
 // each stratum of the sorted list, folded so that the sums even out.  Everything after the first W n items is popped
 // dynamically.  The assignment is a permutation of [0, W n) whatever the real placement is, so results never depend on it.
-__device__ __forceinline__ uint32_t first_item_of_block(uint32_t units, uint32_t nwg, uint32_t& queue_x, uint32_t& first_dynamic) {
+__device__ __forceinline__ uint32_t first_item_of_block(uint32_t units, uint32_t& queue_x, uint32_t& first_dynamic) {
   if (units == 0u) {  // no assignment: everything is popped
     queue_x = 0u;
     first_dynamic = 0u;
     return 0xffffffffu;
   }
-  const uint32_t n = units / 8u, W = nwg / units;  // launchers guarantee units % 8 == 0, nwg % units == 0
+  const uint32_t n = units / 8u, W = gridDim.x / units;  // launchers guarantee units % 8 == 0, gridDim.x % units == 0
   const uint32_t b = blockIdx.x, slot = b / units, u = (b % units) / 8u;
   queue_x = b % 8u;
   first_dynamic = W * n;
@@ -150,7 +150,7 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
     return true;
   };
   uint32_t x0, base;
-  const uint32_t q0 = first_item_of_block((uint32_t)a.units, gridDim.x, x0, base);
+  const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   (void)run_item(x0, q0);
   // then serve the queue of the XCD the wave really runs on (HW_REG_XCC_ID; equal to x0 on this chip)
   const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 7u;
@@ -161,7 +161,7 @@ __device__ __forceinline__ void run_work_queue(const BlendArgs& a, bool with_emp
     q = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
     if (!run_item(x, base + q)) break;
   }
-  if (a.self_reset && lane_id() == 0) retire_queue(a.queue, gridDim.x);
+  if (a.self_reset && lane_id() == 0) retire_queue(a.queue);
 }
 
 // Read-only tables of an earlier kernel, read through the SCALAR cache at a wave-uniform index (s_load: its counter,
@@ -1076,35 +1076,6 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
   return seg_hi - seg_lo;
 }
 
-// Zero-fill of up to FILL_MAX arrays (floats) by the `nb` side blocks of a launch, block `b` of them: 16-byte stores over the
-// aligned middle, scalar stores at the two ends; consecutive blocks take consecutive 16-byte x (4 x blockDim.x) pieces, four
-// stores in flight per thread.
-__device__ __forceinline__ void zero_fill_arrays(const FillArgs& f, long long b, long long nb) {
-  const long long th = (long long)blockDim.x;
-#pragma unroll
-  for (int k = 0; k < FILL_MAX; ++k) {
-    float* const p = f.ptr[k];
-    const long long n = f.n[k];
-    if (p == nullptr || n <= 0) continue;
-    const long long head = min(n, (long long)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / 4u));
-    const long long n4 = (n - head) / 4;
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4* const q = reinterpret_cast<f4*>(p + head);
-    const f4 z = {0.f, 0.f, 0.f, 0.f};
-    for (long long i0 = b * 4 * th; i0 < n4; i0 += nb * 4 * th) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long long i = i0 + u * th + threadIdx.x;
-        if (i < n4) q[i] = z;
-      }
-    }
-    if (b == 0) {
-      for (long long i = threadIdx.x; i < head; i += th) p[i] = 0.f;
-      for (long long i = head + 4 * n4 + threadIdx.x; i < n; i += th) p[i] = 0.f;
-    }
-  }
-}
-
 #ifndef GSR_BWD_WAVES_PER_EU
 #define GSR_BWD_WAVES_PER_EU 4  // (A/B builds: 5 with GSR_BLEND_WAVES_PER_SIMD=5)
 #endif
@@ -1116,16 +1087,6 @@ blend_backward_kernel(const BlendArgs a) {
   __shared__ float4 sco[2][WAVE];
   __shared__ float sacc[2][WAVE][ACC_LDS_ROW];  // raw moments 0..8 of every chunk slot (row stride 9: odd, the four rows of a flush instruction spread over the banks)
   __shared__ uint32_t s_item;
-  // Side blocks (round 6): the workgroups behind the persistent ones zero-fill the caller's gradient OUTPUTS (BlendArgs::fill).
-  // All CUs are taken by the persistent workgroups at first (4 x 108 VGPRs per SIMD: no fifth wave fits), so a side block
-  // starts when a persistent workgroup has run out of work and left -- in the launch's drain, a quarter of its length, during
-  // which SIMDs idle and the memory system idles throughout (K7 moves 1.4 TB/s).  K8+K9 then visits only the Gaussians K7
-  // touched (GSR_FLAG_OUTPUTS_ZEROED): one in ten on the benchmark view instead of reading 236 B and writing 264 B for all.
-  const uint32_t nwg = a.bwd_wgs != 0 ? (uint32_t)a.bwd_wgs : gridDim.x;
-  if (blockIdx.x >= nwg) {
-    zero_fill_arrays(a.fill, (long long)blockIdx.x - nwg, (long long)gridDim.x - nwg);
-    return;
-  }
   for (int i = threadIdx.x; i < 2 * WAVE * ACC_LDS_ROW; i += WAVE * BWD_WAVES) (&sacc[0][0][0])[i] = 0.f;
   // (element i was zeroed by thread i % 256, i.e. by any wave: with the deferred flush the placement-assigned first item
   // reaches its first ds_add_f32 without passing a workgroup barrier otherwise.  Once per kernel, not per item.)
@@ -1188,7 +1149,7 @@ blend_backward_kernel(const BlendArgs a) {
   };
   // first item assigned by placement (see first_item_of_block), the rest popped
   uint32_t x0, base;
-  const uint32_t q0 = first_item_of_block((uint32_t)a.units, nwg, x0, base);
+  const uint32_t q0 = first_item_of_block((uint32_t)a.units, x0, base);
   {
     const uint32_t n0 = nwork > x0 ? (nwork - x0 + 7u) / 8u : 0u;
     if (q0 < n0) run_tile(x0 + 8u * q0);
@@ -1211,7 +1172,7 @@ blend_backward_kernel(const BlendArgs a) {
     rec[4] = longest;
     rec[5] = first;
   }
-  if (a.self_reset && threadIdx.x == 0) retire_queue(a.queue, nwg);
+  if (a.self_reset && threadIdx.x == 0) retire_queue(a.queue);
 }
 
 // ----------------------------------------------------------------------------------
@@ -1319,7 +1280,10 @@ constexpr int BWD_BUCKETS = 256;
 // (blocks 1 .. gridDim.x - 1; block 0 is the work list): the list is one block of dependent round trips during which the
 // rest of the chip idles.  Measured: work list 8.2 us + a separate fill of 44 bytes per Gaussian 8.9 us -> 14 us together
 // (the fill runs at 3.1 TB/s here against 4.9 TB/s alone), and one launch less between the forward and the backward.
-typedef FillArgs ClearArgs;
+struct ClearArgs {
+  float* ptr[4];
+  long long n[4];  // floats
+};
 template <bool SEG>
 __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const uint32_t* __restrict__ est,
                                                                 uint32_t* __restrict__ order, uint32_t* __restrict__ meta,
@@ -1329,7 +1293,31 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
                                                                 const uint32_t* __restrict__ ck_work, uint32_t stride,
                                                                 int seg_share) {  // seg_share: 0, or the threshold in 1/8 of a fair share
   if (blockIdx.x != 0) {
-    zero_fill_arrays(clear, (long long)blockIdx.x - 1, (long long)gridDim.x - 1);
+    const long long nb = (long long)gridDim.x - 1, b = (long long)blockIdx.x - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float* const p = clear.ptr[k];
+      const long long n = clear.n[k];
+      if (p == nullptr || n <= 0) continue;
+      // 16-byte stores over the aligned middle, scalar stores at the two ends
+      const long long head = min(n, (long long)(((16u - (unsigned)(reinterpret_cast<uintptr_t>(p) & 15u)) & 15u) / 4u));
+      const long long n4 = (n - head) / 4;
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      f4* const q = reinterpret_cast<f4*>(p + head);
+      const f4 z = {0.f, 0.f, 0.f, 0.f};
+      // consecutive blocks take consecutive 64 KB pieces (4 x 16 KB per thread block and round), four stores in flight per thread
+      for (long long i0 = b * 4096; i0 < n4; i0 += nb * 4096) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long i = i0 + u * 1024 + threadIdx.x;
+          if (i < n4) q[i] = z;
+        }
+      }
+      if (b == 0) {
+        for (long long i = threadIdx.x; i < head; i += 1024) p[i] = 0.f;
+        for (long long i = head + 4 * n4 + threadIdx.x; i < n; i += 1024) p[i] = 0.f;
+      }
+    }
     return;
   }
   // (BWD_SUB counters per bucket, chosen by the lane: see tile_worklist_kernel in gsr_binning.hip)
@@ -1561,7 +1549,7 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
   // 5 no workgroup barrier per chunk (the quadrant waves drift apart), 6 = 5 without the global atomics
   static const int ablate = [] { const char* e = getenv("GSR_BWD_ABLATE"); return e ? atoi(e) : 0; }();
   bool seg_items = false;  // the work list holds list-segment items (views whose forward left checkpoints)
-  ClearArgs clear = {};
+  ClearArgs clear = {{nullptr, nullptr, nullptr, nullptr}, {0, 0, 0, 0}};
   if (a.clear_grads) {
     const long long P = a.P;
     clear.ptr[0] = a.acc; clear.n[0] = (long long)ACC_ROW * P;
@@ -1584,13 +1572,8 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
                          a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
                          (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
   }
-  // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward; behind them the side blocks that zero-fill
-  // the caller's outputs (8 per CU: 64 KB pieces of up to 270 MB)
-  bool any_fill = false;
-  for (int k = 0; k < FILL_MAX; ++k) any_fill = any_fill || (a.fill.ptr[k] != nullptr && a.fill.n[k] > 0);
-  const unsigned nwg = blend_grid_size(true, s, sh) / BWD_WAVES;
-  a.bwd_wgs = (int)nwg;
-  const dim3 g(nwg + (any_fill ? 8u * (unsigned)cus_of_stream(s) : 0u)), b(WAVE * BWD_WAVES);
+  // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
+  const dim3 g(blend_grid_size(true, s, sh) / BWD_WAVES), b(WAVE * BWD_WAVES);
   switch (ablate) {
     case 1: hipLaunchKernelGGL((blend_backward_kernel<1, false, false>), g, b, 0, s, a); break;
     case 2: hipLaunchKernelGGL((blend_backward_kernel<2, false, false>), g, b, 0, s, a); break;

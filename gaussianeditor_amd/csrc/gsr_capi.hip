@@ -495,24 +495,13 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 }
 
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* acc,
-                       const gsr_fill_list* zero_fill, unsigned flags) {
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags) {
   // (a backward of a view whose forward was declared forward-only: the flags of one view travel together)
-  if ((flags & ~GSR_FLAG_ALL) || (flags & (GSR_FLAG_FORWARD_ONLY | GSR_FLAG_ACC_SELF_CLEAN | GSR_FLAG_OUTPUTS_ZEROED)))
-    return GSR_ERR_BAD_ARGUMENT;
-  if (zero_fill != nullptr) {
-    if (zero_fill->count < 0 || zero_fill->count > FILL_MAX) return GSR_ERR_BAD_ARGUMENT;
-    for (int k = 0; k < zero_fill->count; ++k)
-      if (zero_fill->bytes[k] != 0 && (!zero_fill->ptr[k] || (zero_fill->bytes[k] & 3u) || ((uintptr_t)zero_fill->ptr[k] & 3u)))
-        return GSR_ERR_BAD_ARGUMENT;
-  }
+  if ((flags & ~GSR_FLAG_ALL) || (flags & (GSR_FLAG_FORWARD_ONLY | GSR_FLAG_ACC_SELF_CLEAN))) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0) return GSR_OK;
   if (P < 0 || !acc || ((uintptr_t)acc & 63u)) return GSR_ERR_BAD_ARGUMENT;  // (a row must not straddle two 64-byte lines)
-  if (R == 0) {  // nothing to blend: the accumulator rows stay zero -- or become zero; the zeros asked for are written
+  if (R == 0) {  // nothing to blend: the accumulator rows stay zero -- or become zero
     if (flags & GSR_FLAG_CLEAR_GRADS) GSR_HIP(hipMemsetAsync(acc, 0, sizeof(float) * ACC_ROW * (size_t)P, (hipStream_t)stream));
-    if (zero_fill != nullptr)
-      for (int k = 0; k < zero_fill->count; ++k)
-        if (zero_fill->bytes[k] != 0) GSR_HIP(hipMemsetAsync(zero_fill->ptr[k], 0, zero_fill->bytes[k], (hipStream_t)stream));
     return GSR_OK;
   }
   if (R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
@@ -529,11 +518,6 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   a.P = P;
   a.clear_grads = (flags & GSR_FLAG_CLEAR_GRADS) ? 1 : 0;
-  if (zero_fill != nullptr)
-    for (int k = 0; k < zero_fill->count; ++k) {
-      a.fill.ptr[k] = (float*)zero_fill->ptr[k];
-      a.fill.n[k] = (long long)(zero_fill->bytes[k] / 4);
-    }
   GSR_HIP(launch_blend_backward((hipStream_t)stream, a));
   return GSR_OK;
 }
@@ -545,7 +529,7 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
                                     const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
                                     float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                                     float* dL_drgb, float* dL_dscales, float* dL_drots, uint8_t* row_state = nullptr,
-                                    bool self_clean = false, bool outputs_zeroed = false) {
+                                    bool self_clean = false) {
   if (P == 0) return GSR_OK;
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
@@ -575,7 +559,6 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   pa.dL_drot = scales ? dL_drots : nullptr;
   pa.row_state = row_state;
   pa.acc_clean = self_clean ? const_cast<float*>(acc) : nullptr;  // (GSR_FLAG_ACC_SELF_CLEAN: the caller's table, writable by contract)
-  pa.outputs_zeroed = outputs_zeroed && row_state == nullptr ? 1 : 0;
   GSR_HIP(launch_preprocess_backward((hipStream_t)stream, pa));
   return GSR_OK;
 }
@@ -614,11 +597,11 @@ int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, con
                             float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
                             float* dL_dscales, float* dL_drots, unsigned flags) {
   if (shs && !dL_dsh) return GSR_ERR_BAD_ARGUMENT;
-  if (flags & ~(GSR_FLAG_ACC_SELF_CLEAN | GSR_FLAG_OUTPUTS_ZEROED)) return GSR_ERR_BAD_ARGUMENT;  // (the two flags this half reads)
+  if (flags & ~GSR_FLAG_ACC_SELF_CLEAN) return GSR_ERR_BAD_ARGUMENT;  // (the one flag this half reads)
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                   viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
                                   dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, nullptr, dL_dscales, dL_drots, nullptr,
-                                  (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0, (flags & GSR_FLAG_OUTPUTS_ZEROED) != 0);
+                                  (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0);
 }
 
 int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
@@ -750,38 +733,13 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
   if (P == 0) return GSR_OK;
   if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
   const bool self_clean = (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0;
-  if ((self_clean && (flags & GSR_FLAG_CLEAR_GRADS)) || (flags & GSR_FLAG_OUTPUTS_ZEROED)) return GSR_ERR_BAD_ARGUMENT;
-  if (!dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D || (shs && !dL_dsh) || (scales && (!dL_dscales || !dL_drots)))
-    return GSR_ERR_BAD_ARGUMENT;
-  // The zeros of every output are written by the side blocks of K7's launch (in its drain); K8+K9 then visits the touched
-  // Gaussians only.  (GSR_BWD_DENSE=1, A/B runs: the dense K8+K9 of rounds 1-5, which writes every row itself.)
-  static const bool dense = [] { const char* e = getenv("GSR_BWD_DENSE"); return e && e[0] == '1'; }();
-  gsr_fill_list fl;
-  memset(&fl, 0, sizeof(fl));
-  const bool sparse = !dense && R > 0;
-  if (sparse) {
-    auto add = [&](float* p, size_t floats) {
-      if (p != nullptr && floats != 0) {
-        fl.ptr[fl.count] = p;
-        fl.bytes[fl.count++] = floats * sizeof(float);
-      }
-    };
-    add(dL_dmeans2D, 3 * (size_t)P);
-    add(dL_dopacity, (size_t)P);
-    add(dL_dcolors, 3 * (size_t)P);
-    add(dL_dmeans3D, 3 * (size_t)P);
-    add(dL_dcov3D, 6 * (size_t)P);
-    if (shs) add(dL_dsh, 3 * (size_t)M * (size_t)P);
-    if (scales) add(dL_dscales, 3 * (size_t)P);
-    if (scales) add(dL_drots, 4 * (size_t)P);
-  }
-  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, sparse ? &fl : nullptr,
-                              flags & ~GSR_FLAG_ACC_SELF_CLEAN);
+  if (self_clean && (flags & GSR_FLAG_CLEAR_GRADS)) return GSR_ERR_BAD_ARGUMENT;
+  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags & ~GSR_FLAG_ACC_SELF_CLEAN);
   if (st != GSR_OK) return st;
   return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
                                  dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots,
-                                 (self_clean ? GSR_FLAG_ACC_SELF_CLEAN : 0u) | (sparse ? GSR_FLAG_OUTPUTS_ZEROED : 0u));
+                                 self_clean ? GSR_FLAG_ACC_SELF_CLEAN : 0u);
 }
 
 int gsr_mark_visible(void* stream, int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -46,7 +46,6 @@ struct PreBwdArgs {
   float h_x, h_y, tan_fovx, tan_fovy;
   const float* acc;         // (P, ACC_ROW): the blend backward's accumulator rows (dL_dmean2D, dL_dopacity, dL_dconic, dL_dcolor)
   float* acc_clean;         // == acc (GSR_FLAG_ACC_SELF_CLEAN: rows that are not zero are put back to zero) | null
-  int outputs_zeroed;       // GSR_FLAG_OUTPUTS_ZEROED: every output holds zeros already; untouched Gaussians are skipped
   float* dL_dmean2D;        // (P,3) out: columns ACC_MEAN2D .. + 1 of the rows, z = 0
   float* dL_dopacity;       // (P)   out: column ACC_OPACITY
   float* dL_dcolor;         // (P,3) out | null: columns ACC_COLOR .. + 2 (the gradient of colors_precomp)
@@ -57,13 +56,6 @@ struct PreBwdArgs {
   float* dL_dscale;         // (P,3)   | null
   float* dL_drot;           // (P,4)   | null
   uint8_t* row_state;       // (P) | null: gsr_preprocess_backward_rows -- rows that still hold this kernel's zeros are not rewritten
-};
-
-// Arrays (of floats) a launch zero-fills with side blocks (gsr_blend.hip: zero_fill_arrays)
-constexpr int FILL_MAX = 8;
-struct FillArgs {
-  float* ptr[FILL_MAX];
-  long long n[FILL_MAX];  // floats
 };
 
 // K6 / K7 / K12 arguments (gsr_blend.hip)
@@ -97,8 +89,6 @@ struct BlendArgs {
   const float* image_weights;
   float* weights;
   int32_t* cnt;
-  int bwd_wgs;     // backward launch: its persistent workgroups (the blocks behind them are side blocks), set by the launcher
-  FillArgs fill;   // backward: arrays the side blocks of the launch zero-fill (gsr_blend.hip: zero_fill_arrays)
   int P;           // number of Gaussians (rows of the backward's accumulator table)
   int clear_grads; // GSR_FLAG_CLEAR_GRADS: the backward clears its accumulator rows itself (launch_blend_backward)
   int fast_exp;    // GSR_FLAG_FAST_EXP: hardware 2^x instead of the specified polynomial (gsr_blend.hip: blend_exp)

@@ -550,11 +550,7 @@ __device__ __forceinline__ void sh_tile_store_rows(float* __restrict__ dst_rows,
 // Gaussians of ten get all-zero gradients from a view (culled, or no pixel blended them); their rows are rewritten only if
 // they do not hold this kernel's zeros already (row_state[g] != 0), so what leaves the chip per view is the rows that are
 // non-zero now or were the last time -- 248 B x ~20 % instead of 248 B x P.  dL_dcov3D is always written.
-// SPARSE (PreBwdArgs::outputs_zeroed, GSR_FLAG_OUTPUTS_ZEROED): every output array already holds zeros (the side blocks of the
-// blend backward's launch wrote them while its last items drained), so a Gaussian whose accumulator row is all zero -- nine of
-// ten on the benchmark view: culled, or blended by no pixel -- is done before a single parameter is read.  What this kernel
-// moves falls from (236 + 264) B per Gaussian to the 64-byte rows + ~1 KB per touched Gaussian.
-template <bool ROWS, bool SPARSE = false>
+template <bool ROWS>
 __global__ void __launch_bounds__(GAUSS_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
 preprocess_backward_kernel(const PreBwdArgs a) {
   __shared__ float4 sh_tile[GAUSS_BLOCK / 64][SH_TILE_F4];
@@ -606,11 +602,6 @@ preprocess_backward_kernel(const PreBwdArgs a) {
       const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
       w[0] = z; w[1] = z; w[2] = z; w[3] = z;
     }
-  }
-  if (SPARSE) {
-    const bool touched = !(acc_m2d.x == 0.f) || !(acc_m2d.y == 0.f) || !(acc_m2d.w == 0.f) || !(acc_con.x == 0.f) ||
-                         !(acc_con.y == 0.f) || !(acc_con.w == 0.f) || !(acc_col.x == 0.f) || !(acc_col.y == 0.f) || !(acc_col.z == 0.f);
-    if (!live || !touched) return;  // (all-zero accumulator rows give all-zero gradients: the zeros are already there)
   }
 
   if (live && a.radii[idx] > 0) {
@@ -831,9 +822,7 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     if ((nonzero ? 1 : 0) != was) a.row_state[idx] = nonzero ? 1 : 0;
     if (a.dL_dsh != nullptr) store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
   } else if (a.dL_dsh != nullptr) {
-    if (SPARSE) {  // (one row here and there: no wave-cooperative tile)
-      store_sh_grad(a.dL_dsh + (size_t)idx * a.M * 3, a.M, dsh, ncoef);
-    } else if (a.M == 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0) {
+    if (a.M == 16 && (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0) {
       const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
       const int row0 = idx_raw - lane;  // first row of this wave
       if (row0 < a.P) sh_tile_store_rows(a.dL_dsh + (size_t)row0 * 48, min(64, a.P - row0), sh_tile[wv], lane, dsh, ncoef);
@@ -1283,7 +1272,6 @@ hipError_t launch_view_messages_accumulate(hipStream_t s, int64_t P, int D, int 
 hipError_t launch_preprocess_backward(hipStream_t s, const PreBwdArgs& a) {
   const int nb = (a.P + GAUSS_BLOCK - 1) / GAUSS_BLOCK;
   if (a.row_state != nullptr) hipLaunchKernelGGL(preprocess_backward_kernel<true>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
-  else if (a.outputs_zeroed) hipLaunchKernelGGL((preprocess_backward_kernel<false, true>), dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
   else hipLaunchKernelGGL(preprocess_backward_kernel<false>, dim3(nb), dim3(GAUSS_BLOCK), 0, s, a);
   return hipGetLastError();
 }

@@ -294,7 +294,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             # (also when nothing was rendered: the call then only clears the accumulator table)
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), None, bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
             if dL_drgb is not None:
                 grad_alloc("after_blend_backward", acc, False)
             _native.check("gsr_preprocess_backward_rows", L.gsr_preprocess_backward_rows(
@@ -318,7 +318,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
             # (also when nothing was rendered: the call then only clears the accumulator table)
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), None, bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
             # notification (no allocation): K7 is enqueued, K8+K9 not yet -- multiview.py starts the exchange of the
             # touched-row counts here, so that it (and the host's wait for it) runs underneath K8+K9
             grad_alloc("after_blend_backward", acc, False)

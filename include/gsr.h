@@ -56,7 +56,7 @@ extern "C" {
 /* 4 (round 5): adds gsr_near_workspace_size / gsr_near_points (round 4 had left the number at 3), the scratch layouts
  * changed again (sizes come from gsr_scratch_sizes: rebuild nothing, re-query), images of more than GSR_MAX_TILES tiles
  * are refused by the backward entry points instead of being walked wrongly. */
-/* 5 (round 6): adds gsr_arrays_equal, gsr_fill_list, GSR_FLAG_ACC_SELF_CLEAN / GSR_FLAG_OUTPUTS_ZEROED; the blend backward accumulates into ONE table of 64-byte rows (`acc`, GSR_ACC_*)
+/* 5 (round 6): adds gsr_arrays_equal; the blend backward accumulates into ONE table of 64-byte rows (`acc`, GSR_ACC_*)
  * instead of four arrays, and gsr_preprocess_backward* copies dL_dmeans2D / dL_dopacity (/ dL_dcolors) out of it: the
  * signatures of gsr_backward, gsr_blend_backward, gsr_preprocess_backward{,_rgb,_rows}, gsr_view_message_plan_blend and
  * gsr_debug_blend_backward_profile changed. */
@@ -142,12 +142,6 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *       (which it makes unnecessary).  With the two halves called separately: gsr_blend_backward WITHOUT GSR_FLAG_CLEAR_GRADS
  *       on the zero table, then gsr_preprocess_backward with this flag.  A caller that reads `acc` between the two halves
  *       on ANOTHER stream (gsr_view_message_plan_blend under K8+K9) must not use it;
- *   GSR_FLAG_OUTPUTS_ZEROED (ABI 5; read by gsr_preprocess_backward) every output array of the call already holds zeros
- *       (gsr_blend_backward's `zero_fill` wrote them -- or the caller): a Gaussian whose accumulator row is all zero, i.e.
- *       one no pixel blended -- nine of ten on the benchmark view --, is skipped before any of its parameters is read; only
- *       the rows of touched Gaussians are written.  Results equal the dense kernel's for finite parameters (an all-zero row
- *       gives all-zero gradients; with a non-finite parameter the dense kernel computes 0 x inf for every visible Gaussian,
- *       this one only for touched ones).  gsr_backward does both halves itself and needs no flag;
  *   GSR_FLAG_SHARED_SIMDS (ABI 4; read by the blend / trace entry points) the caller overlaps this view's kernels with
  *                        another view's on a second stream: the persistent blend kernels are launched with 2 waves per
  *                        SIMD instead of 4, which leaves wave slots and registers for the other stream's kernels (a rank
@@ -160,8 +154,7 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
 #define GSR_FLAG_FORWARD_ONLY 8u
 #define GSR_FLAG_SHARED_SIMDS 16u
 #define GSR_FLAG_ACC_SELF_CLEAN 32u
-#define GSR_FLAG_OUTPUTS_ZEROED 64u
-#define GSR_FLAG_ALL 127u
+#define GSR_FLAG_ALL 63u
 
 /* Number of sort-key bits, 32 + getHigherMsb(tiles) (rasterizer_impl.cu:36-49, 253). */
 int gsr_sort_key_bits(int W, int H);
@@ -238,8 +231,7 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
  *       -munsafe-fp-atomics, i.e. its float adds are the hardware's global_atomic_add_f32, which is only defined on
  *       coarse-grained memory (on fine-grained memory the adds are silently lost).  The same holds for `weights` / `cnt` of
  *       gsr_trace_weights.
- *   Fully written by the library (no need to zero -- the zeros of the Gaussians no pixel blended are written by side blocks of
- *       K7's launch, and K8+K9 visits the touched ones only): dL_dmeans2D (P,3) [z = 0], dL_dopacity (P), dL_dcolors (P,3) [may be
+ *   Fully written by the library (no need to zero): dL_dmeans2D (P,3) [z = 0], dL_dopacity (P), dL_dcolors (P,3) [may be
  *       NULL: only a caller with precomputed colours needs it], dL_dmeans3D (P,3), dL_dcov3D (P,6),
  *       dL_dsh (P,M,3) [NULL if shs == NULL], dL_dscales (P,3) and dL_drots (P,4) [NULL if scales == NULL].
  *   (The reference zero-fills all nine of its outputs, rasterize_points.cu:120-128, and accumulates into four of them.) */
@@ -256,25 +248,15 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
  * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward.
  * After gsr_blend_backward alone `acc` holds the sums in the GSR_ACC_* columns; gsr_preprocess_backward reads them and
  * writes dL_dmeans2D / dL_dopacity (/ dL_dcolors) next to its own outputs. */
-/* Arrays gsr_blend_backward zero-fills on the side: K7 is a launch of persistent workgroups whose last quarter is the drain of
- * its longest items -- SIMDs idle, the memory system idles throughout --, and the blocks behind the persistent ones write the
- * zeros there.  ptr[i]: device pointer (4-byte aligned), bytes[i]: a multiple of 4; count <= 8.  NULL = nothing to fill. */
-typedef struct gsr_fill_list {
-  void* ptr[8];
-  size_t bytes[8];
-  int count;
-} gsr_fill_list;
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* acc,
-                       const gsr_fill_list* zero_fill, unsigned flags);
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags);
 int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                             const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
                             const void* geom, float* acc, float* dL_dmeans2D, float* dL_dopacity,
                             float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dsh,
-                            float* dL_dscales, float* dL_drots,
-                            unsigned flags /* GSR_FLAG_ACC_SELF_CLEAN, GSR_FLAG_OUTPUTS_ZEROED */);
+                            float* dL_dscales, float* dL_drots, unsigned flags /* 0 | GSR_FLAG_ACC_SELF_CLEAN */);
 
 /* Multi-GPU exchange support (gaussianeditor_amd/multiview.py).  Per view the SH gradient is
  * rank one, dL_dsh[k] = c_k(dir) * dL_dRGB with dir = normalize(mean - campos) (backward.cu:44-98), so ranks exchange

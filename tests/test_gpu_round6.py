@@ -327,74 +327,3 @@ def test_accumulator_table_kept_across_backwards_is_left_zero():
     finally:
         _C._ACC_PERSIST = was
         _C._ACC_TABLES.clear()
-
-
-def test_backward_fills_every_output_itself_and_visits_touched_gaussians_only(oracle):
-    """Round 6: gsr_backward has the side blocks of K7's launch write the zeros of every output, and K8+K9 skips the Gaussians
-    no pixel blended (GSR_FLAG_OUTPUTS_ZEROED).  Outputs handed over full of NaN (an allocator that poisons what it hands out)
-    come back equal to the oracle's -- exact zeros for every untouched Gaussian included --, for SH and for precomputed colours,
-    odd sizes, P not a multiple of anything; and the dense route through the two separate entry points gives the same."""
-    import ctypes
-
-    import numpy as np
-
-    from gaussianeditor_amd import _native
-    from gaussianeditor_amd.diff_gaussian_rasterization import _C
-    from helpers import assert_grads_close, oracle_backward, oracle_forward, seed_gradient
-
-    for P, W, H, s0, seed, precomp in ((20011, 320, 200, 0.02, 6, False), (4099, 250, 131, 0.05, 7, True), (977, 33, 17, 0.3, 8, False)):
-        case = make_case(P, W, H, seed=seed, s0=s0)
-        sc, rs = case["sc"], settings(case, DEV)
-        cols = torch.rand(P, 3, generator=torch.Generator().manual_seed(seed)) if precomp else None
-        G = seed_gradient(H, W, seed) * (H * W)
-        f = oracle_forward(oracle, case, colors_precomp=cols)
-        g = oracle_backward(oracle, case, f, G, colors_precomp=cols)
-        d = lambda t: t.to(DEV)  # noqa: E731
-        e = torch.empty(0, device=DEV)
-        x, o, s_, r_ = d(sc["xyz"]), d(sc["opacity"]), d(sc["scaling"]), d(sc["rotation"])
-        sh = e if precomp else d(sc["features"])
-        col = d(cols) if precomp else e
-        R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
-            rs.bg, x, col, o, s_, r_, 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, H, W, sh, 3, rs.campos, False, False)
-
-        def poison(name, shape, zero):
-            if name in ("acc_rows", "row_state", "sh_rgb", "after_blend_backward"):
-                return None
-            return torch.full(shape, float("nan"), device=DEV)
-
-        out = _C.rasterize_gaussians_backward(rs.bg, x, radii, col, s_, r_, 1.0, e, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
-                                              rs.tanfovy, d(G), sh, 3, rs.campos, geom, R, binning, img, False,
-                                              grad_allocator=poison)
-        torch.cuda.synchronize()
-        names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
-        got = {k: t.cpu().numpy() for k, t in zip(names, out) if t is not None and t.numel() and (k != "dL_dcolors" or precomp)
-               and k != "dL_dcov3D" and (k != "dL_dsh" or not precomp)}
-        assert all(np.isfinite(v).all() for v in got.values()), [k for k, v in got.items() if not np.isfinite(v).all()]
-        assert_grads_close(got, {k: g[k].reshape(got[k].shape) for k in got}, tag=f"sparse P={P}")
-        untouched = ~(np.abs(g["dL_dmeans2D"].reshape(P, -1)).max(axis=1) > 0) & ~(np.abs(g["dL_dopacity"].reshape(P)) > 0)
-        assert untouched.sum() > 0.05 * P
-        for k, v in got.items():
-            assert not v.reshape(P, -1)[untouched].any(), k  # exact zeros, written by the fill
-        assert not out[4].cpu().numpy().any()  # dL_dcov3D without a precomputed covariance: zeros (backward.cu:273 never feeds it)
-        # the dense route: K7 alone on a cleared table, then the dense K8+K9 (flags 0) into poisoned outputs
-        L = _native.lib()
-        sp = torch.cuda.current_stream().cuda_stream
-        acc = torch.empty(P * 16, device=DEV)
-        nan = lambda *sh_: torch.full(sh_, float("nan"), device=DEV)  # noqa: E731
-        dm2, dop, dcl, dm3, dcv, dsh, dsc, drt = nan(P, 3), nan(P), nan(P, 3), nan(P, 3), nan(P, 6), nan(P, 16, 3), nan(P, 3), nan(P, 4)
-        p = lambda t: t.data_ptr()  # noqa: E731
-        _native.check("k7", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(d(G)), p(acc), None, 4))
-        _native.check("k89", L.gsr_preprocess_backward(sp, P, 3, 0 if precomp else 16, W, H, p(x), None if precomp else p(sh), p(s_), 1.0,
-                                                       p(r_), None, p(rs.viewmatrix), p(rs.projmatrix), p(rs.campos), rs.tanfovx,
-                                                       rs.tanfovy, p(radii), p(geom), p(acc), p(dm2), p(dop), p(dcl) if precomp else None,
-                                                       p(dm3), p(dcv), None if precomp else p(dsh), p(dsc), p(drt), 0))
-        torch.cuda.synchronize()
-        dense = dict(dL_dmeans2D=dm2, dL_dopacity=dop.view(P, 1), dL_dmeans3D=dm3, dL_dscales=dsc, dL_drotations=drt)
-        if precomp:
-            dense["dL_dcolors"] = dcl
-        else:
-            dense["dL_dsh"] = dsh
-        for k, t in dense.items():
-            a, b = got[k].reshape(P, -1), t.cpu().numpy().reshape(P, -1)
-            assert np.isfinite(b).all() and not b[untouched].any(), k
-            assert np.abs(a - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), k  # (the float atomics' run-to-run rounding)
