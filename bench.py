@@ -846,6 +846,17 @@ def main():
         else:
             allr = [mine]
         per_rank = [[float(x) for x in r.tolist()] for r in allr]
+        # do the replicas hold the same bits?  (the exchanged gradients of the last step; one MAX + one MIN all-reduce of
+        # an exact fingerprint, multiview.replicas_identical) -- a mismatch makes the run FAIL behind its line
+        from gaussianeditor_amd.multiview import replicas_identical
+
+        exchanged = [v for k, v in sorted(bucket.views.items()) if v is not None]
+        identical = bool(replicas_identical(exchanged)) if world > 1 else True
+        print(f"[bench rank {rank}] world_size seen by the {dist.get_backend() if dist.is_initialized() else 'no'} backend: "
+              f"{dist.get_world_size() if dist.is_initialized() else 1}, device {dev}, route {route['last']}, "
+              f"views {list(my_views)}, step {percentile(step_ms, 0.5) or 0.0:.3f} ms (local {percentile(local_ms, 0.5) or 0.0:.3f} + "
+              f"exchange {percentile(exch_ms, 0.5) or 0.0:.3f}), sent {int((lx or {}).get('bytes_sent', 0))} B, received "
+              f"{int((lx or {}).get('bytes_received', 0))} B, replicas identical: {identical}", file=sys.stderr, flush=True)
         try:
             nccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
         except Exception as ex:  # (a build without the binding)
@@ -857,6 +868,7 @@ def main():
             "shared_gpu_test_run": shared,
             "views_per_step": views, "views_per_rank": len(my_views),
             "route": route["last"],
+            "replicas_identical": identical,
             "per_rank": {"step_ms_gpu": [r[0] for r in per_rank],
                          "local_ms_gpu": [r[1] for r in per_rank],
                          "exchange_ms_gpu": [r[2] for r in per_rank],
@@ -1042,6 +1054,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
+    if multi_gpu is not None and not multi_gpu["replicas_identical"]:
+        raise SystemExit("bench.py: the ranks do NOT hold bit-identical gradients after the exchange (see the per-rank lines)")
 
 
 if __name__ == "__main__":

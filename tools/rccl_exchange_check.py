@@ -91,9 +91,18 @@ def main():
                     failures.append(f"{exch}/{route}: {k} is not bit-identical on rank {rank} and rank 0")
         if not torch.equal(radii, want_radii):
             failures.append(f"{exch}/{route}: batch-max radii differ")
-        if rank == 0:
-            print(f"[rccl_exchange_check] world {world} exchange {exch} route {route}: ok" if not failures else
-                  f"[rccl_exchange_check] failures so far: {failures}", flush=True)
+        # every rank says what IT saw (first contact with an 8-GPU node: the lines must agree with each other and with
+        # profiles/README.md, "what to run on the 8-GPU node")
+        from gaussianeditor_amd.multiview import replicas_identical
+
+        same = replicas_identical([bucket.views[k] for k in names])
+        if not same and route in ("rows",):
+            failures.append(f"{exch}/{route}: the replicas' gradients are not bit-identical")
+        lx = bucket.last_exchange or {}
+        print(f"[rccl_exchange_check rank {rank}] world_size seen by {dist.get_backend()}: {dist.get_world_size()}, device {dev}, "
+              f"exchange {exch} -> route {route} (expected {expect}), sent {int(lx.get('bytes_sent', 0))} B received "
+              f"{int(lx.get('bytes_received', 0))} B, replicas identical: {same}, "
+              f"{'ok' if not failures else 'FAILURES: ' + '; '.join(failures)}", flush=True)
     # sparse + persistent rows (GradBucket(sparse_rows=True, persistent_rows=True)) over several steps on ONE bucket: the
     # exchange writes only the rows some view touched, the backward rewrites a zero row only if it does not hold zeros
     # already; after every step the valid rows hold the batch sums, the others are zero (SH rows: not written at all)
