@@ -203,10 +203,13 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True, info=None):
             wg = rec[:nwg]
             livewg = wg[:, 1] > 0
             if bool(livewg.any()):
-                span = int((wg[livewg, 1].max() - wg[livewg, 0].min()).item())
+                # (the XCDs' cycle counters are not aligned with each other: a workgroup's own end - start is, the longest
+                #  workgroup stands for the launch -- the persistent workgroups all start within the first microsecond)
+                durs = (wg[livewg, 1] - wg[livewg, 0]).to(torch.float64)
+                span = int(durs.max().item())
                 items = rec[nwg:].reshape(-1, 4)[:, 0]
                 longest = int(items.max().item())
-                mean_wg = float((wg[livewg, 1] - wg[livewg, 0]).float().mean().item())
+                mean_wg = float(durs.mean().item())
                 info["critical_item_frac"] = longest / max(span, 1)
                 info["mean_workgroup_frac"] = mean_wg / max(span, 1)
                 info["k7_items"] = int((items > 0).sum().item())
