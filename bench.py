@@ -179,8 +179,8 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True, info=None):
             _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
                                                            p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
                                                            p(rs.projmatrix), p(rs.campos), tfx, tfy, p(radii_t), p(geom),
-                                                           p(acc_rows), p(d_m2), p(d_op), None, p(d_m3), p(d_cov), p(d_sh), p(d_sc),
-                                                           p(d_rot), 32))
+                                                           p(acc_rows), p(d_m2), p(d_op), None, p(d_m3), None, p(d_sh), p(d_sc),
+                                                           p(d_rot), 32))  # (no dL_dcolors / dL_dcov3D: SHs, scales + rotations)
             ev[5].record(s)
         torch.cuda.synchronize(dev)
         if it >= 2:

@@ -535,7 +535,8 @@ static int preprocess_backward_impl(void* stream, int P, int D, int M, int W, in
   if (!means3D || !viewmatrix || !projmatrix || !radii || !geom) return GSR_ERR_BAD_ARGUMENT;
   // this geometry state was left by gsr_preprocess(GSR_FLAG_FORWARD_ONLY): what K8+K9 reads of it was never written
   if (shs && geom_is_forward_only(geom)) return GSR_ERR_BAD_ARGUMENT;
-  if (!acc || ((uintptr_t)acc & 63u) || !dL_dmeans2D || !dL_dopacity || !dL_dmeans3D || !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;
+  if (!acc || ((uintptr_t)acc & 63u) || !dL_dmeans2D || !dL_dopacity || !dL_dmeans3D) return GSR_ERR_BAD_ARGUMENT;
+  if (cov3D_precomp && !dL_dcov3D) return GSR_ERR_BAD_ARGUMENT;  // (without a precomputed covariance its gradient is optional)
   if (shs && ((!dL_dsh && !dL_drgb) || !campos)) return GSR_ERR_BAD_ARGUMENT;
   if (scales && (!rotations || !dL_dscales || !dL_drots)) return GSR_ERR_BAD_ARGUMENT;
   if (!cov3D_precomp && !scales) return GSR_ERR_BAD_ARGUMENT;  // the 3D covariance is recomputed, not read from `geom`

@@ -816,7 +816,8 @@ preprocess_backward_kernel(const PreBwdArgs a) {
     // colour accumulator is not this kernel's input)
     const bool nonzero = nonzero_in;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+    for (int i = 0; i < 6; ++i)
+      if (a.dL_dcov3D != nullptr) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
     const uint8_t was = a.row_state[idx];
     if (!nonzero && was == 0) return;  // the rows hold the zeros written when this Gaussian last went from non-zero to zero
     if ((nonzero ? 1 : 0) != was) a.row_state[idx] = nonzero ? 1 : 0;
@@ -858,7 +859,8 @@ preprocess_backward_kernel(const PreBwdArgs a) {
   }
   if (!ROWS) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);
+    for (int i = 0; i < 6; ++i)
+      if (a.dL_dcov3D != nullptr) K9_ST(&a.dL_dcov3D[6 * (size_t)idx + i], dcov[i]);  // (null: no precomputed covariance to take a gradient)
   }
   if (a.dL_drgb != nullptr) {
     a.dL_drgb[3 * (size_t)idx] = drgb.x;

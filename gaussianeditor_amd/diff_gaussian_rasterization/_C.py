@@ -205,7 +205,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                  viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, sh, degree, campos,
                                  geomBuffer, R, binningBuffer, imageBuffer, debug, flags=None, grad_allocator=None):
     """RasterizeGaussiansBackwardCUDA, rasterize_points.cu:97-157 ->
-    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+    (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D | None, dL_dsh, dL_dscales, dL_drotations).
     `flags` (extension, keyword): the flags the forward of this view ran with; None = options.current_flags().
     `grad_allocator` (extension, keyword): fn(name, shape, zero) -> tensor | None for the gradient outputs, asked for
     "means2D", "opacities", "means3D", "cov3Ds_precomp", "sh", "scales", "rotations" with the tensor's shape.  An allocator
@@ -260,7 +260,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     dL_dcolors = (torch.zeros if grad_alloc is not None else torch.empty)((P, NUM_CHANNELS), dtype=torch.float32, device=dev) \
         if has_colors else None  # (with SHs: set below, once the table is chosen)
     dL_dmeans3D = _alloc(grad_alloc, "means3D", (P, 3), False, dev)
-    dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev)
+    # the gradient of cov3D_precomp: only where that input exists (the reference fills the tensor with its intermediate
+    # dL_dcov3D either way -- 24 B per Gaussian nobody reads when scales / rotations are given; here: None)
+    dL_dcov3D = _alloc(grad_alloc, "cov3Ds_precomp", (P, 6), False, dev) if cov3D_precomp.numel() != 0 else None
     # "rgb" exchange mode (multiview.py): an allocator that hands out a (P,3) "sh_rgb" tensor asks for the clamp-masked
     # colour gradient INSTEAD of the (P,M,3) SH gradient; dL_dsh is then returned as None and rebuilt after the exchange
     dL_drgb = grad_alloc("sh_rgb", (P, 3), False) if (grad_alloc is not None and M != 0) else None
@@ -301,7 +303,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), acc.data_ptr(),
-                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), col_out, dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), col_out, dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D),
                 _ptr(dL_dsh) if dL_drgb is None else None, None if dL_drgb is None else dL_drgb.data_ptr(),
                 dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None,
                 row_state.data_ptr()))
@@ -312,7 +314,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos), float(tan_fovx), float(tan_fovy),
                 radii.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer), imageBuffer.data_ptr(), dL_dpix.data_ptr(),
                 acc.data_ptr(), dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), col_out,
-                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
+                dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), _ptr(dL_dsh), dL_dscales.data_ptr() if has_scales else None,
                 dL_drotations.data_ptr() if has_scales else None, bwd_flags))
         else:
             # (also when nothing was rendered: the call then only clears the accumulator table)
@@ -326,7 +328,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), acc.data_ptr(),
-                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_drgb.data_ptr(),
+                dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), dL_drgb.data_ptr(),
                 dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None))
         if debug:
             torch.cuda.synchronize(dev)

@@ -232,7 +232,8 @@ int gsr_blend_forward_aux(void* stream, int P, int64_t R, int W, int H, const fl
  *       coarse-grained memory (on fine-grained memory the adds are silently lost).  The same holds for `weights` / `cnt` of
  *       gsr_trace_weights.
  *   Fully written by the library (no need to zero): dL_dmeans2D (P,3) [z = 0], dL_dopacity (P), dL_dcolors (P,3) [may be
- *       NULL: only a caller with precomputed colours needs it], dL_dmeans3D (P,3), dL_dcov3D (P,6),
+ *       NULL: only a caller with precomputed colours needs it], dL_dmeans3D (P,3), dL_dcov3D (P,6) [may be NULL when
+ *       cov3D_precomp is NULL: it is the gradient of that input; 24 B per Gaussian nobody reads otherwise],
  *       dL_dsh (P,M,3) [NULL if shs == NULL], dL_dscales (P,3) and dL_drots (P,4) [NULL if scales == NULL].
  *   (The reference zero-fills all nine of its outputs, rasterize_points.cu:120-128, and accumulates into four of them.) */
 int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, const float* bg, const float* means3D,
