@@ -174,7 +174,7 @@ def stage_times(dev, params, rs, G, D, flags, iters, backward=True, info=None):
         ev[3].record(s)
         if backward:
             _native.check("bwd", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc_rows),
-                                                      flags))
+                                                      None, flags))
             ev[4].record(s)
             _native.check("pbw", L.gsr_preprocess_backward(sp, P, D, M, W, H, p(params["xyz"]), p(params["features"]),
                                                            p(params["scaling"]), 1.0, p(params["rotation"]), None, p(rs.viewmatrix),
@@ -357,14 +357,24 @@ def extra_configs(dev, flags, budget_s=60.0):
         get_features = property(lambda s: s.t["features"])
 
     def timed(fn, steps, warmup):
+        # (the cyclic collector off around the timed steps, as around the headline's: one generation-2 pass is 50-90 ms -- inside
+        #  a 30-step window it turned a 0.86 ms step into 2.06 ms once, profiles/r06_z_bench.json)
+        import gc
+
         for _ in range(warmup):
             fn()
         torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            fn()
-        torch.cuda.synchronize(dev)
-        return (time.perf_counter() - t0) / steps
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / steps
+        finally:
+            if was:
+                gc.enable()
 
     # ---- C3 / C5 on the headline scene at the editor's 512 x 512
     sc = synth_scene(1_000_000, seed=0, s0=0.01)

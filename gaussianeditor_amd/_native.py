@@ -57,21 +57,21 @@ SIGNATURES = {
     "gsr_blend_forward_aux": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     "gsr_backward": (c_int, [_P, c_int, c_int, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, c_float, _P, _P, _P,
                              _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
-    # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags)
-    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),
+    # (stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, touched, flags)
+    "gsr_blend_backward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drots, flags)
     "gsr_preprocess_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                         c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_drgb, dL_dscales, dL_drots)
     "gsr_preprocess_backward_rgb": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
-                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                            c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_uint]),
     # (... radii, geom, acc, dL_dmeans2D, dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_drgb, dL_dscales, dL_drots, row_state)
     "gsr_preprocess_backward_rows": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_float, _P, _P, _P, _P, _P,
                                             c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gsr_sh_grad_compose": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "gsr_view_message_words": (c_int, [c_int64, c_int64, POINTER(c_int64)]),
     "gsr_view_message_plan": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, POINTER(c_int64)]),
-    "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P, _P]),
+    "gsr_view_message_plan_blend": (c_int, [_P, c_int64, _P, _P]),
     "gsr_view_message_pack": (c_int, [_P, c_int64, POINTER(DenseGrads), _P, _P, _P, _P, c_int64, _P]),
     "gsr_view_messages_accumulate": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads)]),
     "gsr_view_messages_accumulate_rows": (c_int, [_P, c_int64, c_int, c_int, c_int, _P, c_int64, c_int64, _P, POINTER(DenseGrads), _P]),

@@ -874,6 +874,10 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
         nz = ma != 0.f;
       }
       if (used && nz && emit) unsafeAtomicAdd(&a.acc[(size_t)sid[fb][p] * ACC_ROW + col], val);
+      if (a.touched != nullptr && emit) {  // (wave-uniform) the exchange's row mask, without a pass over the table: lane 15 of a
+        const uint64_t nzm = __ballot(used && nz);  // group marks the group's Gaussian if any of its columns was added to
+        if (col == 15u && p < fsize && ((nzm >> (16u * sub)) & 0xffffull) != 0ull) a.touched[sid[fb][p]] = 1;
+      }
       if (p < fsize && col < 9u) row[col] = 0.f;  // (every read of this instruction precedes it: one wave, program order)
     }
   };
@@ -1554,11 +1558,14 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     const long long P = a.P;
     clear.ptr[0] = a.acc; clear.n[0] = (long long)ACC_ROW * P;
   }
+  if (a.touched != nullptr) {  // the row mask always starts from zero (P bytes rounded up to whole floats: gsr.h asks for the padding)
+    clear.ptr[1] = reinterpret_cast<float*>(a.touched); clear.n[1] = ((long long)a.P + 3) / 4;
+  }
   if (a.work_est == nullptr || a.work_maxc == nullptr || a.bwd_order == nullptr) return hipErrorInvalidValue;
   {
     // its own work list, ordered by the work the forward measured
     static const int halves = [] { const char* e = getenv("GSR_BWD_HALVES"); return e ? atoi(e) : 10; }();  // tiles above 1.25 fair shares: measured best (sweep 6..16)
-    const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : 0u;  // (1 .. 8 per CU: the same 14 us)
+    const unsigned fill_blocks = a.clear_grads ? 2u * (unsigned)cus_of_stream(s) : (a.touched != nullptr ? 16u : 0u);  // (1 .. 8 per CU: the same 14 us)
     // GSR_BWD_SEG: tiles above this many eighths of a fair share are cut into list segments where the forward left
     // checkpoints (0: never; tests use 1)
     static const int seg_share = [] { const char* e = getenv("GSR_BWD_SEG"); return e ? atoi(e) : 5; }();

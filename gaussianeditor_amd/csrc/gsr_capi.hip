@@ -495,13 +495,16 @@ int gsr_debug_blend_forward_profile(void* stream, int P, int64_t R, int W, int H
 }
 
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags) {
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, uint8_t* touched,
+                       unsigned flags) {
   // (a backward of a view whose forward was declared forward-only: the flags of one view travel together)
   if ((flags & ~GSR_FLAG_ALL) || (flags & (GSR_FLAG_FORWARD_ONLY | GSR_FLAG_ACC_SELF_CLEAN))) return GSR_ERR_BAD_ARGUMENT;
   if (P == 0) return GSR_OK;
   if (P < 0 || !acc || ((uintptr_t)acc & 63u)) return GSR_ERR_BAD_ARGUMENT;  // (a row must not straddle two 64-byte lines)
+  if (touched != nullptr && ((uintptr_t)touched & 15u)) return GSR_ERR_BAD_ARGUMENT;
   if (R == 0) {  // nothing to blend: the accumulator rows stay zero -- or become zero
     if (flags & GSR_FLAG_CLEAR_GRADS) GSR_HIP(hipMemsetAsync(acc, 0, sizeof(float) * ACC_ROW * (size_t)P, (hipStream_t)stream));
+    if (touched != nullptr) GSR_HIP(hipMemsetAsync(touched, 0, (size_t)P, (hipStream_t)stream));
     return GSR_OK;
   }
   if (R < 0 || W <= 0 || H <= 0) return GSR_ERR_BAD_ARGUMENT;
@@ -514,6 +517,7 @@ int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float
   BlendArgs a = make_blend_args(W, H, g, b, im, bg, 1, R);
   a.dL_dpix = dL_dpix;
   a.acc = acc;
+  a.touched = touched;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
   a.P = P;
@@ -609,13 +613,15 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
                                 const float* scales, float scale_modifier, const float* rotations,
                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                const void* geom, float* acc, float* dL_dmeans2D, float* dL_dopacity,
                                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
-                                float* dL_dscales, float* dL_drots) {
+                                float* dL_dscales, float* dL_drots, unsigned flags) {
   if (!shs || !dL_drgb) return GSR_ERR_BAD_ARGUMENT;
+  if (flags & ~GSR_FLAG_ACC_SELF_CLEAN) return GSR_ERR_BAD_ARGUMENT;
   return preprocess_backward_impl(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                   viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,
-                                  nullptr, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots);
+                                  nullptr, dL_dmeans3D, dL_dcov3D, nullptr, dL_drgb, dL_dscales, dL_drots, nullptr,
+                                  (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0);
 }
 
 int gsr_preprocess_backward_rows(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
@@ -669,14 +675,10 @@ int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local,
   return GSR_OK;
 }
 
-int gsr_view_message_plan_blend(void* stream, int64_t P, const float* acc, uint8_t* mask, void* workspace) {
+int gsr_view_message_plan_blend(void* stream, int64_t P, const uint8_t* touched, void* workspace) {
   if (P == 0) return GSR_OK;
-  if (P < 0 || !acc || !mask || !workspace) return GSR_ERR_BAD_ARGUMENT;
-  hipStream_t s = (hipStream_t)stream;
-  const float* data[1] = {acc};
-  const int row_len[1] = {(int)ACC_ROW};
-  GSR_HIP(launch_touched_rows(s, P, 1, data, row_len, mask));
-  GSR_HIP(launch_compact_plan(s, P, mask, workspace));
+  if (P < 0 || !touched || !workspace) return GSR_ERR_BAD_ARGUMENT;
+  GSR_HIP(launch_compact_plan((hipStream_t)stream, P, touched, workspace));
   return GSR_OK;
 }
 
@@ -735,7 +737,7 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
   if (R > 0 && !binning) return GSR_ERR_BAD_ARGUMENT;
   const bool self_clean = (flags & GSR_FLAG_ACC_SELF_CLEAN) != 0;
   if (self_clean && (flags & GSR_FLAG_CLEAR_GRADS)) return GSR_ERR_BAD_ARGUMENT;
-  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, flags & ~GSR_FLAG_ACC_SELF_CLEAN);
+  int st = gsr_blend_backward(stream, P, R, W, H, bg, geom, binning, image, dL_dpix, acc, nullptr, flags & ~GSR_FLAG_ACC_SELF_CLEAN);
   if (st != GSR_OK) return st;
   return gsr_preprocess_backward(stream, P, D, M, W, H, means3D, shs, scales, scale_modifier, rotations, cov3D_precomp,
                                  viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom, acc, dL_dmeans2D, dL_dopacity,

@@ -84,6 +84,7 @@ struct BlendArgs {
   // backward
   const float* dL_dpix;
   float* acc;      // (P, ACC_ROW): one 64-byte row of accumulators per Gaussian (ACC_* columns, gsr_common.h / include/gsr.h)
+  uint8_t* touched;  // (P) | null: 1 for every Gaussian whose row this launch adds to (cleared by the launch itself)
   // tracing
   int C;
   const float* image_weights;

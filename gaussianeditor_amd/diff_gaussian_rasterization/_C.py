@@ -216,8 +216,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                            (GSR_FLAG_CLEAR_GRADS).  A float32 tensor of 16 P elements, 64-byte aligned, or None;
       "sh_rgb"             shape (P,3): a tensor here asks for the clamp-masked colour gradient INSTEAD of dL_dsh (which is
                            then returned as None; gaussianeditor_amd.multiview rebuilds it after the exchange);
-      "after_blend_backward"  a notification, only in the "sh_rgb" mode: `shape` is the accumulator table as a (P,16)
-                           tensor, K7 has been enqueued and K8+K9 has not; the return value is ignored;
+      "after_blend_backward"  a notification, only in the "sh_rgb" mode: `shape` is K7's row mask (uint8 (P,): 1 for every
+                           Gaussian whose accumulator row it adds to), K7 has been enqueued and K8+K9 has not; the return
+                           value is ignored;
       "row_state"          shape (P,): a uint8 tensor here says that "means2D", "opacities", "means3D", "sh" / "sh_rgb",
                            "scales" and "rotations" were answered with tensors the allocator keeps across calls, with this
                            per-Gaussian state next to them (include/gsr.h: gsr_preprocess_backward_rows): rows that still
@@ -273,11 +274,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if row_state is not None and not (isinstance(row_state, torch.Tensor) and row_state.dtype == torch.uint8 and
                                       row_state.numel() == P and row_state.is_contiguous() and row_state.device == dev):
         row_state = None
-    # Which table?  The plain route (gsr_backward, nobody reads the table between K7 and K8+K9) uses the one kept across
-    # backwards on this stream: zero on entry, zeroed again by K8+K9 -- no clear.  The exchange routes hand the table to a
-    # side stream between the two kernels (after_blend_backward): a fresh table, cleared by K7's own launch.
+    # Which table?  The one kept across backwards on this stream: zero on entry, zeroed again by K8+K9 -- no clear (nobody reads
+    # the table between K7 and K8+K9: the exchange routes plan their messages from K7's `touched` mask, handed to
+    # after_blend_backward).  With an allocator's own table or persistent rows: a table cleared by K7's own launch.
     stream = _stream(dev)
-    persist = _ACC_PERSIST and acc is None and row_state is None and dL_drgb is None
+    persist = _ACC_PERSIST and acc is None and row_state is None
     if persist:
         acc = _checkout_acc(dev, stream, P)
         bwd_flags = flags | options.FLAG_ACC_SELF_CLEAN
@@ -294,11 +295,12 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         col_out = dL_dcolors.data_ptr() if has_colors else None
         if row_state is not None:  # gradient arrays kept across calls: only the rows that change are written
             # (also when nothing was rendered: the call then only clears the accumulator table)
+            touched = torch.empty(((P + 15) // 16) * 16, dtype=torch.uint8, device=dev) if dL_drgb is not None else None
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), _ptr(touched), bwd_flags))
             if dL_drgb is not None:
-                grad_alloc("after_blend_backward", acc, False)
+                grad_alloc("after_blend_backward", touched[:P], False)
             _native.check("gsr_preprocess_backward_rows", L.gsr_preprocess_backward_rows(
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
@@ -318,18 +320,21 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 dL_drotations.data_ptr() if has_scales else None, bwd_flags))
         else:
             # (also when nothing was rendered: the call then only clears the accumulator table)
+            touched = torch.empty(((P + 15) // 16) * 16, dtype=torch.uint8, device=dev)  # K7 clears it and marks the rows it adds to
             _native.check("gsr_blend_backward", L.gsr_blend_backward(
                 _stream(dev), P, int(R), W, H, background.data_ptr(), geomBuffer.data_ptr(), _ptr(binningBuffer),
-                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), bwd_flags))
+                imageBuffer.data_ptr(), dL_dpix.data_ptr(), acc.data_ptr(), touched.data_ptr(),
+                bwd_flags & ~options.FLAG_ACC_SELF_CLEAN))
             # notification (no allocation): K7 is enqueued, K8+K9 not yet -- multiview.py starts the exchange of the
-            # touched-row counts here, so that it (and the host's wait for it) runs underneath K8+K9
-            grad_alloc("after_blend_backward", acc, False)
+            # touched-row counts here (from K7's row mask), so that it and the host's wait for it run underneath K8+K9
+            grad_alloc("after_blend_backward", touched[:P], False)
             _native.check("gsr_preprocess_backward_rgb", L.gsr_preprocess_backward_rgb(
                 _stream(dev), P, int(degree), M, W, H, means3D.data_ptr(), _ptr(sh), _ptr(scales), float(scale_modifier),
                 _ptr(rotations), _ptr(cov3D_precomp), viewmatrix.data_ptr(), projmatrix.data_ptr(), _ptr(campos),
                 float(tan_fovx), float(tan_fovy), radii.data_ptr(), geomBuffer.data_ptr(), acc.data_ptr(),
                 dL_dmeans2D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), dL_drgb.data_ptr(),
-                dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None))
+                dL_dscales.data_ptr() if has_scales else None, dL_drotations.data_ptr() if has_scales else None,
+                options.FLAG_ACC_SELF_CLEAN if persist else 0))
         if debug:
             torch.cuda.synchronize(dev)
     if persist:  # both halves are enqueued: in stream order the table is all zero again
@@ -390,25 +395,24 @@ def view_message_plan(grads5, rgb, readback=True):
     return (mask, work, P, dev), (int(count.value) if readback else work[:8].view(torch.int64))
 
 
-def view_message_plan_blend(acc):
-    """The same plan from the blend backward's accumulator table (P,16), i.e. BEFORE K8+K9 has run --
-    gsr_view_message_plan_blend.  Never synchronises: returns (plan, count) with count a 1-element int64 device tensor
-    valid in stream order."""
-    _require_cuda(acc, "acc")
-    dev, P = acc.device, int(acc.size(0))
+def view_message_plan_blend(touched):
+    """The same plan from the blend backward's row mask (uint8 (P,), written by K7 itself), i.e. BEFORE K8+K9 has run --
+    gsr_view_message_plan_blend.  The mask IS the plan's mask.  Never synchronises: returns (plan, count) with count a
+    1-element int64 device tensor valid in stream order."""
+    _require_cuda(touched, "touched")
+    dev, P = touched.device, int(touched.numel())
     if P == 0:
         return (None, None, 0, dev), torch.zeros(1, dtype=torch.int64, device=dev)
-    if acc.dim() != 2 or acc.size(1) != _native.ACC_ROW or not acc.is_contiguous() or acc.dtype != torch.float32:
-        raise RuntimeError("view_message_plan_blend: expected the (P,16) float32 accumulator table")
+    if touched.dtype != torch.uint8 or not touched.is_contiguous():
+        raise RuntimeError("view_message_plan_blend: expected the contiguous uint8 row mask of the blend backward")
     L = _native.lib()
-    mask = torch.empty(P, dtype=torch.uint8, device=dev)
     nbytes = ctypes.c_size_t(0)
     _native.check("gsr_compact_workspace_size", L.gsr_compact_workspace_size(P, ctypes.byref(nbytes)))
     work = torch.empty(int(nbytes.value), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _native.check("gsr_view_message_plan_blend", L.gsr_view_message_plan_blend(
-            _stream(dev), P, acc.data_ptr(), mask.data_ptr(), work.data_ptr()))
-    return (mask, work, P, dev), work[:8].view(torch.int64)
+            _stream(dev), P, touched.data_ptr(), work.data_ptr()))
+    return (touched, work, P, dev), work[:8].view(torch.int64)
 
 
 def view_message_pack(plan, grads5, rgb, campos, cap, message):

@@ -125,7 +125,7 @@ class GradBucket:
         #: "rgb" mode: this rank's clamp-masked colour gradient (P,3), written by the backward
         self.rgb = torch.zeros((P, 3), dtype=torch.float32, device=device) if sh_exchange == "rgb" else None
         self.sh_degree = None  # active SH degree of the last backward ("rgb" mode needs it to rebuild dL_dsh)
-        #: called with the blend backward's accumulator table (P,16) between K7 and K8+K9 (multiview_step sets it: the
+        #: called with the blend backward's row mask (uint8 (P,)) between K7 and K8+K9 (multiview_step sets it: the
         #: touched-row counts are exchanged from there, underneath K8+K9)
         self.on_blend_done = None
         self._pending_counts = None
@@ -170,7 +170,7 @@ class GradBucket:
             if ok and _DEBUG_ROWS:
                 self.check_persistent_rows()
             return self.row_state if ok else None
-        if name == "after_blend_backward":  # a notification, not an allocation (`shape` = the accumulator table, (P,16))
+        if name == "after_blend_backward":  # a notification, not an allocation (`shape` = K7's row mask, uint8 (P,))
             if self.on_blend_done is not None:
                 self.on_blend_done(shape)
             return None
@@ -303,14 +303,14 @@ _ROW_BYTES = 4 * 18
 _ROW_SEGS = ("means3D", "scales", "rotations", "means2D", "opacities")
 
 
-def _start_counts_exchange(bucket: GradBucket, acc, group, n: int):
-    """Called between K7 and K8+K9 of this rank's backward: marks the touched rows from the blend backward's accumulator
-    table, and exchanges the ranks' row counts -- on a side stream, so that the plan kernels, the tiny all-gather AND
+def _start_counts_exchange(bucket: GradBucket, touched, group, n: int):
+    """Called between K7 and K8+K9 of this rank's backward with K7's row mask (uint8 (P,): the Gaussians whose accumulator
+    rows it adds to): plans the message from it, and exchanges the ranks' row counts -- on a side stream, so that the plan kernels, the tiny all-gather AND
     the host's wait for its result all run while K8+K9 (~100 us) occupies the launch stream.  The step's one host
     synchronisation then costs the GPU nothing: when K8+K9 retires, pack / all-gather / accumulate are already queued."""
-    dev = acc.device
+    dev = touched.device
     if dev.type != "cuda":  # gloo on CPU (tests): nothing to overlap
-        plan, mine = _C.view_message_plan_blend(acc)
+        plan, mine = _C.view_message_plan_blend(touched)
         gathered = [torch.empty_like(mine) for _ in range(n)]
         dist.all_gather(gathered, mine, group=group)
         return plan, torch.cat(gathered), None
@@ -320,7 +320,8 @@ def _start_counts_exchange(bucket: GradBucket, acc, group, n: int):
     ready.record(main)  # K7 is enqueued in front of this
     with torch.cuda.stream(side):
         side.wait_event(ready)
-        plan, mine = _C.view_message_plan_blend(acc)
+        touched.record_stream(side)  # (allocated under the launch stream by the backward, read here)
+        plan, mine = _C.view_message_plan_blend(touched)
         gathered = torch.empty(n, dtype=torch.int64, device=dev)
         if dist.get_backend(group) == "nccl":
             dist.all_gather_into_tensor(gathered, mine.contiguous(), group=group)
@@ -500,8 +501,8 @@ def multiview_step(settings: GaussianRasterizationSettings, params: Dict[str, to
     if exchanging and bucket.sh_exchange == "rgb" and rows in ("auto", True):
         n = dist.get_world_size(group)
 
-        def start_counts(acc):  # between K7 and K8+K9 of this rank's backward
-            bucket._pending_counts = _start_counts_exchange(bucket, acc, group, n)
+        def start_counts(touched):  # between K7 and K8+K9 of this rank's backward
+            bucket._pending_counts = _start_counts_exchange(bucket, touched, group, n)
 
         bucket.on_blend_done = start_counts
     try:
@@ -598,9 +599,9 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
     speculate = spec_cap is not None
     state = {}
 
-    def after_blend(acc):  # between K7 and K8+K9 of a local view: mask + count on a side stream, underneath K8+K9
+    def after_blend(touched):  # between K7 and K8+K9 of a local view: mask + count on a side stream, underneath K8+K9
         if not on_gpu:
-            plan, mine = _C.view_message_plan_blend(acc)
+            plan, mine = _C.view_message_plan_blend(touched)
             state.update(plan=plan, count=mine, planned=None, done=None)
             return
         main = torch.cuda.current_stream(dev)
@@ -609,7 +610,8 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
         ready.record(main)
         with torch.cuda.stream(side):
             side.wait_event(ready)
-            plan, mine = _C.view_message_plan_blend(acc)
+            touched.record_stream(side)  # (allocated under the view's stream by the backward, read here)
+            plan, mine = _C.view_message_plan_blend(touched)
             planned = torch.cuda.Event()
             planned.record(side)
             host, done = mine, None

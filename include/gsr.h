@@ -135,13 +135,13 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
  *                        bar, but a pixel whose alpha or transmittance sits within a rounding of a threshold
  *                        (1/255, 1e-4) may take the other branch than the CPU oracle, so n_contrib / final_T are no
  *                        longer bit-identical to it (they are not bit-identical to the reference's libm build either).
- *   GSR_FLAG_ACC_SELF_CLEAN (ABI 5; read by gsr_backward / gsr_preprocess_backward) the accumulator table `acc` is one the caller KEEPS between
+ *   GSR_FLAG_ACC_SELF_CLEAN (ABI 5; read by gsr_backward / gsr_preprocess_backward / _rgb) the accumulator table `acc` is one the caller KEEPS between
  *       backwards: it is all zero on entry (the caller's promise -- hipMemset it once) and all zero again when the call has
  *       run: K8+K9, which reads every row anyway, writes zeros over the rows K7 touched (one Gaussian in ten on the
  *       benchmark view: 6 MB instead of a 64 MB clear in front of every backward).  Not combined with GSR_FLAG_CLEAR_GRADS
  *       (which it makes unnecessary).  With the two halves called separately: gsr_blend_backward WITHOUT GSR_FLAG_CLEAR_GRADS
- *       on the zero table, then gsr_preprocess_backward with this flag.  A caller that reads `acc` between the two halves
- *       on ANOTHER stream (gsr_view_message_plan_blend under K8+K9) must not use it;
+ *       on the zero table, then gsr_preprocess_backward (or _rgb) with this flag.  Nothing else may read `acc` while K8+K9
+ *       runs (the exchange plans its messages from K7's `touched` mask, not from the table);
  *   GSR_FLAG_SHARED_SIMDS (ABI 4; read by the blend / trace entry points) the caller overlaps this view's kernels with
  *                        another view's on a second stream: the persistent blend kernels are launched with 2 waves per
  *                        SIMD instead of 4, which leaves wave slots and registers for the other stream's kernels (a rank
@@ -249,8 +249,12 @@ int gsr_backward(void* stream, int P, int D, int M, int64_t R, int W, int H, con
  * (backward.cu:559-622).  gsr_backward == gsr_blend_backward followed by gsr_preprocess_backward.
  * After gsr_blend_backward alone `acc` holds the sums in the GSR_ACC_* columns; gsr_preprocess_backward reads them and
  * writes dL_dmeans2D / dL_dopacity (/ dL_dcolors) next to its own outputs. */
+/* `touched` (P bytes rounded up to a multiple of 16, 16-byte aligned, device; may be NULL): cleared by the call, then 1 for
+ * every Gaussian whose accumulator row K7 adds to -- the row mask of the multi-GPU exchange (gsr_view_message_plan_blend)
+ * without a pass over the 64 P bytes of the table. */
 int gsr_blend_backward(void* stream, int P, int64_t R, int W, int H, const float* bg, const void* geom,
-                       const void* binning, const void* image, const float* dL_dpix, float* acc, unsigned flags);
+                       const void* binning, const void* image, const float* dL_dpix, float* acc, uint8_t* touched,
+                       unsigned flags);
 int gsr_preprocess_backward(void* stream, int P, int D, int M, int W, int H, const float* means3D, const float* shs,
                             const float* scales, float scale_modifier, const float* rotations,
                             const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
@@ -271,9 +275,9 @@ int gsr_preprocess_backward_rgb(void* stream, int P, int D, int M, int W, int H,
                                 const float* scales, float scale_modifier, const float* rotations,
                                 const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                                 const float* campos, float tan_fovx, float tan_fovy, const int32_t* radii,
-                                const void* geom, const float* acc, float* dL_dmeans2D, float* dL_dopacity,
+                                const void* geom, float* acc, float* dL_dmeans2D, float* dL_dopacity,
                                 float* dL_dmeans3D, float* dL_dcov3D, float* dL_drgb,
-                                float* dL_dscales, float* dL_drots);
+                                float* dL_dscales, float* dL_drots, unsigned flags /* 0 | GSR_FLAG_ACC_SELF_CLEAN */);
 
 /* The same kernel for gradient arrays the caller keeps ACROSS calls (a training loop's gradient bucket).  A view leaves
  * nine Gaussians of ten with all-zero gradients (culled, or blended by no pixel), and rewriting those zeros is most of
@@ -383,9 +387,9 @@ int gsr_adam_step_rows(void* stream, int num_tensors, const gsr_adam_tensor* ten
  *                                 does not block: the count is then the uint64 at the start of `workspace`, in
  *                                 stream order (multiview.py all-gathers it from there: one host sync for all ranks'
  *                                 counts instead of two);
- *   gsr_view_message_plan_blend   the same plan from what gsr_blend_backward ALONE leaves behind -- its accumulator table
- *                                 `acc` (P, GSR_ACC_ROW): a Gaussian no pixel
- *                                 blended has an all-zero row there, and gsr_preprocess_backward turns all-zero rows into
+ *   gsr_view_message_plan_blend   the same plan from what gsr_blend_backward ALONE leaves behind -- the `touched` mask it
+ *                                 writes next to its accumulator table (which then IS the plan's mask): a Gaussian no pixel
+ *                                 blended has an all-zero row in the table and a 0 there, and gsr_preprocess_backward turns all-zero rows into
  *                                 all-zero gradients, so this mask is a superset of gsr_view_message_plan's (a row it
  *                                 adds carries zeros: the sums do not change).  It never blocks; the count is the uint64 at
  *                                 the start of `workspace`.  Purpose: the ranks can exchange their counts and the host can
@@ -412,7 +416,7 @@ typedef struct gsr_dense_grads {
 int gsr_view_message_words(int64_t P, int64_t cap, int64_t* words);
 int gsr_view_message_plan(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, uint8_t* mask,
                           void* workspace, int64_t* count_host);
-int gsr_view_message_plan_blend(void* stream, int64_t P, const float* acc, uint8_t* mask, void* workspace);
+int gsr_view_message_plan_blend(void* stream, int64_t P, const uint8_t* touched, void* workspace);
 int gsr_view_message_pack(void* stream, int64_t P, const gsr_dense_grads* local, const float* rgb, const float* campos,
                           const uint8_t* mask, void* workspace, int64_t cap, float* message);
 int gsr_view_messages_accumulate(void* stream, int64_t P, int D, int M, int num_views, const float* messages,

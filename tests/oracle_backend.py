@@ -52,13 +52,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     if grad_allocator is not None:
         grad_allocator("acc_rows", (16 * P,), False)  # (the binding's first request of a backward)
     if M != 0 and grad_allocator is not None and grad_allocator("sh_rgb", (P, 3), False) is not None:
-        # the notification between K7 and K8+K9: the blend backward's accumulator table, (P,16) (include/gsr.h: GSR_ACC_*)
-        acc = torch.zeros((P, 16), dtype=torch.float32)
-        acc[:, 0:2] = torch.from_numpy(np.ascontiguousarray(g["dL_dmeans2D"])).reshape(P, 3)[:, :2]
-        acc[:, 3] = torch.from_numpy(np.ascontiguousarray(g["dL_dopacity"])).reshape(P)
-        acc[:, 4:8] = torch.from_numpy(np.ascontiguousarray(g["dL_dconic"])).reshape(P, 4)
-        acc[:, 8:11] = torch.from_numpy(np.ascontiguousarray(g["dL_dcolors"])).reshape(P, 3)
-        grad_allocator("after_blend_backward", acc, False)
+        # the notification between K7 and K8+K9: K7's row mask (uint8 (P,): the Gaussians whose accumulator rows -- dL_dmeans2D,
+        # dL_dopacity, dL_dconic, dL_dcolors; include/gsr.h GSR_ACC_* -- it adds to)
+        rows = np.concatenate([np.ascontiguousarray(g[k]).reshape(P, -1) for k in ("dL_dmeans2D", "dL_dopacity", "dL_dconic", "dL_dcolors")],
+                              axis=1)
+        grad_allocator("after_blend_backward", torch.from_numpy((rows != 0).any(axis=1).astype(np.uint8)), False)
     out = []
     for name, key, shape in (("means2D", "dL_dmeans2D", (P, 3)), ("colors_precomp", "dL_dcolors", (P, 3)),
                              ("opacities", "dL_dopacity", (P, 1)), ("means3D", "dL_dmeans3D", (P, 3)),
@@ -95,9 +93,8 @@ def view_message_plan(grads5, rgb, readback=True):
     return idx, (int(idx.numel()) if readback else torch.tensor([idx.numel()], dtype=torch.int64))
 
 
-def view_message_plan_blend(acc):
-    rows = acc.reshape(int(acc.size(0)), -1)
-    idx = (rows != 0).any(dim=1).nonzero().view(-1)
+def view_message_plan_blend(touched):
+    idx = (touched != 0).nonzero().view(-1)
     return idx, torch.tensor([idx.numel()], dtype=torch.int64)
 
 

@@ -104,13 +104,13 @@ def test_argument_validation_needs_no_gpu():
     assert L.gsr_preprocess(None, 10, 3, 16, one, one, 1.0, one, one, one, None, None, one, one, one, 64, 64, 1.0, 1.0,
                             0, 0, 64, one, one, r) == -1
     assert L.gsr_blend_forward(None, 10, 5, 64, 64, one, one, one, one, one, one, 64) == -1
-    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, 64) == -1
+    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, one, None, 64) == -1
     assert L.gsr_trace_weights(None, 10, 5, 64, 64, 1, one, one, one, one, one, one, 64) == -1
     # the blend backward's work items carry the tile id in 20 bits (GSR_MAX_TILES of include/gsr.h): a larger image is
     # refused, not walked with masked tile ids (16 400^2 pixels = 1 025^2 tiles > 2^20)
-    assert L.gsr_blend_backward(None, 10, 5, 16400, 16400, one, one, one, one, one, one, 0) == -1
+    assert L.gsr_blend_backward(None, 10, 5, 16400, 16400, one, one, one, one, one, one, None, 0) == -1
     # the accumulator table must not straddle 64-byte lines (one memory-side request per row)
-    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, ctypes.c_void_p(256 + 16), 0) == -1
+    assert L.gsr_blend_backward(None, 10, 5, 64, 64, one, one, one, one, one, ctypes.c_void_p(256 + 16), None, 0) == -1
     assert "GSR_MAX_TILES (1 << 20)" in open(os.path.join(ROOT, "include", "gsr.h")).read()
 
 
@@ -175,13 +175,13 @@ def test_forward_only_flag_is_refused_by_the_backward_entry_points():
 
     L = _native.lib()
     one = ctypes.c_void_p(256)  # never dereferenced: the flags are rejected first
-    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, 8)
+    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, None, 8)
     assert st == -1 and b"bad argument" in L.gsr_status_string(st)
-    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, 8 | 4)
+    st = L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, None, 8 | 4)
     assert st == -1
     # GSR_FLAG_ACC_SELF_CLEAN (32) belongs to gsr_backward alone -- K7 on its own cannot leave the table zero --, and not next to
     # GSR_FLAG_CLEAR_GRADS (4)
-    assert L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, 32) == -1
+    assert L.gsr_blend_backward(None, 4, 4, 32, 32, one, one, one, one, one, one, None, 32) == -1
     assert L.gsr_backward(None, 4, 3, 16, 4, 32, 32, one, one, one, None, one, 1.0, one, None, one, one, one, 1.0, 1.0, one, one, one,
                           one, one, one, one, one, None, one, one, one, one, one, 32 | 4) == -1
 

@@ -58,10 +58,10 @@ def _worker_rgb(rank, world, port, out_dir, rows, s0, P=P):
             touched_of = []
             orig = allreduce_view_grads.__globals__["_C"].view_message_plan_blend
 
-            def spy(acc):  # the whole step plans from the blend backward's accumulator table (P,16), between K7 and K8+K9
-                assert tuple(acc.shape) == (P, 16)
-                touched_of.append(float((acc != 0).any(dim=1).float().mean()))
-                return orig(acc)
+            def spy(touched):  # the whole step plans from the blend backward's row mask (uint8 (P,)), between K7 and K8+K9
+                assert tuple(touched.shape) == (P,) and touched.dtype == torch.uint8
+                touched_of.append(float((touched != 0).float().mean()))
+                return orig(touched)
 
             mpatch.setattr(allreduce_view_grads.__globals__["_C"], "view_message_plan_blend", spy)
             params = {k: sc[k] for k in ("xyz", "opacity", "features", "scaling", "rotation")}

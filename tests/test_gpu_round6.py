@@ -327,3 +327,43 @@ def test_accumulator_table_kept_across_backwards_is_left_zero():
     finally:
         _C._ACC_PERSIST = was
         _C._ACC_TABLES.clear()
+
+
+def test_blend_backward_row_mask_equals_the_nonzero_rows_of_its_table():
+    """gsr_blend_backward's `touched` mask (what the multi-GPU exchange plans its messages from, without a pass over the
+    64 P bytes of the table): cleared by the call, 1 exactly for the Gaussians whose accumulator row is not all zero --
+    on a small image, on SPLIT / half-tile items, and when nothing is rendered."""
+    import ctypes
+
+    from gaussianeditor_amd import _native
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+    from helpers import seed_gradient
+
+    L = _native.lib()
+    for P, W, H, s0, seed in ((20011, 320, 200, 0.02, 6), (5000, 640, 360, 0.4, 21), (977, 33, 17, 0.3, 8)):
+        case = make_case(P, W, H, seed=seed, s0=s0)
+        sc, rs = case["sc"], settings(case, DEV)
+        d = lambda t: t.to(DEV)  # noqa: E731
+        e = torch.empty(0, device=DEV)
+        R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+            rs.bg, d(sc["xyz"]), e, d(sc["opacity"]), d(sc["scaling"]), d(sc["rotation"]), 1.0, e, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, H, W, d(sc["features"]), 3, rs.campos, False, False)
+        G = d(seed_gradient(H, W, seed) * (H * W))
+        acc = torch.full((P, 16), float("nan"), device=DEV)
+        touched = torch.full((((P + 15) // 16) * 16,), 7, dtype=torch.uint8, device=DEV)
+        sp = torch.cuda.current_stream().cuda_stream
+        p = lambda t: t.data_ptr()  # noqa: E731
+        _native.check("k7", L.gsr_blend_backward(sp, P, R, W, H, p(rs.bg), p(geom), p(binning), p(img), p(G), p(acc), p(touched), 4))
+        torch.cuda.synchronize()
+        rows = (acc != 0).any(dim=1)
+        assert bool(torch.isfinite(acc).all()) and 0 < int(rows.sum()) < P
+        assert torch.equal(touched[:P] != 0, rows) and int(touched[:P].max()) == 1
+        # ... and the plan built from it counts exactly those rows
+        plan, count = _C.view_message_plan_blend(touched[:P])
+        torch.cuda.synchronize()
+        assert int(count.item()) == int(rows.sum())
+    # nothing rendered: the mask is cleared all the same
+    touched.fill_(9)
+    _native.check("k7", L.gsr_blend_backward(sp, P, 0, W, H, p(rs.bg), p(geom), None, p(img), p(G), p(acc), p(touched), 4))
+    torch.cuda.synchronize()
+    assert not bool(touched[:P].any())
