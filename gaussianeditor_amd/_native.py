@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #: GSR_LIBRARY_PATH (development only: A/B timing of differently built libraries, tools/ab_variants.py) replaces the
 #: in-tree library; it must export the same ABI and is loaded under the same "no fallback" rule.
 LIB_PATH = os.environ.get("GSR_LIBRARY_PATH") or os.path.join(_HERE, "libgsr_hip.so")
-GSR_ABI_VERSION = 5
+GSR_ABI_VERSION = 6
 
 _P = c_void_p
 #: floats per row of the blend backward's accumulator table and its columns (include/gsr.h: GSR_ACC_*)
@@ -51,6 +51,9 @@ SIGNATURES = {
     "gsr_sort_key_bits": (c_int, [c_int, c_int]),
     "gsr_preprocess": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
                                c_float, c_float, c_int, c_int, c_uint, _P, _P, POINTER(c_int64)]),
+    "gsr_preprocess_begin": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
+                                     c_float, c_float, c_int, c_int, c_uint, _P, _P, POINTER(_P)]),
+    "gsr_preprocess_end": (c_int, [_P, c_int, c_int, c_int, _P, _P, POINTER(c_int64)]),
     "gsr_arrays_equal": (c_int, [_P, c_int, POINTER(_P), POINTER(_P), POINTER(c_size_t), POINTER(c_int)]),
     "gsr_bin": (c_int, [_P, c_int, c_int64, c_int64, c_int, c_int, _P, _P, _P]),
     "gsr_blend_forward": (c_int, [_P, c_int, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P, c_uint]),

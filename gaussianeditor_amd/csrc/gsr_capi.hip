@@ -53,6 +53,28 @@ struct ThreadSlots {
   }
 };
 
+// A fresh slot for device `dev` (pinned, device-mapped, zeroed).
+HostSlot* new_slot(int dev, hipError_t* err) {
+  int cur = -1;
+  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
+  void* p = nullptr;
+  void* dp = nullptr;
+  HostSlot* h = nullptr;
+  if ((*err = hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped)) == hipSuccess) {
+    if ((*err = hipHostGetDevicePointer(&dp, p, 0)) == hipSuccess) {
+      memset(p, 0, GEOM_HDR_BYTES);
+      h = new HostSlot();
+      h->words = (uint32_t*)p;
+      h->dev_words = (uint32_t*)dp;
+      h->device = dev;
+    } else {
+      (void)hipHostFree(p);
+    }
+  }
+  if (switched) (void)hipSetDevice(cur);
+  return h;
+}
+
 // The slot of the calling thread for the device `stream` belongs to (NOT the thread's current device: a C-ABI caller
 // may hand over a stream of another device).
 // On failure *err tells why: hipSuccess = the device ordinal is outside the pool (an argument problem), otherwise the
@@ -78,24 +100,8 @@ HostSlot* host_slot(hipStream_t stream, hipError_t* err) {
       return h;
     }
   }
-  int cur = -1;
-  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != dev && hipSetDevice(dev) == hipSuccess;
-  void* p = nullptr;
-  void* dp = nullptr;
-  HostSlot* h = nullptr;
-  if ((*err = hipHostMalloc(&p, GEOM_HDR_BYTES, hipHostMallocPortable | hipHostMallocMapped)) == hipSuccess) {
-    if ((*err = hipHostGetDevicePointer(&dp, p, 0)) == hipSuccess) {
-      memset(p, 0, GEOM_HDR_BYTES);
-      h = new HostSlot();
-      h->words = (uint32_t*)p;
-      h->dev_words = (uint32_t*)dp;
-      h->device = dev;
-      mine.held[dev] = h;
-    } else {
-      (void)hipHostFree(p);
-    }
-  }
-  if (switched) (void)hipSetDevice(cur);
+  HostSlot* h = new_slot(dev, err);
+  mine.held[dev] = h;
   return h;
 }
 
@@ -308,18 +314,41 @@ int gsr_scratch_sizes(int P, int64_t R, int64_t G, int W, int H, size_t sizes[3]
   return GSR_OK;
 }
 
-int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
-                   const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
-                   const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
-                   int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, unsigned flags,
-                   int32_t* radii, void* geom, int64_t counts_host[2]) {
-  // `prefiltered`: the reference promises with it that no point fails the frustum test and TRAPS the device when one
-  // does (auxiliary.h:156-160).  No caller sets it (render() passes False, gaussian_renderer/__init__.py:83); a culled
-  // point is simply culled here, which is what the flag's absence does.
-  (void)prefiltered;
-  if (counts_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
-  counts_host[0] = counts_host[1] = 0;
-  if (P == 0) return GSR_OK;
+namespace {
+// A slot of its own for a split readback (gsr_preprocess_begin .. _end): taken from the pool, not the thread's held one, so
+// that any number of views may be in flight on one thread and _end may run on another.
+HostSlot* checkout_slot(hipStream_t stream, hipError_t* err) {
+  int dev = 0;
+  hipDevice_t sdev = 0;
+  *err = hipSuccess;
+  if (stream != nullptr && hipStreamGetDevice(stream, &sdev) == hipSuccess)
+    dev = (int)sdev;
+  else if ((*err = hipGetDevice(&dev)) != hipSuccess)
+    return nullptr;
+  if (dev < 0 || dev >= MAX_DEV) return nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    if (g_pool_free[dev] != nullptr) {
+      HostSlot* h = g_pool_free[dev];
+      g_pool_free[dev] = h->next_free;
+      h->next_free = nullptr;
+      return h;
+    }
+  }
+  return new_slot(dev, err);
+}
+void return_slot(HostSlot* h) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  h->next_free = g_pool_free[h->device];
+  g_pool_free[h->device] = h;
+}
+
+// The argument checks of gsr_preprocess / gsr_preprocess_begin (before anything touches the runtime: they answer on a machine
+// without a GPU too).
+int preprocess_args_ok(int P, int D, int M, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp, const float* colors_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* campos, int W, int H, int skip_color,
+                       unsigned flags, const int32_t* radii, const void* geom) {
   if (P < 0 || W <= 0 || H <= 0 || D < 0 || D > 3 || (flags & ~GSR_FLAG_ALL)) return GSR_ERR_BAD_ARGUMENT;
   if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii || !geom || misaligned(geom)) return GSR_ERR_BAD_ARGUMENT;
   if (cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr)) return GSR_ERR_BAD_ARGUMENT;
@@ -329,7 +358,16 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
     if (colors_precomp == nullptr && (shs == nullptr || campos == nullptr)) return GSR_ERR_BAD_ARGUMENT;
     if (colors_precomp == nullptr && M < (D + 1) * (D + 1)) return GSR_ERR_BAD_ARGUMENT;
   }
-  hipStream_t s = (hipStream_t)stream;
+  return GSR_OK;
+}
+
+// First half of gsr_preprocess: K1 and the two depth-sort passes that never depend on the key range; the
+// first of them publishes the counts into `slot` behind generation `*seq`.
+int preprocess_begin_impl(hipStream_t s, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                          const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                          const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                          int W, int H, float tan_fovx, float tan_fovy, int skip_color, unsigned flags, int32_t* radii,
+                          void* geom, HostSlot* slot, uint32_t* seq_out) {
   PreArgs a;
   a.P = P; a.D = D; a.M = M;
   a.means3D = means3D; a.scales = scales; a.scale_modifier = scale_modifier; a.rotations = rotations;
@@ -350,18 +388,23 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   // num_rendered (and the range of the depth keys); the first kernel behind it -- the histogram of the first depth-sort
   // pass -- writes those words into pinned, device-mapped host memory, a generation word last.  The first two passes of
   // the depth sort are enqueued at once and run while the host waits.
-  hipError_t slot_err = hipSuccess;
-  HostSlot* slot = host_slot(s, &slot_err);
-  if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT /* device ordinal beyond the pool */ : hip_fail(slot_err);
   const uint32_t seq = ++slot->seq ? slot->seq : ++slot->seq;  // (never 0: that is what a fresh slot holds)
-  const int legacy = bin_legacy(W, H);
-  if (legacy) GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
+  *seq_out = seq;
+  if (bin_legacy(W, H)) GSR_HIP(launch_depth_passes(s, P, a.g, 0, 2, slot->dev_words, seq));
   else GSR_HIP(launch_depth_passes_grouped(s, P, a.g, 0, 2, false, slot->dev_words, seq));
+  return GSR_OK;
+}
+
+// Second half: wait for the counts, launch the depth-sort passes that needed the key range.
+int preprocess_end_impl(hipStream_t s, int P, int W, int H, void* geom, HostSlot* slot, uint32_t seq, int64_t counts_host[2]) {
   // Poll the generation word (an event would put a barrier packet into the stream -- a 6 us bubble -- and sleeping on
   // an interrupt costs far more than the ~80 us normally waited for).  The spin is BOUNDED in time: after 5 ms (a long
   // queue of earlier work on the stream, or a failed launch) the thread stops burning a core and blocks in
   // hipStreamSynchronize, which also surfaces any launch error; the word is then either there or the call fails.
   GSR_HIP(wait_for_slot(slot, seq, s));
+  const Geom g = carve_geom(geom, P);
+  const int gx = (W + TILE - 1) / TILE;
+  const int legacy = bin_legacy(W, H);
   const uint32_t* w = slot->words;
   const uint64_t total = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
   const uint32_t kmax = w[GEOM_HDR_KEYMAX], kinv = w[GEOM_HDR_KEYINVMAX];
@@ -371,19 +414,85 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
   for (uint32_t d = total ? (kmax ^ kmin) : 0u; d; d >>= 1) ++nbits;
   if (legacy) {
     const int passes = nbits <= 16 ? 2 : (nbits + 7) / 8;
-    if (passes > 2) GSR_HIP(launch_depth_passes(s, P, a.g, 2, passes));
-    GSR_HIP(launch_depth_finish(s, P, a.g, passes, a.gx, 0));
+    if (passes > 2) GSR_HIP(launch_depth_passes(s, P, g, 2, passes));
+    GSR_HIP(launch_depth_finish(s, P, g, passes, gx, 0));
   } else {
     // The LAST pass also leaves what the emission of gsr_bin needs (depth_scatter_kernel<true>), and which pass that is
     // is only known now: at least one pass follows the two that ran under the wait (a key range of <= 16 bits: its
     // digit is the same for every key -- a stable pass that moves nothing).
     const int passes = nbits <= 24 ? 3 : 4;
-    GSR_HIP(launch_depth_passes_grouped(s, P, a.g, 2, passes, true));
+    GSR_HIP(launch_depth_passes_grouped(s, P, g, 2, passes, true));
   }
   if (total >= (1ull << 31)) return GSR_ERR_TOO_MANY;
   counts_host[0] = (int64_t)total;
   counts_host[1] = legacy ? 0 : (int64_t)((uint64_t)w[GEOM_HDR_GROUPS] | ((uint64_t)w[GEOM_HDR_GROUPS + 1] << 32));
   return GSR_OK;
+}
+}  // namespace
+
+int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                   const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                   const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                   int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, unsigned flags,
+                   int32_t* radii, void* geom, int64_t counts_host[2]) {
+  // `prefiltered`: the reference promises with it that no point fails the frustum test and TRAPS the device when one
+  // does (auxiliary.h:156-160).  No caller sets it (render() passes False, gaussian_renderer/__init__.py:83); a culled
+  // point is simply culled here, which is what the flag's absence does.
+  (void)prefiltered;
+  if (counts_host == nullptr) return GSR_ERR_BAD_ARGUMENT;
+  counts_host[0] = counts_host[1] = 0;
+  if (P == 0) return GSR_OK;
+  const int ok = preprocess_args_ok(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                    viewmatrix, projmatrix, campos, W, H, skip_color, flags, radii, geom);
+  if (ok != GSR_OK) return ok;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t slot_err = hipSuccess;
+  HostSlot* slot = host_slot(s, &slot_err);
+  if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT /* device ordinal beyond the pool */ : hip_fail(slot_err);
+  uint32_t seq = 0;
+  const int st = preprocess_begin_impl(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                                       colors_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, skip_color,
+                                       flags, radii, geom, slot, &seq);
+  if (st != GSR_OK) return st;
+  return preprocess_end_impl(s, P, W, H, geom, slot, seq, counts_host);
+}
+
+int gsr_preprocess_begin(void* stream, int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                         const float* rotations, const float* opacities, const float* shs, const float* cov3D_precomp,
+                         const float* colors_precomp, const float* viewmatrix, const float* projmatrix, const float* campos,
+                         int W, int H, float tan_fovx, float tan_fovy, int prefiltered, int skip_color, unsigned flags,
+                         int32_t* radii, void* geom, void** ticket) {
+  (void)prefiltered;
+  if (ticket == nullptr) return GSR_ERR_BAD_ARGUMENT;
+  *ticket = nullptr;
+  if (P <= 0) return GSR_ERR_BAD_ARGUMENT;  // (nothing to wait for: an empty scene takes gsr_preprocess)
+  const int ok = preprocess_args_ok(P, D, M, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                                    viewmatrix, projmatrix, campos, W, H, skip_color, flags, radii, geom);
+  if (ok != GSR_OK) return ok;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t slot_err = hipSuccess;
+  HostSlot* slot = checkout_slot(s, &slot_err);
+  if (slot == nullptr) return slot_err == hipSuccess ? GSR_ERR_BAD_ARGUMENT : hip_fail(slot_err);
+  uint32_t seq = 0;
+  const int st = preprocess_begin_impl(s, P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs, cov3D_precomp,
+                                       colors_precomp, viewmatrix, projmatrix, campos, W, H, tan_fovx, tan_fovy, skip_color,
+                                       flags, radii, geom, slot, &seq);
+  if (st != GSR_OK) {
+    return_slot(slot);
+    return st;
+  }
+  *ticket = slot;  // (its `seq` is the generation to wait for: a slot serves one view at a time)
+  return GSR_OK;
+}
+
+int gsr_preprocess_end(void* stream, int P, int W, int H, void* geom, void* ticket, int64_t counts_host[2]) {
+  if (ticket == nullptr || counts_host == nullptr || P <= 0 || W <= 0 || H <= 0 || !geom || misaligned(geom))
+    return GSR_ERR_BAD_ARGUMENT;
+  counts_host[0] = counts_host[1] = 0;
+  HostSlot* slot = (HostSlot*)ticket;
+  const int st = preprocess_end_impl((hipStream_t)stream, P, W, H, geom, slot, slot->seq, counts_host);
+  return_slot(slot);  // (also after a failure: the ticket is spent either way)
+  return st;
 }
 
 int gsr_arrays_equal(void* stream, int n, const void* const* a, const void* const* b, const size_t* bytes, int* equal_host) {

@@ -82,7 +82,14 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(device: torch.device) -> int:
+    """The current stream of `device` as a raw hipStream_t (torch.cuda.current_stream() builds a Stream object per call: 5 us
+    each, a dozen times per view, on a launch thread the pipelined view batch is bound by)."""
+    if _raw_stream is not None and device.index is not None:
+        return _raw_stream(device.index)
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -148,6 +155,82 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         if debug:
             torch.cuda.synchronize(dev)  # CHECK_CUDA, auxiliary.h:166-173
     return R, out_color, out_depth, radii, geom, binning, img
+
+
+class PendingForward:
+    """What rasterize_gaussians_begin() leaves for rasterize_gaussians_finish(): the view's arguments, its outputs so far and
+    the native ticket of its counts."""
+    __slots__ = ("dev", "stream", "P", "H", "W", "flags", "debug", "background", "radii", "geom", "ticket", "keep")
+
+
+def rasterize_gaussians_begin(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                              viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                              prefiltered, debug, flags=None) -> "PendingForward":
+    """First half of rasterize_gaussians() (extension, no reference counterpart; include/gsr.h gsr_preprocess_begin): K1 and
+    the first depth-sort passes are enqueued on the current stream and the call returns WITHOUT waiting for num_rendered.
+    rasterize_gaussians_finish(pending), on the same stream, does the rest and returns what rasterize_gaussians() returns;
+    between the two the launch thread may enqueue other work (the view batch of multiview.py: the next view's begin comes
+    before this view's backward, so the host never waits for a readback).  The argument tensors must stay unchanged until
+    finish returned (they are kept alive here)."""
+    flags = _flags(flags)
+    _check_means(means3D)
+    _require_cuda(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    if P == 0:
+        raise RuntimeError("rasterize_gaussians_begin: an empty scene has nothing to wait for; call rasterize_gaussians()")
+    M = int(sh.size(1)) if sh.size(0) != 0 else 0
+    means3D, opacity = _f32(means3D, "means3D"), _f32(opacity, "opacity", dev)
+    background, viewmatrix, projmatrix, campos = (_f32(background, "bg", dev), _f32(viewmatrix, "viewmatrix", dev),
+                                                  _f32(projmatrix, "projmatrix", dev), _f32(campos, "campos", dev))
+    colors, scales, rotations, cov3D_precomp, sh = (_f32(colors, "colors_precomp", dev), _f32(scales, "scales", dev),
+                                                    _f32(rotations, "rotations", dev),
+                                                    _f32(cov3D_precomp, "cov3D_precomp", dev), _f32(sh, "sh", dev))
+    pf = PendingForward()
+    pf.dev, pf.P, pf.H, pf.W, pf.flags, pf.debug, pf.background = dev, P, H, W, flags, bool(debug), background
+    pf.keep = (means3D, opacity, viewmatrix, projmatrix, campos, colors, scales, rotations, cov3D_precomp, sh)
+    pf.radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        pf.stream = _stream(dev)
+        gbytes, _, _ = _native.scratch_sizes(P, 0, W, H)
+        pf.geom = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+        ticket = ctypes.c_void_p()
+        _native.check("gsr_preprocess_begin", _native.lib().gsr_preprocess_begin(
+            pf.stream, P, int(degree), M, _ptr(means3D), _ptr(scales), float(scale_modifier), _ptr(rotations), _ptr(opacity),
+            _ptr(sh), _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H,
+            float(tan_fovx), float(tan_fovy), int(bool(prefiltered)), 0, flags, pf.radii.data_ptr(), pf.geom.data_ptr(),
+            ctypes.byref(ticket)))
+    pf.ticket = ticket
+    return pf
+
+
+def rasterize_gaussians_finish(pf: "PendingForward"):
+    """Second half of rasterize_gaussians(): -> (num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    if pf.ticket is None:
+        raise RuntimeError("rasterize_gaussians_finish: this pending forward was finished already")
+    dev, P, H, W, flags = pf.dev, pf.P, pf.H, pf.W, pf.flags
+    L = _native.lib()
+    with torch.cuda.device(dev):
+        s = _stream(dev)
+        if s != pf.stream:
+            raise RuntimeError("rasterize_gaussians_finish must run on the stream rasterize_gaussians_begin ran on")
+        ticket, pf.ticket = pf.ticket, None  # (spent by the native call whatever it returns)
+        counts = (ctypes.c_int64 * 2)()
+        _native.check("gsr_preprocess_end", L.gsr_preprocess_end(s, P, W, H, pf.geom.data_ptr(), ticket, counts))
+        R, G = int(counts[0]), int(counts[1])
+        _, bbytes, ibytes = _native.scratch_sizes(P, R, W, H, G)
+        binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
+        img = torch.empty(ibytes, dtype=torch.uint8, device=dev)
+        out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+        out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        _native.check("gsr_bin", L.gsr_bin(s, P, R, G, W, H, pf.geom.data_ptr(), _ptr(binning), img.data_ptr()))
+        _native.check("gsr_blend_forward", L.gsr_blend_forward(
+            s, P, R, W, H, pf.background.data_ptr(), pf.geom.data_ptr(), _ptr(binning), img.data_ptr(),
+            out_color.data_ptr(), out_depth.data_ptr(), flags))
+        if pf.debug:
+            torch.cuda.synchronize(dev)
+    pf.keep = None
+    return R, out_color, out_depth, pf.radii, pf.geom, binning, img
 
 
 def rasterize_gaussians_aux(background, colors, num_rendered, geomBuffer, binningBuffer, imgBuffer, image_height,

@@ -51,6 +51,9 @@ import threading as _threading
 
 #: GSR_VIEW_PIPELINE=0: multiview_batch_step renders its views one after the other on the launch stream (default: two streams)
 _VIEW_PIPELINE = _os.environ.get("GSR_VIEW_PIPELINE", "1") != "0"
+#: GSR_VIEW_AHEAD: how many views' forwards the pipelined batch finishes ahead of the backward it issues (0 or 1; one stream
+#: per view in flight)
+_VIEW_AHEAD = max(0, min(2, int(_os.environ.get("GSR_VIEW_AHEAD", "0"))))
 
 #: The helper streams of this module, ONE set per device and process, shared by every GradBucket: torch's caching allocator
 #: keeps a block pool per stream, so streams created per bucket stranded the cached blocks of every bucket that was dropped
@@ -231,6 +234,31 @@ def _view_forward(settings, means3D, opacities, shs, scales, rotations):
     R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
         rs.bg, m3, absent, op, sc, rot, rs.scale_modifier, absent, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
         rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, flags=flags)
+    return color, radii, depth, (flags, R, geom, binning, img, m3, sh, sc, rot, absent)
+
+
+def _view_forward_begin(settings, means3D, opacities, shs, scales, rotations):
+    """`_view_forward` in two halves (the pipelined view batch): K1 of the view is enqueued on the current stream and the call
+    returns without waiting for its counts (_C.rasterize_gaussians_begin).  The L1 route has no such split: it is deferred to
+    `_view_forward_finish` as a whole."""
+    if _VIEW_AUTOGRAD or settings.debug or means3D.size(0) == 0:
+        return ("whole", settings, means3D, opacities, shs, scales, rotations)
+    rs = settings
+    flags = _options.current_flags()
+    m3, sh, op, sc, rot = (t.detach() for t in (means3D, shs, opacities, scales, rotations))
+    absent = m3.new_empty(0)
+    pending = _C.rasterize_gaussians_begin(
+        rs.bg, m3, absent, op, sc, rot, rs.scale_modifier, absent, rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+        rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, flags=flags)
+    return ("split", pending, (flags, m3, sh, sc, rot, absent))
+
+
+def _view_forward_finish(begun):
+    """-> what `_view_forward` returns, on the stream `_view_forward_begin` ran on."""
+    if begun[0] == "whole":
+        return _view_forward(*begun[1:])
+    _, pending, (flags, m3, sh, sc, rot, absent) = begun
+    R, color, depth, radii, geom, binning, img = _C.rasterize_gaussians_finish(pending)
     return color, radii, depth, (flags, R, geom, binning, img, m3, sh, sc, rot, absent)
 
 
@@ -608,6 +636,9 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
         side = bucket._side_stream = _device_stream(dev, "side")
         ready = torch.cuda.Event()
         ready.record(main)
+        free = state.pop("bucket_free", None)
+        if free is not None:  # (pipelined batch) K8+K9 is the first kernel of this view that writes the bucket: only now
+            main.wait_event(free)  # must the previous view's message be packed -- this view's K7 ran underneath that
         with torch.cuda.stream(side):
             side.wait_event(ready)
             touched.record_stream(side)  # (allocated under the view's stream by the backward, read here)
@@ -631,13 +662,13 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
     tight, counts, colors, depths = [], [], [], []
     radii_max = None
     bucket.on_blend_done = after_blend
-    # Two-stream VIEW PIPELINING (speculative form, several views on this rank): view v + 1's forward -- K1, the depth sort,
-    # the binning: one bandwidth kernel and a chain of small latency-bound ones -- is enqueued on the other stream right
-    # after view v's backward, whose K7 is bound by VALU issue, so the two overlap; the host blocks in the forward's one
-    # readback meanwhile.  The backward of view v + 1 waits (on the GPU) until view v's message has been packed: the bucket
-    # is the one buffer all backwards write.  Results do not depend on the schedule.  Measured on one MI355X
-    # (tools/pipeline_probe.py, profiles/r04_c_pipelining.md): 0.61 -> 0.52 ms per view with the blend kernels at 2 waves
-    # per SIMD, 1.13 -> 0.96 ms on deep tiles.  GSR_VIEW_PIPELINE=0 turns it off.
+    # Two-stream VIEW PIPELINING (speculative form, several views on this rank): the views alternate between two streams, so
+    # that view v + 1's forward -- K1, the depth sort, the binning: bandwidth and latency-bound kernels -- runs underneath view
+    # v's backward, whose K7 is bound by VALU issue.  The forward is issued in two halves (_view_forward_begin / _finish): the
+    # launch thread never waits for a view's counts.  The backward of view v + 1 waits (on the GPU) until view v's message has
+    # been packed: the bucket is the one buffer all backwards write.  Results do not depend on the schedule.  Measured on one
+    # MI355X: profiles/r04_c_pipelining.md (0.61 -> 0.52 ms per view), profiles/r06_i_view_pipelining.md (the split forward).
+    # GSR_VIEW_PIPELINE=0 turns it off.
     pipeline = speculate and on_gpu and k_local > 1 and _VIEW_PIPELINE
     # ... and the library, not its caller, says so to the rasterizer: the renders of a pipelined batch carry
     # GSR_FLAG_SHARED_SIMDS (2 persistent blend waves per SIMD; until round 4 bench.py set GSR_BLEND_WAVES_PER_SIMD=2 for the
@@ -647,29 +678,61 @@ def _batch_step(settings_list, params, dL_dcolor_list, bucket, group, marks, spe
         if pipeline:
             with shared:
                 main = torch.cuda.current_stream(dev)
-                S = bucket._view_streams = (_device_stream(dev, "view0"), _device_stream(dev, "view1"))
+                # `ahead` forwards are FINISHED (binning, K6) before the backward in front of them is issued, one more is
+                # begun (K1): with ahead = 1 view v's K7 runs over view v + 1's binning and K6 and view v + 2's K1, and view
+                # v + 1's K7 can follow it at once.  One stream per view in flight.
+                ahead = _VIEW_AHEAD
+                ns = 2 + ahead
+                S = bucket._view_streams = tuple(_device_stream(dev, f"view{i}") for i in range(ns))
                 for st_ in S:
                     st_.wait_stream(main)
                 args = (params["xyz"], params["opacity"], params["features"], params["scaling"], params["rotation"])
-                with torch.cuda.stream(S[0]):
-                    fstate = _view_forward(settings_list[0], *args)
+                begun, fstates = {}, {}
+
+                def begin(v):
+                    with torch.cuda.stream(S[v % ns]):
+                        begun[v] = _view_forward_begin(settings_list[v], *args)
+
+                def finish(v):
+                    with torch.cuda.stream(S[v % ns]):
+                        fstates[v] = _view_forward_finish(begun.pop(v))
+
+                # the launch thread never waits for a view's counts: a view's K1 is enqueued at least one backward before its
+                # binning (include/gsr.h gsr_preprocess_begin / _end; until round 6 the thread spent a K1 per view spinning
+                # and the batch was bound by the host, not by the GPU: profiles/r06_i_view_pipelining.md)
+                begin(0)
+                for u in range(1, min(ahead + 1, k_local)):
+                    begin(u)
+                for u in range(0, min(ahead, k_local)):
+                    finish(u)
                 packed_prev, all_radii = None, []
                 for v in range(k_local):
-                    with torch.cuda.stream(S[v % 2]):
+                    if v + ahead < k_local:
+                        finish(v + ahead)
+                    if v + ahead + 1 < k_local:
+                        begin(v + ahead + 1)
+                    fstate = fstates.pop(v)
+                    with torch.cuda.stream(S[v % ns]):
+                        # the bucket is free once view v - 1's message holds its rows.  K7 writes the stream's accumulator
+                        # table and its row mask, not the bucket, so the wait sits between K7 and K8+K9 (in after_blend),
+                        # except on the L1 route, whose backward runs on the autograd engine's thread
                         if packed_prev is not None:
-                            S[v % 2].wait_event(packed_prev)  # the bucket is free: view v - 1's message holds its rows
+                            if len(fstate[3]) == 6:
+                                S[v % ns].wait_event(packed_prev)
+                            else:
+                                state["bucket_free"] = packed_prev
                         _view_backward(settings_list[v], fstate, dL_dcolor_list[v], bucket)
+                        if state.pop("bucket_free", None) is not None:
+                            raise RuntimeError("multiview_batch_step: the backward did not announce its blend half "
+                                               "(after_blend_backward); the bucket may have been overwritten too early")
                         colors.append(fstate[0].detach())
                         depths.append(fstate[2].detach())
                         all_radii.append(fstate[1])
                         if state["planned"] is not None:
-                            S[v % 2].wait_event(state["planned"])
+                            S[v % ns].wait_event(state["planned"])
                         _C.view_message_pack(state["plan"], grads5, bucket.rgb, bucket.campos, cap, send[v])
                         packed_prev = torch.cuda.Event()
-                        packed_prev.record(S[v % 2])
-                    if v + 1 < k_local:
-                        with torch.cuda.stream(S[(v + 1) % 2]):
-                            fstate = _view_forward(settings_list[v + 1], *args)  # underneath view v's backward
+                        packed_prev.record(S[v % ns])
                 for st_ in S:
                     main.wait_stream(st_)
                 radii_max = all_radii[0].clone()

@@ -60,7 +60,8 @@ extern "C" {
  * instead of four arrays, and gsr_preprocess_backward* copies dL_dmeans2D / dL_dopacity (/ dL_dcolors) out of it: the
  * signatures of gsr_backward, gsr_blend_backward, gsr_preprocess_backward{,_rgb,_rows}, gsr_view_message_plan_blend and
  * gsr_debug_blend_backward_profile changed. */
-#define GSR_ABI_VERSION 5
+/* 6 (round 6): adds gsr_preprocess_begin / gsr_preprocess_end (nothing else changed). */
+#define GSR_ABI_VERSION 6
 /* The blend backward's accumulator table: GSR_ACC_ROW floats (one 64-byte line) per Gaussian, 64-byte aligned.  Columns:
  *   [GSR_ACC_MEAN2D] .x [+1] .y of dL_dmean2D      (backward.cu:545-546)
  *   [GSR_ACC_OPACITY] dL_dopacity                  (backward.cu:554)
@@ -183,6 +184,22 @@ int gsr_preprocess(void* stream, int P, int D, int M, const float* means3D, cons
                    const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
                    int prefiltered, int skip_color, unsigned flags, int32_t* radii, void* geom,
                    int64_t counts_host[2]);
+
+/* gsr_preprocess in two halves (ABI 6), for a caller that keeps several views in flight: _begin checks the arguments,
+ * enqueues K1 and the depth-sort passes that do not depend on the counts, and returns AT ONCE with a ticket; _end (same
+ * stream, same P / W / H / geom; any host thread) waits for that view's counts exactly as gsr_preprocess does, enqueues the
+ * rest of the depth ordering and fills counts_host.  gsr_preprocess(...) == _begin(...) followed by _end(...): same
+ * kernels, same results.  Between the two calls the launch thread may enqueue other views' work -- a rank that renders a
+ * batch of views issues view v + 1's _begin before view v's backward and never waits for a readback at all
+ * (gaussianeditor_amd/multiview.py; the reference's loop over batch["camera"], threestudio/systems/GassuianEditor.py:
+ * 165-207, blocks in cudaMemcpy once per view).  A ticket is spent by _end whatever _end returns; one that is never
+ * passed to _end leaks one 64-byte pinned slot.  P == 0 is refused (GSR_ERR_BAD_ARGUMENT): nothing to wait for. */
+int gsr_preprocess_begin(void* stream, int P, int D, int M, const float* means3D, const float* scales,
+                         float scale_modifier, const float* rotations, const float* opacities, const float* shs,
+                         const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                         const float* projmatrix, const float* campos, int W, int H, float tan_fovx, float tan_fovy,
+                         int prefiltered, int skip_color, unsigned flags, int32_t* radii, void* geom, void** ticket);
+int gsr_preprocess_end(void* stream, int P, int W, int H, void* geom, void* ticket, int64_t counts_host[2]);
 
 /* Are n <= 8 pairs of device arrays identical bit for bit?  a[i] / b[i]: device pointers (4-byte aligned; a pair with
  * a[i] == b[i] or bytes[i] == 0 is equal without being read), bytes[i]: their size, a multiple of 4.  One compare launch

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_typed():
     # the Python binding types every declared symbol, and nothing that is not declared
     assert sorted(_native.SIGNATURES) == syms
     L = _native.lib()
-    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 5
+    assert L.gsr_abi_version() == _native.GSR_ABI_VERSION == 6
     # ... and the library exports NOTHING else: no C++ internals, kernel handles or toolchain objects (-fvisibility=hidden
     # + csrc/gsr.map).  Read from the dynamic symbol table with nm.
     import shutil
@@ -81,6 +81,15 @@ def test_argument_validation_needs_no_gpu():
                             0, 0, 0, None, None, r) == 0 and r[0] == 0 and r[1] == 0
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
                             0, 0, 0, None, None, r) == -1
+    # the split form: no ticket pointer, an empty scene, missing arrays; _end without a ticket
+    tk = ctypes.c_void_p()
+    assert L.gsr_preprocess_begin(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0,
+                                  1.0, 0, 0, 0, None, None, None) == -1
+    assert L.gsr_preprocess_begin(None, 0, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0,
+                                  1.0, 0, 0, 0, None, None, ctypes.byref(tk)) == -1
+    assert L.gsr_preprocess_begin(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0,
+                                  1.0, 0, 0, 0, None, None, ctypes.byref(tk)) == -1 and not tk.value
+    assert L.gsr_preprocess_end(None, 10, 64, 64, ctypes.c_void_p(256), None, r) == -1
     assert L.gsr_preprocess(None, 10, 3, 16, None, None, 1.0, None, None, None, None, None, None, None, None, 64, 64, 1.0, 1.0,
                             0, 0, 0, None, None, None) == -1
     assert L.gsr_bin(None, 10, -1, 0, 64, 64, None, None, None) == -1

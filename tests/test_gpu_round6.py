@@ -367,3 +367,72 @@ def test_blend_backward_row_mask_equals_the_nonzero_rows_of_its_table():
     _native.check("k7", L.gsr_blend_backward(sp, P, 0, W, H, p(rs.bg), p(geom), None, p(img), p(G), p(acc), p(touched), 4))
     torch.cuda.synchronize()
     assert not bool(touched[:P].any())
+
+
+def test_forward_in_two_halves_equals_the_whole_forward():
+    """gsr_preprocess_begin / _end (ABI 6; _C.rasterize_gaussians_begin / _finish): the same kernels as gsr_preprocess, so
+    every output is bit-identical to rasterize_gaussians() -- also with two views in flight on one thread, finished in the
+    other order, and with the halves of the views on two streams as the pipelined view batch issues them.  A pending
+    forward is finished once, on the stream it began on."""
+    from gaussianeditor_amd.diff_gaussian_rasterization import _C
+
+    P, W, H = 30000, 320, 200
+    cases = [make_case(P, W, H, seed=5, s0=0.03, view=v, nviews=3) for v in range(3)]
+    sc = cases[0]["sc"]
+    d = lambda t: t.to(DEV).contiguous()  # noqa: E731
+    xyz, op, sh, scl, rot = (d(sc[k]) for k in ("xyz", "opacity", "features", "scaling", "rotation"))
+    absent = xyz.new_empty(0)
+
+    def call(fn, case):
+        rs = settings(case, DEV)
+        return fn(rs.bg, xyz, absent, op, scl, rot, rs.scale_modifier, absent, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                  rs.tanfovy, rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+
+    whole = [call(_C.rasterize_gaussians, c) for c in cases]
+
+    def same(got, want):
+        assert got[0] == want[0] > 0  # num_rendered
+        for a, b in zip(got[1:4], want[1:4]):  # color, depth, radii
+            assert torch.equal(a, b)
+
+    # two in flight on the current stream, finished in the other order
+    pa, pb = call(_C.rasterize_gaussians_begin, cases[0]), call(_C.rasterize_gaussians_begin, cases[1])
+    fb, fa = _C.rasterize_gaussians_finish(pb), _C.rasterize_gaussians_finish(pa)
+    same(fa, whole[0])
+    same(fb, whole[1])
+    with pytest.raises(RuntimeError, match="finished already"):
+        _C.rasterize_gaussians_finish(pa)
+    # the state a split forward leaves serves the backward like the whole forward's
+    G = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(DEV)
+    rs = settings(cases[0], DEV)
+
+    def backward(f):
+        R, color, depth, radii, geom, binning, img = f
+        return _C.rasterize_gaussians_backward(rs.bg, xyz, radii, absent, scl, rot, rs.scale_modifier, absent, rs.viewmatrix,
+                                               rs.projmatrix, rs.tanfovx, rs.tanfovy, G, sh, rs.sh_degree, rs.campos, geom, R,
+                                               binning, img, False)
+
+    for a, b in zip(backward(fa), backward(whole[0])):
+        if a is not None and a.numel():  # (float atomics: run-to-run rounding only)
+            assert torch.allclose(a, b, rtol=0, atol=2e-5 * float(b.abs().max()) + 1e-30)
+    # two streams, view v + 1 begun before view v is finished (the pipelined batch's order)
+    torch.cuda.synchronize()
+    S = [torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)]
+    with torch.cuda.stream(S[0]):
+        begun = call(_C.rasterize_gaussians_begin, cases[0])
+    got = []
+    for v in range(3):
+        nxt = None
+        if v + 1 < 3:
+            with torch.cuda.stream(S[(v + 1) % 2]):
+                nxt = call(_C.rasterize_gaussians_begin, cases[v + 1])
+        if v == 1:
+            with pytest.raises(RuntimeError, match="must run on the stream"):
+                _C.rasterize_gaussians_finish(begun)  # (the current stream is not the one it began on)
+            assert begun.ticket is not None  # still pending
+        with torch.cuda.stream(S[v % 2]):
+            got.append(_C.rasterize_gaussians_finish(begun))
+        begun = nxt
+    torch.cuda.synchronize()
+    for g, w in zip(got, whole):
+        same(g, w)
