@@ -1185,6 +1185,15 @@ blend_backward_kernel(const BlendArgs a) {
 // mask value(s) to weights[id] and C to cnt[id] (the reference increments cnt inside its
 // channel loop, apply_weights.cu:331-339).
 // ----------------------------------------------------------------------------------
+#ifndef GSR_TRACE_ABLATE
+#define GSR_TRACE_ABLATE 0  // A/B builds, timing only (WRONG results): 1 no atomics, 2 no cross-lane reduction, 3 neither
+#endif
+// The inner loop is K6's (round 6; rounds 1-5 walked one survivor per iteration with a ballot, a branch and a 64-lane reduction
+// per entry: 182 -> 122 us per 512 x 512 view at 10^6 Gaussians, profiles/r06_j_trace_weights.md): survivors are staged in pairs
+// and evaluated two per instruction (packed binary32, same roundings), four per iteration; the serial part -- transmittance,
+// saturation -- runs on selects (Ts = T for a live pixel, -T for one that is done), and what a pixel adds for the four entries
+// (its mask value per channel, and 1 for the count) is summed over the wave four values at a time (wave_sum4_to_rows: 10
+// instructions instead of 4 x 8).
 template <int C, int SPLIT, bool FAST>
 __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, uint32_t quad) {
   PixelWave pw;
@@ -1194,67 +1203,105 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
   const uint2 range = a.ranges[pw.tile];
   if (range.y <= range.x) return;
   const float pfx = (float)pw.px, pfy = (float)pw.py;
+  const f32x2 pfx2 = {pfx, pfx}, pfy2 = {pfy, pfy};
   (void)box;  // (the cull rectangle follows the pixels that are still live, live_pixel_box)
   const size_t pix = (size_t)pw.py * a.W + pw.px, HW = (size_t)a.H * a.W;
   float Cw[C];
 #pragma unroll
   for (int ch = 0; ch < C; ++ch) Cw[ch] = pw.inside ? a.image_weights[(size_t)ch * HW + pix] : 0.f;
-  bool done = !pw.inside;
-  float T = 1.0f;
+  float Ts = pw.inside ? 1.0f : -1.0f;
 
-  __shared__ float4 s0[WAVE], s1[WAVE];
+  // a pair of survivors: {hA0,hA1,nB0,nB1} {hC0,hC1,op0,op1} {x0,x1,y0,y1} (conic pre-scaled: -0.5 A, -B, -0.5 C, exact)
+  __shared__ __align__(16) float spair[WAVE / 2][12];
   __shared__ uint32_t sid[WAVE];
   __shared__ float sacc[C][WAVE];
-  __shared__ int scnt[WAVE];
+  __shared__ float scnt[WAVE];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const bool row_end = (lane & 15) == 15;
   ChunkWalker<true> walk(a, range.x, range.y - range.x);
   for (; walk.valid(); walk.advance()) {
-    const uint64_t live_m = __ballot(!done);
+    const uint64_t live_m = __ballot(Ts > 0.0f);
     if (live_m == 0) break;
     const LiveBox lb = live_pixel_box(live_m, pfx - (float)(lane & 7), pfy - (float)(lane >> 3));
     const bool keep = ((uint32_t)lane < walk.chunk_size()) && can_touch_quad(walk.cur.r0, walk.cur.r1, lb.x0, lb.y0, lb.w, lb.h);
     const uint64_t km = __ballot(keep);
     if (km == 0) continue;
     const uint32_t n = (uint32_t)__popcll(km);
+    const uint32_t n4 = (n + GROUP - 1) & ~(uint32_t)(GROUP - 1);
     __syncthreads();
     if (keep) {
       const uint32_t slot = (uint32_t)__popcll(km & lt_mask);
+      float* q = &spair[slot >> 1][slot & 1u];
+      q[0] = -0.5f * walk.cur.r0.x;
+      q[2] = -walk.cur.r0.y;
+      q[4] = -0.5f * walk.cur.r0.z;
+      q[6] = walk.cur.r0.w;
+      q[8] = walk.cur.r1.x;
+      q[10] = walk.cur.r1.y;
       sid[slot] = walk.cur.id;
-      s0[slot] = make_float4(-0.5f * walk.cur.r0.x, -walk.cur.r0.y, -0.5f * walk.cur.r0.z, walk.cur.r0.w);
-      s1[slot] = walk.cur.r1;
     }
-#pragma unroll
-    for (int ch = 0; ch < C; ++ch) sacc[ch][lane] = 0.f;
-    scnt[lane] = 0;
+    if ((uint32_t)lane >= n && (uint32_t)lane < n4) {
+      // null entries pad the survivors to a multiple of GROUP: opacity 0 => alpha 0 => never a hit
+      float* q = &spair[lane >> 1][lane & 1];
+      q[0] = q[2] = q[4] = q[6] = q[8] = q[10] = 0.f;
+    }
     __syncthreads();
-    for (uint32_t j = 0; j < n; ++j) {
-      if (__all(done)) break;
-      const float4 g = s1[j];
-      const float4 co = s0[j];
-      const float dx = g.x - pfx, dy = g.y - pfy;
-      const float power = blend_power_prescaled(co.x, co.y, co.z, dx, dy);
-      const float alpha = fminf(0.99f, co.w * blend_exp<FAST>(power));
-      bool hit = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-      const float test_T = T * (1.0f - alpha);
-      const bool term = hit && (test_T < 0.0001f);
-      done = done || term;
-      hit = hit && !term;
-      const uint64_t m = __ballot(hit);
-      if (m == 0) continue;
-      if (hit) T = test_T;
-      float v[C];
-#pragma unroll
-      for (int ch = 0; ch < C; ++ch) v[ch] = wave_sum_to_lane63(hit ? Cw[ch] : 0.f);
-      if (lane == 63) {
-#pragma unroll
-        for (int ch = 0; ch < C; ++ch) sacc[ch][j] = v[ch];
-        scnt[j] = (int)__popcll(m) * C;
+    uint32_t flushed = n;  // entries whose totals this chunk wrote (all of them unless every pixel saturated on the way)
+    for (uint32_t j = 0; j < n4; j += GROUP) {
+      if (__all(Ts < 0.0f)) {
+        flushed = j;
+        break;
       }
+      float ae[GROUP], om[GROUP];
+#pragma unroll
+      for (int pp = 0; pp < GROUP / 2; ++pp) {
+        const float* q = &spair[(j >> 1) + pp][0];
+        const float4 q0 = *reinterpret_cast<const float4*>(q), q1 = *reinterpret_cast<const float4*>(q + 4),
+                     q2 = *reinterpret_cast<const float4*>(q + 8);
+        const f32x2 hA = {q0.x, q0.y}, nB = {q0.z, q0.w}, hC = {q1.x, q1.y}, op = {q1.z, q1.w};
+        const f32x2 dx = f32x2{q2.x, q2.y} - pfx2, dy = f32x2{q2.z, q2.w} - pfy2;
+        const f32x2 a_ = (hA * dx) * dx;  // blend_power_prescaled on both entries
+        const f32x2 s_ = __builtin_elementwise_fma(hC * dy, dy, a_);
+        const f32x2 power = __builtin_elementwise_fma(nB * dx, dy, s_);
+        const f32x2 ao = op * blend_exp2<FAST>(power);
+        const float a0 = fminf(0.99f, ao.x), a1 = fminf(0.99f, ao.y);
+        const float g0 = (power.x > 0.0f) ? 0.0f : a0, g1 = (power.y > 0.0f) ? 0.0f : a1;
+        const f32x2 a2 = {(g0 < 1.0f / 255.0f) ? 0.0f : g0, (g1 < 1.0f / 255.0f) ? 0.0f : g1};
+        const f32x2 o2 = f32x2{1.0f, 1.0f} - a2;
+        ae[2 * pp] = a2.x;
+        ae[2 * pp + 1] = a2.y;
+        om[2 * pp] = o2.x;
+        om[2 * pp + 1] = o2.y;
+      }
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) asm volatile("" : "+v"(ae[u]), "+v"(om[u]));
+      // entry skipped for this pixel (power > 0 or alpha < 1/255): alpha := 0, test_T = T exactly, no hit;
+      // T (1 - alpha) < 0.0001: the pixel is done BEFORE this entry counts (apply_weights.cu:318-323), Ts := -T;
+      // pixel done: test_T <= 0, nothing changes.
+      float h[GROUP];
+#pragma unroll
+      for (int u = 0; u < GROUP; ++u) {
+        const float test_T = Ts * om[u];
+        const bool A = !(test_T < 0.0001f);
+        h[u] = (A && ae[u] > 0.0f) ? 1.0f : 0.0f;
+        Ts = A ? test_T : -__builtin_fabsf(Ts);
+      }
+      const uint32_t e = j + ((uint32_t)lane >> 4);  // the entry whose totals end up in this lane's row
+#pragma unroll
+      for (int ch = 0; ch < C; ++ch) {
+        const float z = (GSR_TRACE_ABLATE & 2) ? h[0] * Cw[ch]
+                                                : wave_sum4_to_rows(h[0] > 0.f ? Cw[ch] : 0.f, h[1] > 0.f ? Cw[ch] : 0.f,
+                                                                    h[2] > 0.f ? Cw[ch] : 0.f, h[3] > 0.f ? Cw[ch] : 0.f);
+        if (row_end) sacc[ch][e] = z;
+      }
+      const float zc = (GSR_TRACE_ABLATE & 2) ? h[0] : wave_sum4_to_rows(h[0], h[1], h[2], h[3]);
+      if (row_end) scnt[e] = zc;
     }
     __syncthreads();
-    if ((uint32_t)lane < n) {
-      const int cn = scnt[lane];
-      if (cn != 0) {
+    // (the groups behind a break wrote nothing: their slots hold an earlier chunk's values)
+    if ((uint32_t)lane < min(n, flushed)) {
+      const int cn = (int)scnt[lane] * C;
+      if (cn != 0 && (!(GSR_TRACE_ABLATE & 1) || sacc[0][lane] == 12345.678f)) {
         const size_t id = sid[lane];
 #pragma unroll
         for (int ch = 0; ch < C; ++ch) unsafeAtomicAdd(&a.weights[id * C + ch], sacc[ch][lane]);
@@ -1263,7 +1310,6 @@ __device__ __forceinline__ void trace_item(const BlendArgs& a, uint32_t tile, ui
     }
   }
 }
-
 template <int C, int SPLIT, bool FAST>
 __global__ void __launch_bounds__(WAVE) trace_weights_kernel(const BlendArgs a) {
   run_work_queue<SPLIT>(a, false, [&](uint32_t tile, uint32_t quad, bool) __attribute__((always_inline)) { trace_item<C, SPLIT, FAST>(a, tile, quad); });

@@ -436,3 +436,43 @@ def test_forward_in_two_halves_equals_the_whole_forward():
     torch.cuda.synchronize()
     for g, w in zip(got, whole):
         same(g, w)
+
+
+@pytest.mark.parametrize("C,W,H,s0,opaque", [(1, 250, 131, 0.04, False), (3, 96, 80, 0.3, True), (2, 200, 120, 0.15, True),
+                                             (1, 64, 48, 0.5, True)])
+def test_apply_weights_grouped_loop_edges(oracle, C, W, H, s0, opaque):
+    """K12's inner loop walks four survivors per iteration on selects (round 6).  What the parity cases with 0 / 1 masks do
+    not reach: real-valued mask values (sums within the re-association of the atomics), scenes of large opaque splats in
+    which every pixel of a quadrant saturates in the middle of a chunk (the loop breaks between two groups and flushes only
+    what it wrote), survivor counts that are no multiple of four (padding), ragged images, and a NaN in the mask (it reaches
+    exactly the Gaussians blended at that pixel).  `cnt` is an integer: identical to the oracle's."""
+    import numpy as np
+
+    from gaussianeditor_amd.diff_gaussian_rasterization import GaussianRasterizer
+
+    P = 4000
+    case = make_case(P, W, H, seed=21, s0=s0)
+    sc, cam = case["sc"], case["cam"]
+    if opaque:
+        sc["opacity"] = torch.full_like(sc["opacity"], 0.99)
+    gen = torch.Generator().manual_seed(5)
+    mask = torch.rand(C, H, W, generator=gen)
+    mask[0, H // 2, W // 3] = float("nan")
+    w_ref = np.zeros((P, C), np.float32)
+    c_ref = np.zeros((P,), np.int32)
+    oracle.apply_weights(sc["xyz"], sc["scaling"], sc["rotation"], sc["opacity"], None, cam.world_view_transform,
+                         cam.full_proj_transform, cam.camera_center, W, H, case["tfx"], case["tfy"], mask, w_ref, c_ref)
+    w = torch.zeros((P, C), device=DEV)
+    cnt = torch.zeros((P, 1), dtype=torch.int32, device=DEV)
+    GaussianRasterizer(settings(case, DEV, D=0)).apply_weights(sc["xyz"].to(DEV), None, sc["opacity"].to(DEV), None, w,
+                                                             sc["scaling"].to(DEV), sc["rotation"].to(DEV), None, cnt,
+                                                             mask.to(DEV))
+    torch.cuda.synchronize()
+    got_w, got_c = w.cpu().numpy(), cnt.cpu().numpy().reshape(-1)
+    assert c_ref.sum() > 0 and np.array_equal(got_c, c_ref)
+    assert np.array_equal(np.isnan(got_w), np.isnan(w_ref)) and np.isnan(w_ref).any() and not np.isnan(w_ref).all()
+    ok = ~np.isnan(w_ref)
+    # (sums of up to ~10^3 real values per Gaussian, added sequentially by the oracle and as trees + atomics here)
+    assert np.abs(got_w[ok] - w_ref[ok]).max() <= 2e-5 * max(1.0, float(np.abs(w_ref[ok]).max()))
+    if opaque:  # the scene does what it is here for: most Gaussians in the frustum are hidden behind saturated pixels
+        assert (c_ref > 0).sum() < 0.5 * P
