@@ -323,10 +323,8 @@ def test_edge_geometries(oracle, P, W, H, s0, scale_xyz):
         assert rel_err(v, g[k].reshape(v.shape)) <= 1e-5, k
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_configuration_sweep(oracle, seed):
-    """Seeded random shapes: odd image sizes down to one pixel, any SH degree, P from 1 to a few thousand, random
-    splat size / scene scale / scale_modifier / view.  Forward stage by stage and all six gradients against the oracle."""
+def sweep_case(seed):
+    """The sweep's configuration for `seed` -> (case, scale_modifier, SH degree); also used by tools/fuzz_parity.py."""
     rng = np.random.default_rng(1000 + seed)
     P = int([1, 2, 63, 65, 255, 256][seed] if seed < 6 else rng.integers(300, 6000))
     W = int(rng.choice([1, 2, 15, 17, 31]) if seed % 3 == 0 else rng.integers(1, 400))
@@ -335,6 +333,15 @@ def test_random_configuration_sweep(oracle, seed):
     case = make_case(P, W, H, seed=100 + seed, s0=float(rng.choice([0.01, 0.05, 0.3])), view=int(rng.integers(0, 4)),
                      sh_degree=D, scale_xyz=float(rng.choice([0.2, 1.0, 2.5])))
     sm = float(rng.choice([0.5, 1.0, 1.7]))
+    return case, sm, D
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_configuration_sweep(oracle, seed):
+    """Seeded random shapes: odd image sizes down to one pixel, any SH degree, P from 1 to a few thousand, random
+    splat size / scene scale / scale_modifier / view.  Forward stage by stage and all six gradients against the oracle."""
+    case, sm, D = sweep_case(seed)
+    P, W, H = case["sc"]["xyz"].shape[0], case["W"], case["H"]
     f, _ = _compare_forward(oracle, case, scale_modifier=sm)
     G = seed_gradient(H, W, seed) * (H * W)
     g = oracle_backward(oracle, case, f, G, scale_modifier=sm)
