@@ -458,15 +458,15 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       const uint64_t live_m = __ballot(!done);
       if (live_m == 0) break;
       if (ckpt && walk.chunk == ck_next) {  // (uniform; never for walks shorter than the stride)
-        if (ck_k < (uint32_t)CK_MAX) {
+        if (ck_k < (uint32_t)a.ck_slots) {
           // slot k: T in front of position k * stride, and the colour of segment k - 1.  Written by every pixel of the
           // quadrant (a saturated one writes zeros: the backward never reads them, but it may read the slots of a pixel that
           // is live and simply found nothing to blend)
-          if (pw.inside) a.ck_pool[((size_t)ck_base * CK_MAX + ck_k) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
+          if (pw.inside) a.ck_pool[((size_t)ck_base * (uint32_t)a.ck_slots + ck_k) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
           S01 = f32x2{0.f, 0.f};
           S2 = 0.f;
           // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
-          if (lane == 0) atomicAdd(&a.ck_work[(size_t)tile * CK_MAX + ck_k], evaluated);
+          if (lane == 0) atomicAdd(&a.ck_work[(size_t)tile * (uint32_t)a.ck_slots + ck_k], evaluated);
         }
         ck_next += (uint32_t)a.ck_chunks;
         ck_k++;
@@ -642,11 +642,11 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   if (ckpt) {
     // ... for the whole tile, and -- for the pixels some checkpoint was written for -- the colour of the segment the walk
     // ended in, as if its closing checkpoint had been reached: slot ck_k, or slot 0 once the tile's slots are used up (that
-    // "segment" then reaches to the end of the list).  With it the colour of segment k is ALWAYS in slot k + 1 (k + 1 < CK_MAX)
-    // or in slot 0 (k = CK_MAX - 1), whether the wave went on beyond it or not.
+    // "segment" then reaches to the end of the list).  With it the colour of segment k is ALWAYS in slot k + 1 (k + 1 < ck_slots)
+    // or in slot 0 (k = ck_slots - 1), whether the wave went on beyond it or not.
     if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
     if (ck_k > 1u && pw.inside)
-      a.ck_pool[((size_t)ck_base * CK_MAX + (ck_k < (uint32_t)CK_MAX ? ck_k : 0u)) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
+      a.ck_pool[((size_t)ck_base * (uint32_t)a.ck_slots + (ck_k < (uint32_t)a.ck_slots ? ck_k : 0u)) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
   }
   // the backward's work estimate and walk depth for the quadrant.  One item per quadrant: plain stores; the sub-items of a
   // cut quadrant report the largest of their values (they walk the same list).
@@ -741,11 +741,14 @@ constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile 
 constexpr int ACC_LDS_ROW = 9;  // floats per chunk slot of the backward's LDS accumulators: the nine raw moments
 constexpr uint32_t BWD_ITEM_HALF = 0x80000000u;   // item code: the workgroup handles one half of the tile ...
 constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead of {0,1}
-// ... or (round 4) ONE LIST SEGMENT of a deep tile: positions [seg * stride, (seg + 1) * stride) of its list, the last
-// segment up to the tile's deepest contributor.  The pixels that still contribute behind the segment start from the
-// forward's checkpoint in front of its upper end instead of from their final state (backward_tile).
+// ... or (round 4) A RUN OF LIST SEGMENTS of a deep tile: the checkpoint strides lo .. hi of its list, i.e. positions
+// [lo * stride, (hi + 1) * stride), a run that ends with the tile's last stride up to the tile's deepest contributor.  The
+// pixels that still contribute behind the run start from the forward's checkpoint in front of its upper end instead of from
+// their final state (backward_tile).  The work list makes one item per stride (lo == hi): runs of several strides, merged
+// to about equal measured work, were measured in round 6 and bought nothing (profiles/r06_m_fine_checkpoints.md).
 constexpr uint32_t BWD_ITEM_SEG = 0x10000000u;
-constexpr int BWD_SEG_SHIFT = 20, BWD_NSEG_SHIFT = 24;  // 4 bits each: segment index, number of segments - 1
+constexpr int BWD_SEG_SHIFT = 20, BWD_NSEG_SHIFT = 24;  // 4 bits each: first stride of the run, last stride of the run
+static_assert(CK_MAX <= 16, "a stride index must fit the item code's 4 bits");
 constexpr uint32_t BWD_ITEM_TILE = 0x000fffffu;   // (images of up to 2^20 tiles: GSR_MAX_TILES, checked by gsr_blend_backward)
 static_assert(BWD_ITEM_TILE + 1u == (uint32_t)GSR_MAX_TILES, "include/gsr.h states the backward's tile limit");
 
@@ -772,14 +775,16 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
   const bool half_item = (tile & BWD_ITEM_HALF) != 0u;
   const uint32_t part = (tile & BWD_ITEM_PART) ? 1u : 0u;
   const bool seg_item = SEG && (tile & BWD_ITEM_SEG) != 0u;  // (SEG: a template switch -- the work list of a view without checkpoints holds no such item)
-  const uint32_t seg = (tile >> BWD_SEG_SHIFT) & 15u, nseg_m1 = (tile >> BWD_NSEG_SHIFT) & 15u;
+  const uint32_t seg_first = (tile >> BWD_SEG_SHIFT) & 15u, seg = (tile >> BWD_NSEG_SHIFT) & 15u;  // the run's first / last stride
   tile &= BWD_ITEM_TILE;
   const uint32_t list_base = item.y, tile_max = item.z;
   if (tile_max == 0) return 0u;  // (uniform: nothing of the item's pixels ever contributed)
-  // the list positions this item walks: all of [0, tile_max), or one segment of them
+  // the list positions this item walks: all of [0, tile_max), or a run of strides of them (the stride of the last slot
+  // reaches to the end of the list, and so does whatever stride holds the tile's deepest contributor)
   const uint32_t stride = (uint32_t)a.ck_chunks * WAVE;
-  const uint32_t seg_lo = seg_item ? seg * stride : 0u;
-  const uint32_t seg_hi = (seg_item && seg != nseg_m1) ? min(tile_max, (seg + 1u) * stride) : tile_max;
+  const uint32_t seg_lo = seg_item ? seg_first * stride : 0u;
+  const uint32_t nslots = (uint32_t)a.ck_slots;  // slots in use per tile (<= CK_MAX), the stride of the pool and of ck_work
+  const uint32_t seg_hi = (seg_item && seg != nslots - 1u) ? min(tile_max, (seg + 1u) * stride) : tile_max;
   if (seg_lo >= seg_hi) return 0u;  // (uniform)
   PixelWave pw;
   const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
@@ -818,17 +823,29 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
     // zero: slot k + 1 holds segment k's, slot 0 that of segment CK_MAX - 1 and everything after it), smallest first -- as
     // C_final - C(seg_hi) it was a difference of two numbers near 1 divided by a small transmittance.
     const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
-    const size_t slot0 = (size_t)a.ck_table[tile] * CK_MAX;  // (slot k >= 1: T in front of position k * stride + segment k - 1's colour)
-    const uint32_t m = min((last_contributor - 1u) / stride, (uint32_t)CK_MAX - 1u);  // the segment of the pixel's last contributor
+    const size_t slot0 = (size_t)a.ck_table[tile] * nslots;  // (slot k >= 1: T in front of position k * stride + segment k - 1's colour)
+    const uint32_t m = min((last_contributor - 1u) / stride, nslots - 1u);  // the segment of the pixel's last contributor
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-    for (uint32_t k = (uint32_t)CK_MAX - 1u; k > seg; --k) {  // (wave-uniform bounds; a lane takes part from its own m down)
-      if (k <= m) {
-        const float4 sk = a.ck_pool[(slot0 + (k + 1u < (uint32_t)CK_MAX ? k + 1u : 0u)) * (TILE * TILE) + pidx];
+    // (wave-uniform bounds; a lane takes part from its own m down.  The two slot counts the library itself chooses get a
+    //  loop with a constant upper end -- unrolled, as when CK_MAX was the only count: with both ends variable every
+    //  iteration waits for its own load, 3-4 % of the whole kernel on the deep-tile views)
+    auto add_slot = [&](uint32_t k, uint32_t top) __attribute__((always_inline)) {
+      if (k > seg && k <= m) {
+        const float4 sk = a.ck_pool[(slot0 + (k + 1u < top ? k + 1u : 0u)) * (TILE * TILE) + pidx];
         b0 += sk.y;
         b1 += sk.z;
         b2 += sk.w;
       }
-    }
+    };
+    auto sum_behind = [&](auto slots_c) __attribute__((always_inline)) {
+      constexpr uint32_t S = decltype(slots_c)::value;
+#pragma unroll
+      for (uint32_t i = 1u; i < S; ++i) add_slot(S - i, S);  // k = S - 1 down to 1
+    };
+    if (nslots == (uint32_t)CK_MAX / 2u) sum_behind(std::integral_constant<uint32_t, (uint32_t)CK_MAX / 2u>{});
+    else if (nslots == (uint32_t)CK_MAX) sum_behind(std::integral_constant<uint32_t, (uint32_t)CK_MAX>{});
+    else
+      for (uint32_t k = nslots - 1u; k > seg; --k) add_slot(k, nslots);  // (GSR_CK_SLOTS: any other count)
     T = a.ck_pool[(slot0 + seg + 1u) * (TILE * TILE) + pidx].x;
     B_acc = (b0 * dpx[0] + b1 * dpx[1] + b2 * dpx[2]) / T;
   }
@@ -1341,7 +1358,8 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
                                                                 const ClearArgs clear, const uint32_t* __restrict__ tile_maxc,
                                                                 const uint32_t* __restrict__ ck_table,
                                                                 const uint32_t* __restrict__ ck_work, uint32_t stride,
-                                                                int seg_share) {  // seg_share: 0, or the threshold in 1/8 of a fair share
+                                                                uint32_t slots,   // checkpoint slots in use per tile (<= CK_MAX)
+                                                                int seg_share) {  // 0, or the threshold in 1/8 of a fair share
   if (blockIdx.x != 0) {
     const long long nb = (long long)gridDim.x - 1, b = (long long)blockIdx.x - 1;
 #pragma unroll
@@ -1372,11 +1390,24 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
   // (BWD_SUB counters per bucket, chosen by the lane: see tile_worklist_kernel in gsr_binning.hip)
   constexpr int BWD_SUB = 16, NCNT = (BWD_BUCKETS + 1) * BWD_SUB;
+  constexpr int CK_TILES_MAX = 2048;  // (== ck_tiles(T) at most: the ranks of Image::ck_table)
+  static_assert(BWD_BUCKETS <= 256, "a segment item's bucket is cached in one byte");
   __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];
-  __shared__ uint32_t s_threshold, s_seg_threshold;
+  __shared__ uint32_t s_threshold, s_seg_threshold, s_ncand;
+  // List segments (SEG): what the three passes below need of a cut tile, by the tile's checkpoint rank -- filled ONCE
+  // (round 6; rounds 4-5 re-read the tile's row of ck_work in every pass, one dependent round trip per tile and pass in a
+  // kernel that is ONE block between two blend kernels: 21 us where the kernel without segments takes 9).
+  constexpr uint32_t SEG_CUT = 0x80000000u;
+  __shared__ uint32_t s_tile[SEG ? CK_TILES_MAX : 1];         // tile | strides << 20 | SEG_CUT; 0 = the rank's tile is no candidate
+  __shared__ uint16_t s_queue[SEG ? CK_TILES_MAX : 1];        // ranks of the candidates
+  __shared__ uint8_t s_bucket[SEG ? CK_TILES_MAX : 1][CK_MAX];  // bucket of every stride's item
   const uint32_t sub = threadIdx.x & (BWD_SUB - 1);
   for (int i = threadIdx.x; i < NCNT; i += 1024) cnt[i] = 0;
+  if (SEG) {
+    for (int i = threadIdx.x; i < CK_TILES_MAX; i += 1024) s_tile[i] = 0u;
+    if (threadIdx.x == 0) s_ncand = 0u;
+  }
   // The kernel is one block between the forward and the backward blend, i.e. a chain of dependent round trips: the
   // forward's counts are fetched ONCE (all loads of a thread in flight together; images of up to 1024 * EST_REG tiles keep
   // them in registers, larger ones re-read) and the counters are scanned by one block scan.
@@ -1384,18 +1415,20 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   const bool in_regs = T <= 1024 * EST_REG;
   uint4 er[EST_REG];
   uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
-  const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && stride != 0u && seg_share > 0;
+  uint32_t rank[EST_REG];  // the tile's checkpoint rank (CK_NONE: it owns no slots)
+  const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && ck_work != nullptr && stride != 0u && slots >= 2u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
     const int t = (int)threadIdx.x + 1024 * j;
     er[j] = (in_regs && T > 0) ? reinterpret_cast<const uint4*>(est)[t < T ? t : T - 1] : make_uint4(0u, 0u, 0u, 0u);
     deep[j] = (in_regs && segments && T > 0) ? tile_maxc[t < T ? t : T - 1] : 0u;
+    rank[j] = (in_regs && segments && T > 0) ? ck_table[t < T ? t : T - 1] : CK_NONE;
     if (t >= T) {
       er[j] = make_uint4(0u, 0u, 0u, 0u);
       deep[j] = 0u;
+      rank[j] = CK_NONE;
     }
   }
-  auto est_of = [&](int t, int j) -> uint4 { return in_regs ? er[j] : reinterpret_cast<const uint4*>(est)[t]; };
   // total work -> the weight above which a tile is cut
   uint32_t mine = 0;
   if (in_regs) {
@@ -1415,57 +1448,77 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
   __syncthreads();
   const uint32_t threshold = s_threshold, seg_threshold = s_seg_threshold;
-  // List segments: a tile the backward walks deeper than one checkpoint stride AND whose work is a sizeable share of a
-  // workgroup's becomes one item per stride, provided it owns checkpoint slots (the forward then left the state every
-  // segment starts from); they run in different workgroups at the same time.  -> number of segments (1 = not cut).
-  auto segments_of = [&](int t, uint32_t w, uint32_t dp) -> uint32_t {
-    if (w < seg_threshold || dp <= stride || ck_table[t] == CK_NONE) return 1u;
-    const uint32_t ns = min((dp + stride - 1u) / stride, (uint32_t)CK_MAX);
-    const uint32_t* wrow = ck_work + (size_t)t * CK_MAX;
-    uint32_t prev = 0u, largest = 0u;
-    for (uint32_t k = 1; k < ns; ++k) {
-      const uint32_t at = min(wrow[k], w);
-      largest = max(largest, at > prev ? at - prev : 0u);
-      prev = at;
-    }
-    largest = max(largest, w - prev);
-    // (a cut only pays if it really divides the work: a tile whose front segment holds nearly all of it stays whole)
-    return (uint64_t)largest * 5u <= (uint64_t)w * 4u ? ns : 1u;
-  };
-  uint32_t nseg[EST_REG];
-#pragma unroll
-  for (int j = 0; j < EST_REG; ++j)
-    nseg[j] = (in_regs && segments) ? segments_of((int)threadIdx.x + 1024 * j, er[j].x + er[j].y + er[j].z + er[j].w, deep[j]) : 1u;
   auto bucket_of = [](uint32_t w) -> uint32_t {
     if (w == 0) return BWD_BUCKETS;  // nothing to do: after the end of the list
     return (uint32_t)(BWD_BUCKETS - 1) - min((w - 1u) / 16u, (uint32_t)(BWD_BUCKETS - 1));
   };
+  // every tile of this thread with what the passes need of it: fn(tile, its four counts, its checkpoint rank, its depth)
   auto for_each_tile = [&](auto&& fn) {
     if (in_regs) {
 #pragma unroll
       for (int j = 0; j < EST_REG; ++j) {
         const int t = (int)threadIdx.x + 1024 * j;
-        if (t < T) fn(t, er[j], nseg[j]);
+        if (t < T) fn(t, er[j], rank[j], deep[j]);
       }
     } else {
-      for (int t = threadIdx.x; t < T; t += 1024) {
-        const uint4 e = reinterpret_cast<const uint4*>(est)[t];
-        fn(t, e, segments ? segments_of(t, e.x + e.y + e.z + e.w, tile_maxc[t]) : 1u);
-      }
+      for (int t = threadIdx.x; t < T; t += 1024)
+        fn(t, reinterpret_cast<const uint4*>(est)[t], segments ? ck_table[t] : CK_NONE, segments ? tile_maxc[t] : 0u);
     }
   };
-  (void)est_of;
-  // work of segment j of a cut tile: what the forward evaluated between checkpoints j and j + 1 (the front segment holds
-  // most of it: the deep positions of a list are walked for a few stragglers)
-  auto seg_work = [&](int t, uint32_t w, uint32_t ns, uint32_t j) -> uint32_t {
-    const uint32_t* row = ck_work + (size_t)t * CK_MAX;
-    const uint32_t lo = j == 0u ? 0u : min(row[j], w), hi = j + 1u == ns ? w : min(row[j + 1u], w);
-    return max(hi > lo ? hi - lo : 0u, 1u);
+  if (segments) {
+    // List segments: a tile the backward walks deeper than one checkpoint stride AND whose work is a sizeable share of a
+    // workgroup's becomes one item per stride, provided it owns checkpoint slots (the forward then left the state every
+    // segment starts from); the items run in different workgroups at the same time.  (a) the candidates are queued; (b) ONE
+    // thread per candidate fetches the tile's counts and its whole row of ck_work at once -- entry k: what the forward had
+    // evaluated in the tile when it reached checkpoint k, so stride j holds entries k = j .. j + 1 of it: the front strides
+    // hold most of the work, the deep positions of a list are walked for a few stragglers -- and decides: a cut only pays
+    // if it really divides the work (a tile whose largest stride holds more than 4/5 of it stays whole).
+    for_each_tile([&](int t, const uint4 e, uint32_t rk, uint32_t dp) {
+      const uint32_t w = e.x + e.y + e.z + e.w;
+      if (rk == CK_NONE || rk >= (uint32_t)CK_TILES_MAX || w < seg_threshold || dp <= stride) return;
+      const uint32_t ns = min((dp + stride - 1u) / stride, slots);
+      s_tile[rk] = (uint32_t)t | (ns << 20);
+      s_queue[atomicAdd(&s_ncand, 1u)] = (uint16_t)rk;
+    });
+    __syncthreads();
+    const uint32_t ncand = s_ncand;
+    for (uint32_t c = threadIdx.x; c < ncand; c += 1024) {
+      const uint32_t rk = s_queue[c], tt = s_tile[rk];
+      const uint32_t t = tt & BWD_ITEM_TILE, ns = (tt >> 20) & 31u;
+      const uint4 e = reinterpret_cast<const uint4*>(est)[t];
+      const uint32_t* row = ck_work + (size_t)t * slots;
+      uint32_t at[CK_MAX + 1];  // at[j]: entries evaluated in front of stride j (at[0] = 0, at[j >= ns] = the tile's total)
+#pragma unroll
+      for (uint32_t j = 1; j < (uint32_t)CK_MAX; ++j) at[j] = row[min(j, slots - 1u)];  // (unconditional: all in flight)
+      const uint32_t w = e.x + e.y + e.z + e.w;
+      at[0] = 0u;
+      at[CK_MAX] = w;
+#pragma unroll
+      for (uint32_t j = 1; j < (uint32_t)CK_MAX; ++j) at[j] = j < ns ? min(at[j], w) : w;
+      uint32_t largest = 0u;
+#pragma unroll
+      for (uint32_t j = 0; j < (uint32_t)CK_MAX; ++j) {
+        const uint32_t sw = max(at[j + 1] > at[j] ? at[j + 1] - at[j] : 0u, 1u);
+        if (j < ns) {
+          largest = max(largest, sw);
+          s_bucket[rk][j] = (uint8_t)bucket_of(sw);
+        }
+      }
+      if (ns > 1u && (uint64_t)largest * 5u <= (uint64_t)w * 4u) s_tile[rk] = tt | SEG_CUT;
+    }
+    __syncthreads();
+  }
+  // strides of a tile that is cut (0: it is not)
+  auto strides_of = [&](uint32_t rk) -> uint32_t {
+    if (!segments || rk == CK_NONE || rk >= (uint32_t)CK_TILES_MAX) return 0u;
+    const uint32_t tt = s_tile[rk];
+    return (tt & SEG_CUT) ? ((tt >> 20) & 31u) : 0u;
   };
-  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+  for_each_tile([&](int t, const uint4 e, uint32_t rk, uint32_t) {
     const uint32_t w = e.x + e.y + e.z + e.w;
-    if (ns > 1u) {
-      for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u);
+    const uint32_t ns = strides_of(rk);
+    if (ns != 0u) {
+      for (uint32_t j = 0; j < ns; ++j) atomicAdd(&cnt[(uint32_t)s_bucket[rk][j] * BWD_SUB + sub], 1u);
     } else if (w >= threshold) {
       atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u);
       atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u);
@@ -1493,12 +1546,13 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     }
   }
   __syncthreads();
-  for_each_tile([&](int t, const uint4 e, uint32_t ns) {
+  for_each_tile([&](int t, const uint4 e, uint32_t rk, uint32_t) {
     const uint32_t w = e.x + e.y + e.z + e.w;
-    if (ns > 1u) {
-      for (uint32_t j = 0; j < ns; ++j)
-        order[atomicAdd(&cnt[bucket_of(seg_work(t, w, ns, j)) * BWD_SUB + sub], 1u)] =
-            (uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | ((ns - 1u) << BWD_NSEG_SHIFT);
+    const uint32_t ns = strides_of(rk);
+    if (ns != 0u) {
+      for (uint32_t j = 0; j < ns; ++j)  // (item code: first and last stride of the run -- here one stride)
+        order[atomicAdd(&cnt[(uint32_t)s_bucket[rk][j] * BWD_SUB + sub], 1u)] =
+            (uint32_t)t | BWD_ITEM_SEG | (j << BWD_SEG_SHIFT) | (j << BWD_NSEG_SHIFT);
     } else if (w >= threshold) {
       order[atomicAdd(&cnt[bucket_of(e.x + e.y) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF;
       order[atomicAdd(&cnt[bucket_of(e.z + e.w) * BWD_SUB + sub], 1u)] = (uint32_t)t | BWD_ITEM_HALF | BWD_ITEM_PART;
@@ -1615,15 +1669,18 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     // GSR_BWD_SEG: tiles above this many eighths of a fair share are cut into list segments where the forward left
     // checkpoints (0: never; tests use 1)
     static const int seg_share = [] { const char* e = getenv("GSR_BWD_SEG"); return e ? atoi(e) : 5; }();
+    // (Merging consecutive strides of a cut tile into items of about equal measured work -- the plan of
+    //  profiles/r06_k -- was built and swept over eleven workloads at 2 .. 12 sixteenths of a fair share per item: equal at
+    //  best, 8-40 % slower where pixels walk deep; removed: profiles/r06_m_fine_checkpoints.md.)
     seg_items = a.ck_table != nullptr && a.ck_chunks > 0 && seg_share > 0 && ablate == 0;
     if (seg_items)
       hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
                          a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)a.tile_maxc,
-                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, seg_share);
+                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, (uint32_t)a.ck_slots, seg_share);
     else
       hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
                          a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0);
   }
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size(true, s, sh) / BWD_WAVES), b(WAVE * BWD_WAVES);

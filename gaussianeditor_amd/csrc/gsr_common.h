@@ -130,17 +130,23 @@ struct Image {
   // k stride) -- contributed, accumulated from zero; slot 0 the colour of segment CK_MAX - 1 and everything behind it.  The
   // CK_TILES(T) tiles with the longest lists own CK_MAX consecutive 4 KB slots each, assigned by tile_worklist_kernel -- no
   // allocation, no atomics in the forward's loop.
-  uint32_t* ck_table;   // (T)  the tile's rank among the checkpointed tiles (its slots: rank * CK_MAX + k), or CK_NONE
-  uint32_t* ck_work;    // (T x CK_MAX) entry k: entries the forward had evaluated in the tile when it reached checkpoint k (summed
+  uint32_t* ck_table;   // (T)  the tile's rank among the checkpointed tiles (its slots: rank * S + k, S = the slots the view uses, <= CK_MAX), or CK_NONE
+  uint32_t* ck_work;    // (T x S, room for S = CK_MAX) entry k: entries the forward had evaluated in the tile when it reached checkpoint k (summed
                         //      over its quadrants): how the tile's backward work splits over its list segments.  Zero per view.
   uint32_t* tile_maxc;  // (T)  largest last-contributor position + 1 over the tile's pixels (what the backward walks).  Zero per view.
-  float4* ck_pool;      // (CK_TILES(T) x CK_MAX x 256)
+  float4* ck_pool;      // (CK_TILES(T) x S x 256, room for S = CK_MAX)
   size_t bytes;
 };
-constexpr int CK_MAX = 8;            // slots per tile: 7 checkpoints + the tail (beyond that depth the last segment is longer)
+// Round 6 (second half): FINE checkpoints, COARSE items.  The stride that suits a view depends on how deep its pixels walk
+// their lists, which only the forward measures (profiles/r06_k_checkpoint_stride.md: 512 x 512 views want 256 positions, 1080p
+// views 384-512, the same image with another scene twice that).  So the forward checkpoints at the fine stride with twice the
+// slots (the same 4 096 positions of reach), and the backward's work list MERGES consecutive strides of a tile into items of
+// about equal measured work (backward_worklist_kernel): the item size follows the view, not a constant.
+constexpr int CK_MAX = 16;           // slots per tile: 15 checkpoints + the tail (beyond that depth the last segment is longer)
 constexpr uint32_t CK_NONE = 0xffffffffu;
-constexpr int CK_CHUNKS_DEFAULT = 8;  // checkpoint stride in 64-entry chunks (512 list positions) where checkpoints are on
-__host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (64 MB of slots at most)
+constexpr int CK_CHUNKS_DEFAULT = 4;  // the FINE checkpoint stride in 64-entry chunks (256 list positions); the coarse one is twice that
+constexpr int CK_FINE_TILES = 1024;   // images of up to this many tiles take the fine stride with all CK_MAX slots (gsr_capi.hip: checkpoint_chunks)
+__host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (128 MB of slots at most)
 // with_ck_pool: false leaves the checkpoint pool out of `bytes` (it is the last section, so nothing else moves); the
 // pointer is still set and must not be used then (gsr_scratch_sizes / the blend entry points share one predicate)
 __host__ __device__ inline Image carve_image(void* base, int W, int H, bool with_ck_pool = true) {
@@ -156,13 +162,13 @@ __host__ __device__ inline Image carve_image(void* base, int W, int H, bool with
   im.work_meta = (uint32_t*)(p + off);  off += 256;
   im.work_est = (uint32_t*)(p + off);   off += sizeof(uint32_t) * 4 * T;  // (work_maxc follows without a gap)
   im.work_maxc = (uint32_t*)(p + off);  off = align_up(off + sizeof(uint32_t) * 4 * T);
-  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + 8 /* CK_MAX */ * (T < 2048 ? T : 2048)));
+  im.bwd_order = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * (2 * T + CK_MAX * ck_tiles(T)));
   im.bwd_meta = (uint32_t*)(p + off);   off += 256;
   im.queue_heads = (uint32_t*)(p + off); off += align_up(sizeof(uint32_t) * QUEUE_STRIDE * QUEUE_LINES * QUEUE_KINDS);
   im.ck_table = (uint32_t*)(p + off);   off += align_up(sizeof(uint32_t) * T);
-  im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * 8 /* CK_MAX */ * T);
+  im.ck_work = (uint32_t*)(p + off);    off += align_up(sizeof(uint32_t) * CK_MAX * T);
   im.tile_maxc = (uint32_t*)(p + off);  off += align_up(sizeof(uint32_t) * T);
-  im.ck_pool = (float4*)(p + off);      off += with_ck_pool ? align_up(sizeof(float4) * 256 * 8 /* CK_MAX */ * (T < 2048 ? T : 2048)) : 0;
+  im.ck_pool = (float4*)(p + off);      off += with_ck_pool ? align_up(sizeof(float4) * 256 * CK_MAX * ck_tiles(T)) : 0;
   im.bytes = off;
   return im;
 }

@@ -103,6 +103,7 @@ struct BlendArgs {
   uint32_t* tile_maxc;
   float4* ck_pool;
   int ck_chunks;   // checkpoint stride in 64-entry chunks
+  int ck_slots;    // checkpoint slots in use per tile (<= CK_MAX: the stride of the pool's layout)
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile_items;  // debug (backward): 4 x u64 per (tile, half) after the workgroup records, or null
   uint64_t* profile;

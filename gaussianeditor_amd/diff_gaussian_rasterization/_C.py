@@ -110,7 +110,7 @@ def _preprocess_and_bin(dev, P, D, M, means3D, scales, scale_modifier, rotations
         _ptr(cov3D_precomp), _ptr(colors), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos), W, H, tan_fovx, tan_fovy,
         int(bool(prefiltered)), int(skip_color), flags, radii.data_ptr(), geom.data_ptr(), counts))
     R, G = int(counts[0]), int(counts[1])
-    # (the image scratch is sized once R is known: its checkpoint pool, 64 MB at 1080p, exists only for views with long lists)
+    # (the image scratch is sized once R is known: its checkpoint pool, 128 MB at 1080p, exists only for views with long lists)
     _, bbytes, ibytes = _native.scratch_sizes(P, R, W, H, G)
     binning = torch.empty(bbytes, dtype=torch.uint8, device=dev)
     img = torch.empty(ibytes, dtype=torch.uint8, device=dev)

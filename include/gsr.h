@@ -98,7 +98,7 @@ int gsr_last_hip_error(void);
  * known (sizes[1] is then 0).
  * sizes[0] = geometry (per Gaussian), sizes[1] = binning (per instance),
  * sizes[2] = image (per pixel / tile).  sizes[2] with the real R may be smaller than with R = 0 (the forward's checkpoint
- * pool -- 32 KB per tile, 64 MB at most -- is only needed for views with long lists): a caller that allocates the image
+ * pool -- 64 KB per tile, 128 MB at most -- is only needed for views with long lists): a caller that allocates the image
  * scratch after gsr_preprocess saves it, one that sized it with R = 0 beforehand is always large enough.
  * REUSE: the entry points cannot see how large a scratch buffer is.  An image scratch that is kept and reused for later
  * views (or for a view rendered under the GSR_CK_CHUNKS knob) MUST have been sized with R = 0: one sized with a short-list

@@ -223,12 +223,14 @@ def test_backward_list_segments_match_the_oracle_when_forced_on_small_scenes():
     import subprocess
 
     # (strides below 4 chunks are clamped outside GSR_CK_DEBUG=1, round 5: they are inside the per-row parity bar)
-    env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_CK_DEBUG="1", GSR_BWD_SEG="1")
-    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
-                        "backward_vs_oracle or backward_precomp or forward_all_stages or edge_geometries or backward_twice"],
-                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
-    assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-    assert " passed" in p.stdout
+    # (round 6: sixteen checkpoint slots per tile with the fine stride, eight with the coarse one -- GSR_CK_SLOTS: both here)
+    for slots in ("16", "8", "5"):
+        env = dict(os.environ, GSR_CK_CHUNKS="1", GSR_CK_DEBUG="1", GSR_BWD_SEG="1", GSR_CK_SLOTS=slots)
+        p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-k",
+                            "backward_vs_oracle or backward_precomp or forward_all_stages or edge_geometries or backward_twice"],
+                           capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+        assert p.returncode == 0, (slots, (p.stdout + p.stderr)[-3000:])
+        assert " passed" in p.stdout
     # The three-way test's PER-ROW bar (a Gaussian's own gradient within 1e-3 of itself for all but 0.1 % of the rows) is
     # where a segment's start state shows: the colour behind a checkpoint is the difference of two binary32 accumulators of the
     # forward, so a Gaussian that only ever appears behind transmittance ~1e-3 gets its gradient to ~1e-4 instead of ~1e-6.
