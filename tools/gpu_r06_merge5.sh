@@ -13,7 +13,7 @@ prof() { # name -- command
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/$name -o p -- "$@" > /dev/null 2>&1)
   find $R/$O/$name -name "*.db" | head -1
 }
-for cfg in "--width 1920 --height 1080 --gaussians 6000000" "--gaussians 1000000"; do
+for cfg in ${CFGS:-"--width 1920 --height 1080 --gaussians 6000000" "--gaussians 1000000"}; do
   echo "== $cfg" | tee -a $O/${TAG}_kernels.txt
   DB=$(GSR_LIBRARY_PATH=$HEAD_LIB prof ${TAG}_h python $R/tools/c3_knobs.py $cfg)
   echo "head" | tee -a $O/${TAG}_kernels.txt
