@@ -50,9 +50,13 @@ def test_scratch_sizes_and_sort_bits():
     g1, b1, i1 = _native.scratch_sizes(2000, 5000, 640, 480, 1500)
     # grouped binning: 4 bytes per tile instance (the point list) + 12 per group instance (ping-pong group ids and indices)
     # (the image scratch sized before the counts are known, R = 0, includes the forward's checkpoint pool; with the counts of
-    #  a view with short lists it does not: 32 KB per tile less)
+    #  a view with short lists it does not: 64 KB per tile less -- room for 16 slots of 256 float4 each, round 6)
     assert b0 == 0 and b1 > 5000 * 4 + 1500 * 12 and g1 > g0 > 1000 * 48 and i0 > i1 > 640 * 480 * 8
-    assert i0 - i1 == 40 * 30 * 8 * 4096 and _native.scratch_sizes(2000, 2048 * 1200, 640, 480, 1500)[2] == i0
+    assert i0 - i1 == 40 * 30 * 16 * 4096 and _native.scratch_sizes(2000, 2048 * 1200, 640, 480, 1500)[2] == i0
+    # (images of up to 4 096 tiles checkpoint from a mean list of 1 200 entries per tile, larger ones from 2 048)
+    assert _native.scratch_sizes(2000, 1200 * 1200, 640, 480, 1500)[2] == i0 and _native.scratch_sizes(2000, 1200 * 1200 - 1, 640, 480, 1500)[2] == i1
+    hd0 = _native.scratch_sizes(2000, 0, 1920, 1080)[2]
+    assert _native.scratch_sizes(2000, 2048 * 8160, 1920, 1080, 1500)[2] == hd0 > _native.scratch_sizes(2000, 2048 * 8160 - 1, 1920, 1080, 1500)[2]
     assert _native.scratch_sizes(2000, 5000, 640, 480, 3000)[1] > b1
     # beyond 131 072 tiles (2048 groups of 8 x 8) the tile-pair sort: ping-pong tile ids (uint32 there) + ping-pong indices
     assert _native.scratch_sizes(2000, 5000, 5808, 5808)[1] > 5000 * 16
