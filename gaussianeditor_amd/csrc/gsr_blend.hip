@@ -1390,7 +1390,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   }
   // (BWD_SUB counters per bucket, chosen by the lane: see tile_worklist_kernel in gsr_binning.hip)
   constexpr int BWD_SUB = 16, NCNT = (BWD_BUCKETS + 1) * BWD_SUB;
-  constexpr int CK_TILES_MAX = 2048;  // (== ck_tiles(T) at most: the ranks of Image::ck_table)
+  constexpr int CK_TILES_MAX = CK_TILES_CAP;  // (ck_tiles(T) at most: the ranks of Image::ck_table)
   static_assert(BWD_BUCKETS <= 256, "a segment item's bucket is cached in one byte");
   __shared__ uint32_t cnt[NCNT];
   __shared__ uint32_t smem[1024 / 64 + 1];

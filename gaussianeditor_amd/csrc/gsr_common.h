@@ -146,7 +146,8 @@ constexpr int CK_MAX = 16;           // slots per tile: 15 checkpoints + the tai
 constexpr uint32_t CK_NONE = 0xffffffffu;
 constexpr int CK_CHUNKS_DEFAULT = 4;  // the FINE checkpoint stride in 64-entry chunks (256 list positions); the coarse one is twice that
 constexpr int CK_FINE_TILES = 1024;   // images of up to this many tiles take the fine stride with all CK_MAX slots (gsr_capi.hip: checkpoint_chunks)
-__host__ __device__ inline size_t ck_tiles(size_t T) { return T < 2048 ? T : 2048; }  // (128 MB of slots at most)
+constexpr int CK_TILES_CAP = 2048;    // tiles of a view that can own checkpoint slots: the ones with the longest lists (128 MB of slots at most)
+__host__ __device__ inline size_t ck_tiles(size_t T) { return T < (size_t)CK_TILES_CAP ? T : (size_t)CK_TILES_CAP; }
 // with_ck_pool: false leaves the checkpoint pool out of `bytes` (it is the last section, so nothing else moves); the
 // pointer is still set and must not be used then (gsr_scratch_sizes / the blend entry points share one predicate)
 __host__ __device__ inline Image carve_image(void* base, int W, int H, bool with_ck_pool = true) {
