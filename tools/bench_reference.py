@@ -21,8 +21,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--variant", default="fma")
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--gaussians", type=int, default=1_000_000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
 a = ap.parse_args()
-P, W, H = a.gaussians, 1920, 1080
+P, W, H = a.gaussians, a.width, a.height
 sc = synth_scene(P, seed=0, s0=0.01)
 cam = ring_cameras(8, W, H)[0]
 tfx, tfy = math.tan(cam.FoVx / 2), math.tan(cam.FoVy / 2)
@@ -74,5 +76,5 @@ t0 = time.perf_counter()
 for _ in range(a.steps):
     native_fwd(); native_bwd()
 tt = (time.perf_counter() - t0) / a.steps
-print(json.dumps({"what": f"reference .cu sources, hipcc -O3 ({a.variant}) on MI355X, same 1M/1080p view", "num_rendered": f["num_rendered"],
+print(json.dumps({"what": f"reference .cu sources, hipcc -O3 ({a.variant}) on MI355X, synth-v1 {P} Gaussians, {W}x{H}, ring view 0", "num_rendered": f["num_rendered"],
                   "forward_ms": 1e3 * tf, "train_iter_ms": 1e3 * tt, "forward_renders_per_s": 1 / tf, "train_iters_per_s": 1 / tt}))
