@@ -439,7 +439,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   constexpr bool ckpt = CKPT && !AUX;
   const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));  // pixel inside its tile
   const uint32_t ck_base = ckpt ? a.ck_table[tile] : CK_NONE;  // rank of the tile among the checkpointed ones
-  uint32_t ck_next = (ckpt && ck_base != CK_NONE) ? (uint32_t)a.ck_chunks : 0xffffffffu, ck_k = 1u;
+  uint32_t ck_next = (ckpt && ck_base != CK_NONE) ? (uint32_t)a.ck_pos.chunk[1] : 0xffffffffu, ck_k = 1u;
   auto stage = [&](uint32_t slot, float hA, float nB, float hC, float op, float x, float y, float z, float r, float g,
                    float b, float pos) {
     float* q = sp + (slot >> 1) * FWD_PAIR + (slot & 1u);
@@ -468,8 +468,8 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
           // (what this wave has evaluated so far: the backward's work list splits the tile's estimate with it)
           if (lane == 0) atomicAdd(&a.ck_work[(size_t)tile * (uint32_t)a.ck_slots + ck_k], evaluated);
         }
-        ck_next += (uint32_t)a.ck_chunks;
         ck_k++;
+        ck_next = ck_k < (uint32_t)a.ck_slots ? (uint32_t)a.ck_pos.chunk[ck_k] : 0xffffffffu;  // (the table is ascending)
       }
       uint64_t tc0 = 0;
       if (PROFILE) {
@@ -644,7 +644,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
     // ended in, as if its closing checkpoint had been reached: slot ck_k, or slot 0 once the tile's slots are used up (that
     // "segment" then reaches to the end of the list).  With it the colour of segment k is ALWAYS in slot k + 1 (k + 1 < ck_slots)
     // or in slot 0 (k = ck_slots - 1), whether the wave went on beyond it or not.
-    if (deep > (uint32_t)a.ck_chunks * WAVE && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
+    if (deep > a.ck_pos.pos(1u) && lane == 0) atomicMax(&a.tile_maxc[tile], deep);
     if (ck_k > 1u && pw.inside)
       a.ck_pool[((size_t)ck_base * (uint32_t)a.ck_slots + (ck_k < (uint32_t)a.ck_slots ? ck_k : 0u)) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
   }
@@ -781,10 +781,9 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
   if (tile_max == 0) return 0u;  // (uniform: nothing of the item's pixels ever contributed)
   // the list positions this item walks: all of [0, tile_max), or a run of strides of them (the stride of the last slot
   // reaches to the end of the list, and so does whatever stride holds the tile's deepest contributor)
-  const uint32_t stride = (uint32_t)a.ck_chunks * WAVE;
-  const uint32_t seg_lo = seg_item ? seg_first * stride : 0u;
+  const uint32_t seg_lo = seg_item ? a.ck_pos.pos(seg_first) : 0u;
   const uint32_t nslots = (uint32_t)a.ck_slots;  // slots in use per tile (<= CK_MAX), the stride of the pool and of ck_work
-  const uint32_t seg_hi = (seg_item && seg != nslots - 1u) ? min(tile_max, (seg + 1u) * stride) : tile_max;
+  const uint32_t seg_hi = (seg_item && seg != nslots - 1u) ? min(tile_max, a.ck_pos.pos(seg + 1u)) : tile_max;
   if (seg_lo >= seg_hi) return 0u;  // (uniform)
   PixelWave pw;
   const bool has_pixels = setup_wave(a, tile, half_item ? 2u * part + (uint32_t)(w >> 1) : (uint32_t)w, pw);
@@ -824,7 +823,9 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
     // C_final - C(seg_hi) it was a difference of two numbers near 1 divided by a small transmittance.
     const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
     const size_t slot0 = (size_t)a.ck_table[tile] * nslots;  // (slot k >= 1: T in front of position k * stride + segment k - 1's colour)
-    const uint32_t m = min((last_contributor - 1u) / stride, nslots - 1u);  // the segment of the pixel's last contributor
+    uint32_t m = 0u;  // the segment of the pixel's last contributor: the checkpoints at or in front of its position
+#pragma unroll
+    for (uint32_t k = 1u; k < (uint32_t)CK_MAX; ++k) m += (k < nslots && last_contributor - 1u >= a.ck_pos.pos(k)) ? 1u : 0u;
     float b0 = 0.f, b1 = 0.f, b2 = 0.f;
     // (wave-uniform bounds; a lane takes part from its own m down.  The two slot counts the library itself chooses get a
     //  loop with a constant upper end -- unrolled, as when CK_MAX was the only count: with both ends variable every
@@ -1357,7 +1358,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
                                                                 uint32_t workgroups, int allow_halves,  // allow_halves: 0, or the threshold in 1/8 of a fair share
                                                                 const ClearArgs clear, const uint32_t* __restrict__ tile_maxc,
                                                                 const uint32_t* __restrict__ ck_table,
-                                                                const uint32_t* __restrict__ ck_work, uint32_t stride,
+                                                                const uint32_t* __restrict__ ck_work, const CkTable ckp,
                                                                 uint32_t slots,   // checkpoint slots in use per tile (<= CK_MAX)
                                                                 int seg_share) {  // 0, or the threshold in 1/8 of a fair share
   if (blockIdx.x != 0) {
@@ -1416,6 +1417,7 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
   uint4 er[EST_REG];
   uint32_t deep[EST_REG];  // how far the backward walks the tile (0 unless deeper than one checkpoint stride)
   uint32_t rank[EST_REG];  // the tile's checkpoint rank (CK_NONE: it owns no slots)
+  const uint32_t stride = slots >= 2u ? ckp.pos(1u) : 0u;  // the first checkpoint: a tile the backward walks no deeper is never cut
   const bool segments = SEG && ck_table != nullptr && tile_maxc != nullptr && ck_work != nullptr && stride != 0u && slots >= 2u && seg_share > 0;
 #pragma unroll
   for (int j = 0; j < EST_REG; ++j) {
@@ -1476,7 +1478,9 @@ __global__ void __launch_bounds__(1024) backward_worklist_kernel(int T, const ui
     for_each_tile([&](int t, const uint4 e, uint32_t rk, uint32_t dp) {
       const uint32_t w = e.x + e.y + e.z + e.w;
       if (rk == CK_NONE || rk >= (uint32_t)CK_TILES_MAX || w < seg_threshold || dp <= stride) return;
-      const uint32_t ns = min((dp + stride - 1u) / stride, slots);
+      uint32_t ns = 1u;  // segments the backward's walk reaches into: one more than the checkpoints in front of its end
+#pragma unroll
+      for (uint32_t k = 1u; k < (uint32_t)CK_MAX; ++k) ns += (k < slots && ckp.pos(k) < dp) ? 1u : 0u;
       s_tile[rk] = (uint32_t)t | (ns << 20);
       s_queue[atomicAdd(&s_ncand, 1u)] = (uint16_t)rk;
     });
@@ -1676,11 +1680,11 @@ hipError_t launch_blend_backward(hipStream_t s, BlendArgs a) {
     if (seg_items)
       hipLaunchKernelGGL(backward_worklist_kernel<true>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
                          a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)a.tile_maxc,
-                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, (uint32_t)a.ck_chunks * WAVE, (uint32_t)a.ck_slots, seg_share);
+                         (const uint32_t*)a.ck_table, (const uint32_t*)a.ck_work, a.ck_pos, (uint32_t)a.ck_slots, seg_share);
     else
       hipLaunchKernelGGL(backward_worklist_kernel<false>, dim3(1u + fill_blocks), dim3(1024), 0, s, a.gx * a.gy, a.work_est,
                          a.bwd_order, a.bwd_meta, blend_grid_size(true, s, sh) / BWD_WAVES, halves, clear, (const uint32_t*)nullptr,
-                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, 0u, 0);
+                         (const uint32_t*)nullptr, (const uint32_t*)nullptr, CkTable{}, 0u, 0);
   }
   // #CUs x 4 workgroups of 4 waves: the same 4 waves per SIMD as the forward
   const dim3 g(blend_grid_size(true, s, sh) / BWD_WAVES), b(WAVE * BWD_WAVES);

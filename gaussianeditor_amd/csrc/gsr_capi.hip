@@ -217,9 +217,9 @@ inline int bin_legacy(int W, int H) {
   const int gx = (W + TILE - 1) / TILE, gy = (H + TILE - 1) / TILE;
   return (forced || group_count(W, H) > GROUP_MAX || gx > RECT32_EDGE || gy > RECT32_EDGE) ? 1 : 0;
 }
-// Checkpoint stride of the forward blend in 64-entry chunks, per view: 512 list positions where lists are LONG (deep-tile
-// scenes, 6 M Gaussians: the backward walks up to 7 000 positions of a tile's list; blend backward 438 -> 339 us and
-// 528 -> 314 us), 256 on small images (round 6, below), none where lists are short.  On the benchmark view (mean list 593 entries per tile) the heaviest backward
+// Whether a view's forward leaves checkpoints, and where the first one sits (in 64-entry chunks): where lists are LONG
+// (deep-tile scenes, 6 M Gaussians: the backward walks up to 7 000 positions of a tile's list; blend backward 438 -> 339 us
+// and 528 -> 314 us when introduced at a uniform 512 positions), none where they are short.  On the benchmark view (mean list 593 entries per tile) the heaviest backward
 // items are dense tiles walked 350-450 positions deep, the hundred longest within 13 % of each other and of a workgroup's
 // mean load: cutting them (stride 128 / 192 / 256, any work threshold) adds the per-item start-up of a few hundred more
 // items and buys no balance -- blend backward 219 -> 226-232 us in four same-box A/Bs (profiles/r04_d_segments.md) -- and at
@@ -239,33 +239,50 @@ inline int checkpoint_chunks(int64_t R, int W, int H) {
     return c > 1024 ? 1024 : c;
   }();
   if (env >= 0) return env;
-  // Round 6 (profiles/r06_m_fine_checkpoints.md): with 16 slots a tile a stride of 256 positions reaches as far as 512 did
-  // with 8, and most of what the stride sweeps of r06_k had charged to "fine strides" was the reach.  Images of up to
-  // CK_FINE_TILES tiles (the editor's 512 x 512: no more tiles than the backward has workgroups, so a tile MUST be cut to
-  // fill the chip) take the fine stride; images of up to 4 096 tiles turn checkpoints on from a mean list of 1 200
-  // entries, larger ones from 2 048.
-  // GSR_CK_MIN_LIST overrides the mean list length from which checkpoints are on (tuning knob).
+  // Round 6, second half (profiles/r06_m_fine_checkpoints.md, r06_n_checkpoint_table.md): what the stride sweeps of r06_k had
+  // charged to "fine strides" was the REACH of 8 slots; and what a tile needs is fine cuts where its work is -- in front,
+  // where its pixels are still live -- and reach for the stragglers behind.  Every view with checkpoints now takes all
+  // CK_MAX slots at the positions of `checkpoint_table`: 256 apart in front, 4 096 apart at the end, 16 384 of reach.
+  // Images of up to 4 096 tiles (few tiles per workgroup of the backward: a tile must be cut to fill the chip) turn
+  // checkpoints on from a mean list of 1 200 entries, larger ones from 2 048 (the 1080p synth-v2 view at 1 143 loses
+  // 18 % of its backward with them).  GSR_CK_MIN_LIST overrides the threshold (tuning knob).
   static const int64_t env_min_list = [] {
     const char* e = getenv("GSR_CK_MIN_LIST");
     return (int64_t)(e != nullptr && atoi(e) > 0 ? atoi(e) : 0);
   }();
   const int64_t T = (int64_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
   const int64_t min_list = env_min_list > 0 ? env_min_list : (T <= 4096 ? 1200 : 2048);
-  return R < min_list * T ? 0 : (T <= CK_FINE_TILES ? CK_CHUNKS_DEFAULT : 2 * CK_CHUNKS_DEFAULT);
+  return R < min_list * T ? 0 : CK_CHUNKS_DEFAULT;
 }
-// Checkpoint slots in use per tile: all CK_MAX with the fine stride, half of them with the coarse one -- the same 4 096
-// positions of reach either way (behind it the last segment is longer).  With 16 slots at 512 positions the deep-tile 1080p
-// view LOST 5 % (338 -> 354 us): the strides behind position 4 096 hold a few stragglers' work and every item that starts
-// in front of them sums their slots per pixel.  GSR_CK_SLOTS overrides (2 .. CK_MAX).
+// Checkpoint slots in use per tile: all CK_MAX (the pool and ck_work are laid out with the count in use as their stride).
+// GSR_CK_SLOTS overrides (2 .. CK_MAX; tests).
 inline int checkpoint_slots(int64_t R, int W, int H) {
   static const int env = [] {
     const char* e = getenv("GSR_CK_SLOTS");
     const int v = e != nullptr ? atoi(e) : 0;
     return v < 2 ? 0 : (v > CK_MAX ? CK_MAX : v);
   }();
-  if (env > 0) return env;
+  (void)R; (void)W; (void)H;
+  return env > 0 ? env : CK_MAX;
+}
+// The positions of a view's checkpoints (CkTable, gsr_common.h): 256 positions apart in front, then 512, 1 024, 2 048 and
+// 4 096 -- 16 384 of reach with 16 slots, the first 1 536 positions cut as finely as a uniform stride of 256 cuts them.
+// Measured against uniform tables of every stride on twenty views (profiles/r06_n_checkpoint_table.md): equal where lists
+// are short, 1.2-3x faster backward where they are long (a 512 x 512 view of 6 M Gaussians: K7 778 -> 247 us).
+// GSR_CK_CHUNKS (tests, sweeps) or GSR_CK_GEOM=0: uniform, k * stride.
+inline CkTable checkpoint_table(int64_t R, int W, int H) {
+  static const bool env_chunks = getenv("GSR_CK_CHUNKS") != nullptr;
+  static const bool geom = [] { const char* e = getenv("GSR_CK_GEOM"); return !(e && e[0] == '0'); }();
+  static const uint16_t fine[CK_MAX] = {0, 4, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 192, 256};
+  static_assert(CK_MAX == 16 && CK_CHUNKS_DEFAULT == 4, "the table above is written for 16 slots, the first 4 chunks in");
+  CkTable t;
   const int c = checkpoint_chunks(R, W, H);
-  return (c > 0 && c <= CK_CHUNKS_DEFAULT) ? CK_MAX : CK_MAX / 2;
+  const bool use_fine = geom && !env_chunks;
+  for (int k = 0; k < CK_MAX; ++k) {
+    const int u = k * c;
+    t.chunk[k] = use_fine ? fine[k] : (uint16_t)(u > 65535 ? 65535 : u);
+  }
+  return t;
 }
 // What the blend / export entry points need of the binning scratch sits in front of everything sized by the number of
 // group instances, so they carve with G = 0.
@@ -300,6 +317,7 @@ inline BlendArgs make_blend_args(int W, int H, const Geom& g, const Binning& b, 
   a.queue = im.queue_heads + (size_t)queue_kind * QUEUE_LINES * QUEUE_STRIDE;
   a.ck_chunks = checkpoint_chunks(R, W, H);
   a.ck_slots = checkpoint_slots(R, W, H);
+  a.ck_pos = checkpoint_table(R, W, H);
   if (a.ck_chunks > 0) {
     a.ck_table = im.ck_table;
     a.ck_work = im.ck_work;

@@ -137,15 +137,21 @@ struct Image {
   float4* ck_pool;      // (CK_TILES(T) x S x 256, room for S = CK_MAX)
   size_t bytes;
 };
-// Round 6 (second half): FINE checkpoints, COARSE items.  The stride that suits a view depends on how deep its pixels walk
-// their lists, which only the forward measures (profiles/r06_k_checkpoint_stride.md: 512 x 512 views want 256 positions, 1080p
-// views 384-512, the same image with another scene twice that).  So the forward checkpoints at the fine stride with twice the
-// slots (the same 4 096 positions of reach), and the backward's work list MERGES consecutive strides of a tile into items of
-// about equal measured work (backward_worklist_kernel): the item size follows the view, not a constant.
-constexpr int CK_MAX = 16;           // slots per tile: 15 checkpoints + the tail (beyond that depth the last segment is longer)
+// Round 6 (second half): sixteen slots per tile instead of eight, at positions that are fine in front and coarse behind
+// (CkTable below; gsr_capi.hip: checkpoint_table).  profiles/r06_m_fine_checkpoints.md, r06_n_checkpoint_table.md.
+constexpr int CK_MAX = 16;           // slots per tile: 15 checkpoints + the tail (beyond the last one the last segment is longer)
 constexpr uint32_t CK_NONE = 0xffffffffu;
-constexpr int CK_CHUNKS_DEFAULT = 4;  // the FINE checkpoint stride in 64-entry chunks (256 list positions); the coarse one is twice that
-constexpr int CK_FINE_TILES = 1024;   // images of up to this many tiles take the fine stride with all CK_MAX slots (gsr_capi.hip: checkpoint_chunks)
+constexpr int CK_CHUNKS_DEFAULT = 4;  // the first checkpoint, in 64-entry chunks (256 list positions), where checkpoints are on
+// Where a view's checkpoints sit: checkpoint k (1 <= k < slots) lies in front of list position 64 * chunk[k]; chunk[0] = 0,
+// ascending.  Uniform (k * stride) or -- the small-image class, round 6 -- FINE IN FRONT, COARSE BEHIND: the work of a tile
+// sits where its pixels are still live, in the front of its list, and the deep positions are walked for a few stragglers;
+// how deep "the front" is depends on the scene, which only the forward measures (a 512 x 512 view of 1 M Gaussians wants
+// strides of 256 and 3 000 positions of reach, the same image of 3 M or a 256 x 256 one wants 12 000 of reach:
+// profiles/r06_n).  Passed by value to the three kernels that read it.
+struct CkTable {
+  uint16_t chunk[CK_MAX];
+  __host__ __device__ inline uint32_t pos(uint32_t k) const { return (uint32_t)chunk[k] * 64u; }
+};
 constexpr int CK_TILES_CAP = 2048;    // tiles of a view that can own checkpoint slots: the ones with the longest lists (128 MB of slots at most)
 __host__ __device__ inline size_t ck_tiles(size_t T) { return T < (size_t)CK_TILES_CAP ? T : (size_t)CK_TILES_CAP; }
 // with_ck_pool: false leaves the checkpoint pool out of `bytes` (it is the last section, so nothing else moves); the

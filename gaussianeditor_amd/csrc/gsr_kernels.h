@@ -104,6 +104,7 @@ struct BlendArgs {
   float4* ck_pool;
   int ck_chunks;   // checkpoint stride in 64-entry chunks
   int ck_slots;    // checkpoint slots in use per tile (<= CK_MAX: the stride of the pool's layout)
+  CkTable ck_pos;  // list position of every checkpoint, in 64-entry chunks (gsr_common.h; pos[1] == ck_chunks)
   // debug: per-workgroup timing records (4 x u64 each), or null
   uint64_t* profile_items;  // debug (backward): 4 x u64 per (tile, half) after the workgroup records, or null
   uint64_t* profile;
