@@ -275,12 +275,29 @@ inline CkTable checkpoint_table(int64_t R, int W, int H) {
   static const bool geom = [] { const char* e = getenv("GSR_CK_GEOM"); return !(e && e[0] == '0'); }();
   static const uint16_t fine[CK_MAX] = {0, 4, 8, 12, 16, 20, 24, 32, 40, 48, 64, 80, 96, 128, 192, 256};
   static_assert(CK_MAX == 16 && CK_CHUNKS_DEFAULT == 4, "the table above is written for 16 slots, the first 4 chunks in");
+  // GSR_CK_TABLE="c1,c2,...,c15" (sweeps): the checkpoints' positions in 64-entry chunks, ascending
+  static const CkTable env_table = [] {
+    CkTable e;
+    memset(&e, 0, sizeof(e));
+    const char* p = getenv("GSR_CK_TABLE");
+    for (int k = 1; p != nullptr && *p && k < CK_MAX; ++k) {
+      const long v = strtol(p, const_cast<char**>(&p), 10);
+      e.chunk[k] = (uint16_t)(v > e.chunk[k - 1] ? (v > 65535 ? 65535 : v) : e.chunk[k - 1] + 1);
+      if (*p == ',') ++p;
+      if (k == CK_MAX - 1) e.chunk[0] = 1;  // (marks a complete table; put back to 0 below)
+    }
+    return e;
+  }();
   CkTable t;
   const int c = checkpoint_chunks(R, W, H);
   const bool use_fine = geom && !env_chunks;
   for (int k = 0; k < CK_MAX; ++k) {
     const int u = k * c;
     t.chunk[k] = use_fine ? fine[k] : (uint16_t)(u > 65535 ? 65535 : u);
+  }
+  if (use_fine && env_table.chunk[0] == 1) {
+    t = env_table;
+    t.chunk[0] = 0;
   }
   return t;
 }
