@@ -432,7 +432,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
   // carries its own magnitude's rounding only.
   f32x2 S01 = {0.f, 0.f};
   float S2 = 0.f;
-  // Checkpoints for the backward's list segments (Image::ck_*): in front of list position k * stride the state of every
+  // Checkpoints for the backward's list segments (Image::ck_*): in front of list position pos(k) (CkTable) the state of every
   // pixel that is still live -- transmittance and accumulated colour -- goes into the tile's slot k (one 16-byte store per
   // lane and one atomic per wave: the slots are assigned by tile_worklist_kernel, nothing is allocated here).
   // (CKPT: a template switch, chosen per view by the host -- views with short lists run the kernel without any of this)
@@ -459,7 +459,7 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       if (live_m == 0) break;
       if (ckpt && walk.chunk == ck_next) {  // (uniform; never for walks shorter than the stride)
         if (ck_k < (uint32_t)a.ck_slots) {
-          // slot k: T in front of position k * stride, and the colour of segment k - 1.  Written by every pixel of the
+          // slot k: T in front of position pos(k), and the colour of segment k - 1.  Written by every pixel of the
           // quadrant (a saturated one writes zeros: the backward never reads them, but it may read the slots of a pixel that
           // is live and simply found nothing to blend)
           if (pw.inside) a.ck_pool[((size_t)ck_base * (uint32_t)a.ck_slots + ck_k) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
@@ -741,8 +741,9 @@ constexpr int BWD_WAVES = 4;  // one workgroup = the four quadrants of one tile 
 constexpr int ACC_LDS_ROW = 9;  // floats per chunk slot of the backward's LDS accumulators: the nine raw moments
 constexpr uint32_t BWD_ITEM_HALF = 0x80000000u;   // item code: the workgroup handles one half of the tile ...
 constexpr uint32_t BWD_ITEM_PART = 0x40000000u;   // ... quadrants {2,3} instead of {0,1}
-// ... or (round 4) A RUN OF LIST SEGMENTS of a deep tile: the checkpoint strides lo .. hi of its list, i.e. positions
-// [lo * stride, (hi + 1) * stride), a run that ends with the tile's last stride up to the tile's deepest contributor.  The
+// ... or (round 4) A RUN OF LIST SEGMENTS of a deep tile: the segments lo .. hi between its checkpoints, i.e. positions
+// [pos(lo), pos(hi + 1)) of its list (CkTable: where a view's checkpoints sit), a run that ends with the tile's last segment
+// up to the tile's deepest contributor.  The
 // pixels that still contribute behind the run start from the forward's checkpoint in front of its upper end instead of from
 // their final state (backward_tile).  The work list makes one item per stride (lo == hi): runs of several strides, merged
 // to about equal measured work, were measured in round 6 and bought nothing (profiles/r06_m_fine_checkpoints.md).
@@ -822,7 +823,7 @@ __device__ __forceinline__ uint32_t backward_tile(const BlendArgs& a, const uint
     // zero: slot k + 1 holds segment k's, slot 0 that of segment CK_MAX - 1 and everything after it), smallest first -- as
     // C_final - C(seg_hi) it was a difference of two numbers near 1 divided by a small transmittance.
     const uint32_t pidx = (uint32_t)((pw.py & (TILE - 1)) * TILE + (pw.px & (TILE - 1)));
-    const size_t slot0 = (size_t)a.ck_table[tile] * nslots;  // (slot k >= 1: T in front of position k * stride + segment k - 1's colour)
+    const size_t slot0 = (size_t)a.ck_table[tile] * nslots;  // (slot k >= 1: T in front of position pos(k) + segment k - 1's colour)
     uint32_t m = 0u;  // the segment of the pixel's last contributor: the checkpoints at or in front of its position
 #pragma unroll
     for (uint32_t k = 1u; k < (uint32_t)CK_MAX; ++k) m += (k < nslots && last_contributor - 1u >= a.ck_pos.pos(k)) ? 1u : 0u;

@@ -126,8 +126,8 @@ struct Image {
   uint32_t* queue_heads;// (QUEUE_KINDS x QUEUE_LINES) work-queue cursors + retire counters, QUEUE_STRIDE words apart
   // Checkpoints of the forward blend (round 4): the backward can then walk a tile's list as independent SEGMENTS in
   // separate work items.  A checkpoint of a pixel is one float4, a checkpoint of a tile 256 of them: slot k >= 1 holds the
-  // transmittance in front of list position k * stride and (round 5) the colour segment k - 1 -- positions [(k - 1) stride,
-  // k stride) -- contributed, accumulated from zero; slot 0 the colour of segment CK_MAX - 1 and everything behind it.  The
+  // transmittance in front of list position pos(k) (CkTable below) and (round 5) the colour segment k - 1 -- positions
+  // [pos(k - 1), pos(k)) -- contributed, accumulated from zero; slot 0 the colour of segment CK_MAX - 1 and everything behind it.  The
   // CK_TILES(T) tiles with the longest lists own CK_MAX consecutive 4 KB slots each, assigned by tile_worklist_kernel -- no
   // allocation, no atomics in the forward's loop.
   uint32_t* ck_table;   // (T)  the tile's rank among the checkpointed tiles (its slots: rank * S + k, S = the slots the view uses, <= CK_MAX), or CK_NONE
