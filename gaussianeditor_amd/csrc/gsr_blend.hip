@@ -649,7 +649,8 @@ __device__ __forceinline__ void forward_item(const BlendArgs& a, uint32_t tile, 
       a.ck_pool[((size_t)ck_base * (uint32_t)a.ck_slots + (ck_k < (uint32_t)a.ck_slots ? ck_k : 0u)) * (TILE * TILE) + pidx] = make_float4(T, S01.x, S01.y, S2);
   }
   // the backward's work estimate and walk depth for the quadrant.  One item per quadrant: plain stores; the sub-items of a
-  // cut quadrant report the largest of their values (they walk the same list).
+  // cut quadrant report the largest of their values (they walk the same list; their SUM as the estimate was measured and is
+  // worse, profiles/r06_s_forward_split.md).
   if (a.work_est != nullptr && lane == 0) {
     if (SPLIT == 1) {
       a.work_est[4u * tile + quad] = evaluated;
@@ -1627,7 +1628,15 @@ hipError_t launch_blend_forward(hipStream_t s, BlendArgs a) {
   a.allow_split = split_ok ? 1 : 0;
   // fewer than two quadrant items per persistent wave (bounded by the tile count of the image): cut the quadrants
   const unsigned grid = blend_grid_size(false, s, sh), quads = 4u * (unsigned)(a.gx * a.gy);
-  const int split = !a.allow_split || quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
+  // GSR_FWD_SPLIT_FORCE=1|2|4 (sweeps): the cut of the forward's quadrants whatever the image
+  static const int split_force = [] { const char* e = getenv("GSR_FWD_SPLIT_FORCE"); const int v = e ? atoi(e) : 0; return (v == 1 || v == 2 || v == 4) ? v : 0; }();
+  // A render that will see a backward cuts later (round 6, profiles/r06_s_forward_split.md): the cut costs the BACKWARD --
+  // a quadrant's work estimate is then the largest count among its sub-items, the tile's checkpoint row their sum, and
+  // the backward's work list orders and cuts by both -- 5-35 % of K7 on images of 320 x 320 .. 720 x 720, more than the
+  // forward gains.  Forward-only renders keep the cut that is best for the forward alone.
+  const int split_alone = quads >= 2u * grid ? 1 : (2u * quads >= 2u * grid ? 2 : 4);
+  const int split_train = quads > grid ? 1 : (4u * quads > grid ? 2 : 4);
+  const int split = split_force ? split_force : (!a.allow_split ? 1 : (a.for_backward ? split_train : split_alone));
   const dim3 g(grid), b(WAVE);
 #define GSR_FWD_LAUNCH(AUXV, FASTV, CKV)                                                                        \
   do {                                                                                                          \

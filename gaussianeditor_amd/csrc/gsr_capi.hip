@@ -615,6 +615,7 @@ int gsr_blend_forward(void* stream, int P, int64_t R, int W, int H, const float*
   a.out_depth = out_depth;
   a.fast_exp = (flags & GSR_FLAG_FAST_EXP) ? 1 : 0;
   a.shared_simds = (flags & GSR_FLAG_SHARED_SIMDS) ? 1 : 0;
+  a.for_backward = (flags & GSR_FLAG_FORWARD_ONLY) ? 0 : 1;
   GSR_HIP(launch_blend_forward((hipStream_t)stream, a));
   return GSR_OK;
 }

@@ -96,6 +96,7 @@ struct BlendArgs {
   int shared_simds;  // GSR_FLAG_SHARED_SIMDS: 2 persistent waves per SIMD instead of 4 (another stream's kernels run alongside)
   int self_reset;  // the last workgroup to retire clears the queue cursors (default)
   int allow_split; // forward: quadrants may be cut into 2 or 4 items when the image has few tiles (run_work_queue)
+  int for_backward; // forward: the render's state will be read by a backward (not GSR_FLAG_FORWARD_ONLY, not an auxiliary render)
   int units;       // placement units (SIMDs or CUs) for the assigned first items, 0 = none; gsr_blend.hip: first_item_of_block
   // forward checkpoints / backward list segments (Image::ck_*); ck_table == null: none (auxiliary render, tracing)
   uint32_t* ck_table;
